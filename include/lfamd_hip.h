@@ -1,0 +1,117 @@
+/*
+ * lfamd_hip.h — C ABI of the MI355X (gfx950) quantized-matmul module, libllamafile_amd_hip.so.
+ *
+ * This is the thin device-side boundary the host plug-in (include/llamafile_sgemm.h) dlopen()s,
+ * the way the reference's llamafile/cuda.c:701-753 dlopen()s ggml-rocm.so and imports a fixed
+ * symbol list.  The reference's module exposes a whole ggml backend (12 symbols, cuda.c:726-737);
+ * this tier only accelerates GGML_OP_MUL_MAT / MUL_MAT_ID, so the ABI is the small set below:
+ * plain pointers and sizes, no C++/torch types.  Every function returns 0 on success or a
+ * negative lfamd_status; lfamd_last_error() gives a message.  Nothing here falls back to the CPU.
+ *
+ * Reference counterparts (paths relative to /root/reference):
+ *   lfamd_pack_weights   <- ggml_backend_cuda_buffer_set_tensor (weights upload; the backend owns
+ *                           the device copy and may re-lay it out), ggml-cuda.cu.patch:16971-16977
+ *   lfamd_mul_mat        <- ggml_cuda_mul_mat policy + ggml_cuda_op_mul_mat_vec_q / _mul_mat_q,
+ *                           ggml-cuda.cu.patch:18377-18443, 14714-14806, 14188-14284;
+ *                           numerics follow the CPU path llamafile_sgemm, tinyblas_cpu_sgemm.inc:274-331
+ *   lfamd_mul_mat_id     <- ggml_cuda_mul_mat_id, ggml-cuda.cu.patch:18499-18635; numerics follow
+ *                           iqk_mul_mat_moe (iqk_mul_mat.inc:204-221) / llamafile_mixmul
+ *   lfamd_quantize_rows  <- quantize_q8_1 (ggml-cuda.cu.patch:15259-15293); formats follow the CPU
+ *                           vec_dot types Q8_0 / Q8_1 / Q8_K
+ */
+#ifndef LFAMD_HIP_H_
+#define LFAMD_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LFAMD_ABI_VERSION 1
+
+enum lfamd_status {
+    LFAMD_OK = 0,
+    LFAMD_ERR_UNSUPPORTED = -1, /* type / shape this module has no kernel for (caller decides) */
+    LFAMD_ERR_INVALID = -2,     /* precondition violated (the reference asserts) */
+    LFAMD_ERR_HIP = -3,         /* HIP runtime error; see lfamd_last_error() */
+    LFAMD_ERR_WORKSPACE = -4,   /* workspace too small */
+};
+
+/* numerics flags for lfamd_mul_mat */
+#define LFAMD_FLAG_Q0_VREGS32 1u /* restate the reference's 32-vector-register (AVX512) build of
+                                    tinyBLAS_Q0: Kahan on 2x1/1x2/1x1 edge tiles (tinyblas_cpu.h:797-830) */
+#define LFAMD_FLAG_PRECISE 2u    /* FLAG_precise (--precise): Kahan everywhere in the Q0 kernels */
+#define LFAMD_FLAG_FORCE_GENERIC 4u /* debugging: route through the generic (untuned) kernel */
+
+int lfamd_abi_version(void);
+const char *lfamd_last_error(void);
+
+/* Device management. */
+int lfamd_device_count(void);
+int lfamd_init(int device); /* hipSetDevice + arch check (gfx950 required) */
+int lfamd_device_name(int device, char *buf, size_t len);
+
+/* Device memory (thin wrappers so a C host needs no HIP headers). */
+int lfamd_malloc(void **dptr, size_t bytes);
+int lfamd_free(void *dptr);
+int lfamd_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream);
+int lfamd_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream);
+int lfamd_memset(void *dst, int value, size_t bytes, void *stream);
+int lfamd_stream_sync(void *stream);
+
+/* ---- weights ----------------------------------------------------------------------------
+ * Weights are kept on the device in a PACKED layout chosen per type so that every kernel reads
+ * them with coalesced 16-byte-per-lane loads (DESIGN.md "Data layout in HBM").  `raw` is the
+ * tensor exactly as GGUF/ggml stores it: `rows` rows, `raw_row_bytes` apart, each a sequence of
+ * blocks (include/lfamd_blocks.h).  Packing is a device kernel: raw and packed are device
+ * pointers. */
+size_t lfamd_packed_size(int type, long rows, long cols);
+int lfamd_pack_weights(int type, long rows, long cols, const void *d_raw, size_t raw_row_bytes,
+                       void *d_packed, void *stream);
+
+/* ---- activations --------------------------------------------------------------------------
+ * f32 rows -> the reference's activation block format (vec_dot_type: Q8_0, Q8_1 or Q8_K in
+ * llamafile's field order).  Same rounding as the scalar reference quantisers. */
+int lfamd_quantize_rows(int vec_dot_type, const float *d_x, long nrows, long cols, size_t x_row_bytes,
+                        void *d_y, size_t y_row_bytes, void *stream);
+
+/* ---- GGML_OP_MUL_MAT -----------------------------------------------------------------------
+ * C[j*ldc + i] = sum_l A[i][l] * B[j][l]   (C = A^T B, column-major C like llamafile_sgemm)
+ *   A: packed weights (lfamd_pack_weights), m rows x k elements, type Atype
+ *   B: n rows in the reference's activation format Btype (= vec_dot_type of Atype), row stride
+ *      b_row_bytes
+ *   C: f32, ldc >= m
+ * Policy (cf. ggml_cuda_mul_mat): n <= 8 -> wave-reduction GEMV kernels, else dequant-to-MFMA
+ * GEMM.  `workspace` must hold lfamd_mul_mat_workspace() bytes (may be NULL if that is 0). */
+size_t lfamd_mul_mat_workspace(int Atype, long m, long k, long n);
+int lfamd_mul_mat(int Atype, const void *d_A_packed, long m, long k, int Btype, const void *d_B,
+                  size_t b_row_bytes, long n, float *d_C, long ldc, void *d_workspace,
+                  size_t workspace_bytes, unsigned flags, void *stream);
+
+/* ---- GGML_OP_MUL_MAT_ID (mixture of experts) -------------------------------------------------
+ * For every (token, thinker): result[token][thinker][:] = W[plan[token][thinker]] x
+ * thought[token][thinker % tasks][:]   (tinyblas_cpu_mixmul.inc:39-50).
+ *   d_W_packed: `experts` packed matrices, each lfamd_packed_size(type, rows, cols) bytes apart
+ *   d_thought : activation rows in vec_dot format, index (token*tasks + task), stride b_row_bytes
+ *   d_plan    : int32 [tokens][thinkers]
+ *   d_result  : f32 [tokens][thinkers][rows] */
+size_t lfamd_mul_mat_id_workspace(int type, long rows, long cols, int experts, long tokens, int thinkers);
+int lfamd_mul_mat_id(int type, const void *d_W_packed, long rows, long cols, int experts, int Btype,
+                     const void *d_thought, size_t b_row_bytes, int tasks, long tokens,
+                     const int32_t *d_plan, int thinkers, float *d_result, void *d_workspace,
+                     size_t workspace_bytes, unsigned flags, void *stream);
+
+/* ---- instrumentation ------------------------------------------------------------------------
+ * Average device time (microseconds, HIP events on `stream`) of `iters` back-to-back launches of
+ * the same lfamd_mul_mat call, after `warmup` untimed ones. */
+int lfamd_time_mul_mat(int Atype, const void *d_A_packed, long m, long k, int Btype, const void *d_B,
+                       size_t b_row_bytes, long n, float *d_C, long ldc, void *d_workspace,
+                       size_t workspace_bytes, unsigned flags, void *stream, int warmup, int iters,
+                       float *avg_us);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LFAMD_HIP_H_ */

@@ -1,0 +1,307 @@
+// api.hip — the C ABI of libllamafile_amd_hip.so (include/lfamd_hip.h).
+//
+// Dispatch policy mirrors ggml_cuda_mul_mat (ggml-cuda.cu.patch:18377-18443): n <= 8 -> GEMV
+// kernels (MMVQ_MAX_BATCH_SIZE = 8, :14359), otherwise the MFMA GEMM; types without a tuned kernel
+// run the generic kernel.  There is no CPU fallback anywhere in this module.
+#include "lfamd_device.h"
+#include "../../include/lfamd_hip.h"
+
+#include <stdio.h>
+#include <string.h>
+
+extern "C" {
+hipError_t lfamd_launch_pack_q4k(const void *, size_t, long, long, void *, hipStream_t);
+hipError_t lfamd_launch_pack_q6k(const void *, size_t, long, long, void *, hipStream_t);
+hipError_t lfamd_launch_pack_q80(const void *, size_t, long, long, void *, hipStream_t);
+hipError_t lfamd_launch_pack_raw(const void *, size_t, long, size_t, void *, hipStream_t);
+hipError_t lfamd_launch_prep_q8k(const void *, size_t, long, long, long, void *, void *, void *, hipStream_t);
+hipError_t lfamd_launch_generic(int, const void *, long, long, int, const void *, size_t, long, float *, long, hipStream_t);
+hipError_t lfamd_launch_gemv(int, const void *, long, long, const void *, size_t, long, float *, long, int, int,
+                             hipStream_t);
+hipError_t lfamd_launch_gemm_kq(int, const void *, long, long, const void *, const void *, const void *, long, long,
+                                float *, long, hipStream_t);
+hipError_t lfamd_launch_quantize(int, const float *, long, long, size_t, void *, size_t, hipStream_t);
+hipError_t lfamd_launch_moe(int, const void *, long, long, int, size_t, int, const void *, size_t, int, long,
+                            const int32_t *, int, float *, void *, size_t, unsigned, hipStream_t);
+size_t lfamd_moe_workspace(int, long, long, int, long, int);
+}
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, const char *detail) {
+    snprintf(g_err, sizeof(g_err), fmt, detail);
+    return code;
+}
+
+static int hip_fail(hipError_t e, const char *where) {
+    snprintf(g_err, sizeof(g_err), "%s: %s", where, hipGetErrorString(e));
+    return LFAMD_ERR_HIP;
+}
+
+#define HIPCHK(expr, where)                                                                                            \
+    do {                                                                                                               \
+        hipError_t e_ = (expr);                                                                                        \
+        if (e_ != hipSuccess)                                                                                          \
+            return hip_fail(e_, where);                                                                                \
+    } while (0)
+
+static inline size_t align_up(size_t x, size_t a) {
+    return (x + a - 1) / a * a;
+}
+
+extern "C" {
+
+int lfamd_abi_version(void) {
+    return LFAMD_ABI_VERSION;
+}
+
+const char *lfamd_last_error(void) {
+    return g_err;
+}
+
+int lfamd_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+        return 0;
+    return n;
+}
+
+int lfamd_device_name(int device, char *buf, size_t len) {
+    hipDeviceProp_t p;
+    HIPCHK(hipGetDeviceProperties(&p, device), "hipGetDeviceProperties");
+    snprintf(buf, len, "%s (%s)", p.name, p.gcnArchName);
+    return LFAMD_OK;
+}
+
+int lfamd_init(int device) {
+    hipDeviceProp_t p;
+    HIPCHK(hipGetDeviceProperties(&p, device), "hipGetDeviceProperties");
+    if (strncmp(p.gcnArchName, "gfx950", 6) != 0)
+        return fail(LFAMD_ERR_UNSUPPORTED, "device arch %s is not gfx950 (MI355X); this module has no other code objects",
+                    p.gcnArchName);
+    HIPCHK(hipSetDevice(device), "hipSetDevice");
+    return LFAMD_OK;
+}
+
+int lfamd_malloc(void **dptr, size_t bytes) {
+    HIPCHK(hipMalloc(dptr, bytes ? bytes : 16), "hipMalloc");
+    return LFAMD_OK;
+}
+int lfamd_free(void *dptr) {
+    HIPCHK(hipFree(dptr), "hipFree");
+    return LFAMD_OK;
+}
+int lfamd_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream) {
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream), "hipMemcpyAsync h2d");
+    return LFAMD_OK;
+}
+int lfamd_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream) {
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream), "hipMemcpyAsync d2h");
+    return LFAMD_OK;
+}
+int lfamd_memset(void *dst, int value, size_t bytes, void *stream) {
+    HIPCHK(hipMemsetAsync(dst, value, bytes, (hipStream_t)stream), "hipMemsetAsync");
+    return LFAMD_OK;
+}
+int lfamd_stream_sync(void *stream) {
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream), "hipStreamSynchronize");
+    return LFAMD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+
+static bool type_known(int t) {
+    switch (t) {
+    case LFAMD_TYPE_F32:
+    case LFAMD_TYPE_F16:
+    case LFAMD_TYPE_BF16:
+    case LFAMD_TYPE_Q4_0:
+    case LFAMD_TYPE_Q4_1:
+    case LFAMD_TYPE_Q5_0:
+    case LFAMD_TYPE_Q5_1:
+    case LFAMD_TYPE_Q8_0:
+    case LFAMD_TYPE_Q2_K:
+    case LFAMD_TYPE_Q3_K:
+    case LFAMD_TYPE_Q4_K:
+    case LFAMD_TYPE_Q5_K:
+    case LFAMD_TYPE_Q6_K:
+    case LFAMD_TYPE_IQ4_XS:
+        return true;
+    default:
+        return false;
+    }
+}
+
+size_t lfamd_packed_size(int type, long rows, long cols) {
+    if (!type_known(type) || rows < 0 || cols < 0 || cols % lfamd_blck_size(type))
+        return 0;
+    switch (type) {
+    case LFAMD_TYPE_Q4_K:
+        return (size_t)((rows + 31) / 32) * (size_t)(cols / 256) * P4K_TILE;
+    case LFAMD_TYPE_Q6_K:
+        return (size_t)((rows + 31) / 32) * (size_t)(cols / 256) * P6K_TILE;
+    case LFAMD_TYPE_Q8_0:
+        return (size_t)((rows + 7) / 8) * (size_t)((cols / 32 + 3) / 4) * P80_TILE;
+    default:
+        return (size_t)rows * lfamd_row_size(type, cols);
+    }
+}
+
+int lfamd_pack_weights(int type, long rows, long cols, const void *d_raw, size_t raw_row_bytes, void *d_packed,
+                       void *stream) {
+    if (!type_known(type))
+        return fail(LFAMD_ERR_UNSUPPORTED, "pack_weights: unsupported ggml type%s", "");
+    if (rows < 0 || cols < 0 || cols % lfamd_blck_size(type) || raw_row_bytes < lfamd_row_size(type, cols))
+        return fail(LFAMD_ERR_INVALID, "pack_weights: bad shape%s", "");
+    if (rows == 0 || cols == 0)
+        return LFAMD_OK;
+    hipStream_t s = (hipStream_t)stream;
+    switch (type) {
+    case LFAMD_TYPE_Q4_K:
+        HIPCHK(lfamd_launch_pack_q4k(d_raw, raw_row_bytes, rows, cols, d_packed, s), "pack_q4k");
+        break;
+    case LFAMD_TYPE_Q6_K:
+        HIPCHK(lfamd_launch_pack_q6k(d_raw, raw_row_bytes, rows, cols, d_packed, s), "pack_q6k");
+        break;
+    case LFAMD_TYPE_Q8_0:
+        HIPCHK(lfamd_launch_pack_q80(d_raw, raw_row_bytes, rows, cols, d_packed, s), "pack_q80");
+        break;
+    default:
+        HIPCHK(lfamd_launch_pack_raw(d_raw, raw_row_bytes, rows, lfamd_row_size(type, cols), d_packed, s), "pack_raw");
+    }
+    return LFAMD_OK;
+}
+
+int lfamd_quantize_rows(int vec_dot_type, const float *d_x, long nrows, long cols, size_t x_row_bytes, void *d_y,
+                        size_t y_row_bytes, void *stream) {
+    if (vec_dot_type != LFAMD_TYPE_Q8_0 && vec_dot_type != LFAMD_TYPE_Q8_1 && vec_dot_type != LFAMD_TYPE_Q8_K)
+        return fail(LFAMD_ERR_UNSUPPORTED, "quantize_rows: unsupported activation type%s", "");
+    if (cols % lfamd_blck_size(vec_dot_type) || y_row_bytes < lfamd_row_size(vec_dot_type, cols))
+        return fail(LFAMD_ERR_INVALID, "quantize_rows: bad shape%s", "");
+    HIPCHK(lfamd_launch_quantize(vec_dot_type, d_x, nrows, cols, x_row_bytes, d_y, y_row_bytes, (hipStream_t)stream),
+           "quantize_rows");
+    return LFAMD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+
+static bool use_gemm(int Atype, long n, unsigned flags) {
+    if (flags & LFAMD_FLAG_FORCE_GENERIC)
+        return false;
+    return n > 8 && (Atype == LFAMD_TYPE_Q4_K || Atype == LFAMD_TYPE_Q6_K);
+}
+
+static bool use_gemv(int Atype, long n, unsigned flags) {
+    if (flags & LFAMD_FLAG_FORCE_GENERIC)
+        return false;
+    if (Atype == LFAMD_TYPE_Q8_0)
+        return true; // the bit-exact kernel services every n for Q8_0 (column tiles of 8)
+    return n <= 8 && (Atype == LFAMD_TYPE_Q4_K || Atype == LFAMD_TYPE_Q6_K);
+}
+
+size_t lfamd_mul_mat_workspace(int Atype, long m, long k, long n) {
+    (void)m;
+    if (!use_gemm(Atype, n, 0))
+        return 0;
+    size_t n_pad = align_up((size_t)n, 64), nb = (size_t)(k / 256);
+    return align_up(n_pad * (size_t)k * 2, 256) + align_up(nb * n_pad * 4, 256) + align_up(n_pad * nb * 32, 256);
+}
+
+int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const void *d_B, size_t b_row_bytes, long n,
+                  float *d_C, long ldc, void *d_ws, size_t ws_bytes, unsigned flags, void *stream) {
+    if (!type_known(Atype))
+        return fail(LFAMD_ERR_UNSUPPORTED, "mul_mat: unsupported weight type%s", "");
+    if (m < 0 || n < 0 || k < 0 || ldc < m || k % lfamd_blck_size(Atype))
+        return fail(LFAMD_ERR_INVALID, "mul_mat: bad shape%s", "");
+    const int vdt = lfamd_vec_dot_type(Atype);
+    const bool float_a = Atype == LFAMD_TYPE_F32 || Atype == LFAMD_TYPE_F16 || Atype == LFAMD_TYPE_BF16;
+    if (float_a) {
+        if (!(Btype == LFAMD_TYPE_F32 || Btype == Atype))
+            return fail(LFAMD_ERR_UNSUPPORTED, "mul_mat: float weights need F32 or same-type activations%s", "");
+    } else if (Btype != vdt) {
+        return fail(LFAMD_ERR_UNSUPPORTED, "mul_mat: activations must be in the weight type's vec_dot format%s", "");
+    }
+    if (b_row_bytes < lfamd_row_size(Btype, k))
+        return fail(LFAMD_ERR_INVALID, "mul_mat: activation row stride too small%s", "");
+    if (m == 0 || n == 0)
+        return LFAMD_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int vregs32 = (flags & LFAMD_FLAG_Q0_VREGS32) ? 1 : 0, precise = (flags & LFAMD_FLAG_PRECISE) ? 1 : 0;
+
+    if (use_gemm(Atype, n, flags)) {
+        size_t need = lfamd_mul_mat_workspace(Atype, m, k, n);
+        if (ws_bytes < need || !d_ws)
+            return fail(LFAMD_ERR_WORKSPACE, "mul_mat: workspace too small%s", "");
+        size_t n_pad = align_up((size_t)n, 64), nb = (size_t)(k / 256);
+        uint8_t *ws = (uint8_t *)d_ws;
+        void *Xh = ws;
+        void *d8T = ws + align_up(n_pad * (size_t)k * 2, 256);
+        void *Xm = (uint8_t *)d8T + align_up(nb * n_pad * 4, 256);
+        HIPCHK(lfamd_launch_prep_q8k(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, s), "prep_q8k");
+        HIPCHK(lfamd_launch_gemm_kq(Atype, d_A, m, k, Xh, d8T, Xm, n, (long)n_pad, d_C, ldc, s), "gemm_kq");
+        return LFAMD_OK;
+    }
+    if (use_gemv(Atype, n, flags)) {
+        HIPCHK(lfamd_launch_gemv(Atype, d_A, m, k, d_B, b_row_bytes, n, d_C, ldc, vregs32, precise, s), "gemv");
+        return LFAMD_OK;
+    }
+    if (Atype == LFAMD_TYPE_Q4_K || Atype == LFAMD_TYPE_Q6_K || Atype == LFAMD_TYPE_Q8_0)
+        return fail(LFAMD_ERR_UNSUPPORTED, "mul_mat: FORCE_GENERIC needs RAW-layout weights; this type is packed%s", "");
+    HIPCHK(lfamd_launch_generic(Atype, d_A, m, k, Btype, d_B, b_row_bytes, n, d_C, ldc, s), "generic");
+    return LFAMD_OK;
+}
+
+size_t lfamd_mul_mat_id_workspace(int type, long rows, long cols, int experts, long tokens, int thinkers) {
+    return lfamd_moe_workspace(type, rows, cols, experts, tokens, thinkers);
+}
+
+int lfamd_mul_mat_id(int type, const void *d_W, long rows, long cols, int experts, int Btype, const void *d_thought,
+                     size_t b_row_bytes, int tasks, long tokens, const int32_t *d_plan, int thinkers, float *d_result,
+                     void *d_ws, size_t ws_bytes, unsigned flags, void *stream) {
+    if (!type_known(type))
+        return fail(LFAMD_ERR_UNSUPPORTED, "mul_mat_id: unsupported weight type%s", "");
+    if (rows < 0 || cols < 0 || cols % lfamd_blck_size(type) || experts <= 0 || tasks <= 0 || thinkers <= 0 ||
+        tasks > thinkers || thinkers > experts)
+        return fail(LFAMD_ERR_INVALID, "mul_mat_id: bad shape%s", "");
+    if (Btype != lfamd_vec_dot_type(type))
+        return fail(LFAMD_ERR_UNSUPPORTED, "mul_mat_id: activations must be in the weight type's vec_dot format%s", "");
+    if (tokens == 0 || rows == 0)
+        return LFAMD_OK;
+    size_t need = lfamd_moe_workspace(type, rows, cols, experts, tokens, thinkers);
+    if (need && (ws_bytes < need || !d_ws))
+        return fail(LFAMD_ERR_WORKSPACE, "mul_mat_id: workspace too small%s", "");
+    HIPCHK(lfamd_launch_moe(type, d_W, rows, cols, experts, lfamd_packed_size(type, rows, cols), Btype, d_thought,
+                            b_row_bytes, tasks, tokens, d_plan, thinkers, d_result, d_ws, ws_bytes, flags,
+                            (hipStream_t)stream),
+           "mul_mat_id");
+    return LFAMD_OK;
+}
+
+int lfamd_time_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const void *d_B, size_t b_row_bytes, long n,
+                       float *d_C, long ldc, void *d_ws, size_t ws_bytes, unsigned flags, void *stream, int warmup,
+                       int iters, float *avg_us) {
+    hipStream_t s = (hipStream_t)stream;
+    for (int i = 0; i < warmup; i++) {
+        int r = lfamd_mul_mat(Atype, d_A, m, k, Btype, d_B, b_row_bytes, n, d_C, ldc, d_ws, ws_bytes, flags, stream);
+        if (r)
+            return r;
+    }
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0), "hipEventCreate");
+    HIPCHK(hipEventCreate(&e1), "hipEventCreate");
+    HIPCHK(hipEventRecord(e0, s), "hipEventRecord");
+    for (int i = 0; i < iters; i++) {
+        int r = lfamd_mul_mat(Atype, d_A, m, k, Btype, d_B, b_row_bytes, n, d_C, ldc, d_ws, ws_bytes, flags, stream);
+        if (r)
+            return r;
+    }
+    HIPCHK(hipEventRecord(e1, s), "hipEventRecord");
+    HIPCHK(hipEventSynchronize(e1), "hipEventSynchronize");
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1), "hipEventElapsedTime");
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    *avg_us = iters > 0 ? ms * 1000.0f / iters : 0.0f;
+    return LFAMD_OK;
+}
+}

@@ -1,0 +1,306 @@
+// generic.hip — type-generic quantised mat-mul on RAW-layout weights (every ggml type of the path).
+//
+// The untuned but complete kernel: it services every weight type iqk_mul_mat / tinyBLAS accept on
+// x86 (iqk_mul_mat.inc:1408-1463, tinyblas_cpu_sgemm.inc:45-240) for any n, with the reference's
+// arithmetic: exact integer block dot products, f32 scales.  Types with a
+// tuned kernel (Q4_K, Q6_K, Q8_0) use gemv.hip / gemm_mfma.hip instead; this one carries the rest
+// (Q4_0, Q4_1, Q5_0, Q5_1, Q2_K, Q3_K, Q5_K, IQ4_XS, F32/F16/BF16) until they get their own.
+//
+// One wave per (weight row, tile of up to 8 activation rows).  Lanes split the row into 16-weight
+// units (32 for the legacy 32-blocks), each lane unpacks its unit once and dots it against up to 8
+// activation rows, then the wave reduces with DPP/shuffles.
+#include "lfamd_device.h"
+
+__device__ static const int8_t kvalues_iq4nl_dev[16] = {-127, -104, -83, -65, -49, -35, -22, -10,
+                                                        1,    13,   25,  38,  53,  69,  89,  113};
+
+// Unpack 16 consecutive weights (unit s of 16 in a super-block) to integer codes q, and the unit's
+// integer scale / min:  w = d*sc*q - dmin*mn.  Formulas: ggml-cuda.cu.patch:3217-3471, 3684-3699.
+template <int TYPE>
+__device__ static inline void unpack16(const uint8_t *blk, int s, int q[16], int &sc, int &mn, float &d, float &dmin) {
+    if constexpr (TYPE == LFAMD_TYPE_Q4_K || TYPE == LFAMD_TYPE_Q5_K) {
+        const uint8_t *scales = blk + 4;
+        d = h2f(*(const uint16_t *)blk);
+        dmin = h2f(*(const uint16_t *)(blk + 2));
+        int j = s >> 1; // 32-wide sub-block
+        scale_min_k4(j, scales, sc, mn);
+        const uint8_t *qs = blk + (TYPE == LFAMD_TYPE_Q4_K ? 16 : 48);
+        int c = j >> 1, hi = j & 1, l0 = (s & 1) * 16;
+        for (int l = 0; l < 16; l++) {
+            uint8_t byte = qs[32 * c + l0 + l];
+            q[l] = hi ? (byte >> 4) : (byte & 15);
+            if constexpr (TYPE == LFAMD_TYPE_Q5_K) {
+                const uint8_t *qh = blk + 16;
+                q[l] += ((qh[l0 + l] >> (2 * c + hi)) & 1) * 16;
+            }
+        }
+    } else if constexpr (TYPE == LFAMD_TYPE_Q6_K) {
+        const uint8_t *ql = blk, *qh = blk + 128;
+        const int8_t *scales = (const int8_t *)(blk + 192);
+        d = h2f(*(const uint16_t *)(blk + 208));
+        dmin = 0.0f;
+        sc = scales[s];
+        mn = 0;
+        int p = s >> 3, quarter = (s >> 1) & 3, l0 = (s & 1) * 16;
+        for (int l = 0; l < 16; l++) {
+            uint8_t qlb = ql[64 * p + (quarter & 1) * 32 + l0 + l];
+            int nib = quarter < 2 ? (qlb & 15) : (qlb >> 4);
+            int hb = (qh[32 * p + l0 + l] >> (2 * quarter)) & 3;
+            q[l] = (nib | (hb << 4)) - 32;
+        }
+    } else if constexpr (TYPE == LFAMD_TYPE_Q2_K) {
+        const uint8_t *scales = blk, *qs = blk + 16;
+        d = h2f(*(const uint16_t *)(blk + 80));
+        dmin = h2f(*(const uint16_t *)(blk + 82));
+        sc = scales[s] & 0xF;
+        mn = scales[s] >> 4;
+        int n = s >> 3, quarter = (s >> 1) & 3, l0 = (s & 1) * 16;
+        for (int l = 0; l < 16; l++)
+            q[l] = (qs[32 * n + l0 + l] >> (2 * quarter)) & 3;
+    } else if constexpr (TYPE == LFAMD_TYPE_Q3_K) {
+        const uint8_t *hmask = blk, *qs = blk + 32, *scales = blk + 96;
+        d = h2f(*(const uint16_t *)(blk + 108));
+        dmin = 0.0f;
+        int is = s;
+        int us = is < 4    ? (scales[is] & 0xF) | (((scales[is + 8] >> 0) & 3) << 4)
+                 : is < 8  ? (scales[is] & 0xF) | (((scales[is + 4] >> 2) & 3) << 4)
+                 : is < 12 ? (scales[is - 8] >> 4) | (((scales[is] >> 4) & 3) << 4)
+                           : (scales[is - 8] >> 4) | (((scales[is - 4] >> 6) & 3) << 4);
+        sc = us - 32;
+        mn = 0;
+        int n = s >> 3, j = (s >> 1) & 3, l0 = (s & 1) * 16;
+        uint8_t m = (uint8_t)(1 << (4 * n + j));
+        for (int l = 0; l < 16; l++) {
+            int v = (qs[32 * n + l0 + l] >> (2 * j)) & 3;
+            q[l] = v - ((hmask[l0 + l] & m) ? 0 : 4);
+        }
+    } else if constexpr (TYPE == LFAMD_TYPE_IQ4_XS) {
+        d = h2f(*(const uint16_t *)blk);
+        dmin = 0.0f;
+        uint16_t scales_h = *(const uint16_t *)(blk + 2);
+        const uint8_t *scales_l = blk + 4, *qs = blk + 8;
+        int ib = s >> 1;
+        int ls = ((scales_l[ib / 2] >> (4 * (ib % 2))) & 0xf) | (((scales_h >> (2 * ib)) & 3) << 4);
+        sc = ls - 32;
+        mn = 0;
+        int hi = s & 1;
+        for (int l = 0; l < 16; l++) {
+            uint8_t byte = qs[16 * ib + l];
+            q[l] = kvalues_iq4nl_dev[hi ? (byte >> 4) : (byte & 15)];
+        }
+    }
+}
+
+// K-quants x Q8_K
+template <int TYPE, int TS>
+__global__ __launch_bounds__(256) void generic_kquant_kernel(const uint8_t *__restrict__ A, long m, int nb,
+                                                             const uint8_t *__restrict__ B, size_t b_row_bytes, long n,
+                                                             float *__restrict__ C, long ldc) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long col0 = (long)blockIdx.y * 8;
+    if (row >= m)
+        return;
+    const int nc = (int)((n - col0) < 8 ? (n - col0) : 8);
+    const uint8_t *arow = A + (size_t)row * nb * TS;
+    float accd[8], accm[8];
+    for (int c = 0; c < 8; c++)
+        accd[c] = accm[c] = 0.0f;
+    const int units = nb * 16;
+    for (int u = lane; u < units; u += 64) {
+        int b = u >> 4, s = u & 15;
+        int q[16], sc, mn;
+        float d, dmin;
+        unpack16<TYPE>(arow + (size_t)b * TS, s, q, sc, mn, d, dmin);
+        for (int c = 0; c < nc; c++) {
+            const lfamd_block_q8_K *y = (const lfamd_block_q8_K *)(B + (col0 + c) * b_row_bytes) + b;
+            int dot = 0;
+            for (int l = 0; l < 16; l++)
+                dot += q[l] * (int)y->qs[16 * s + l];
+            float d8 = y->d;
+            accd[c] = fmaf(d * d8, (float)(sc * dot), accd[c]);
+            accm[c] = fmaf(-dmin * d8, (float)(mn * (int)y->bsums[s]), accm[c]);
+        }
+    }
+    for (int c = 0; c < nc; c++) {
+        float v = accd[c] + accm[c];
+        for (int off = 32; off > 0; off >>= 1)
+            v += __shfl_xor(v, off, 64);
+        if (lane == 0)
+            C[(col0 + c) * ldc + row] = v;
+    }
+}
+
+// legacy 32-blocks x Q8_0 / Q8_1 (iqk_mul_mat.inc:998-1349)
+template <int TYPE, int TS, bool TYPE1>
+__global__ __launch_bounds__(256) void generic_legacy_kernel(const uint8_t *__restrict__ A, long m, int nb,
+                                                             const uint8_t *__restrict__ B, size_t b_row_bytes, long n,
+                                                             float *__restrict__ C, long ldc) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long col0 = (long)blockIdx.y * 8;
+    if (row >= m)
+        return;
+    const int nc = (int)((n - col0) < 8 ? (n - col0) : 8);
+    const uint8_t *arow = A + (size_t)row * nb * TS;
+    float acc[8];
+    for (int c = 0; c < 8; c++)
+        acc[c] = 0.0f;
+    for (int u = lane; u < nb; u += 64) {
+        const uint8_t *blk = arow + (size_t)u * TS;
+        int q[32];
+        float d = h2f(*(const uint16_t *)blk), mval = 0.0f;
+        if constexpr (TYPE == LFAMD_TYPE_Q4_0) {
+            for (int j = 0; j < 16; j++) {
+                q[j] = (blk[2 + j] & 15) - 8;
+                q[j + 16] = (blk[2 + j] >> 4) - 8;
+            }
+        } else if constexpr (TYPE == LFAMD_TYPE_Q4_1) {
+            mval = h2f(*(const uint16_t *)(blk + 2));
+            for (int j = 0; j < 16; j++) {
+                q[j] = blk[4 + j] & 15;
+                q[j + 16] = blk[4 + j] >> 4;
+            }
+        } else if constexpr (TYPE == LFAMD_TYPE_Q5_0) {
+            uint32_t qh = blk[2] | (blk[3] << 8) | (blk[4] << 16) | ((uint32_t)blk[5] << 24);
+            for (int j = 0; j < 16; j++) {
+                q[j] = ((blk[6 + j] & 15) | (((qh >> j) & 1) << 4)) - 16;
+                q[j + 16] = ((blk[6 + j] >> 4) | (((qh >> (j + 16)) & 1) << 4)) - 16;
+            }
+        } else if constexpr (TYPE == LFAMD_TYPE_Q5_1) {
+            mval = h2f(*(const uint16_t *)(blk + 2));
+            uint32_t qh = blk[4] | (blk[5] << 8) | (blk[6] << 16) | ((uint32_t)blk[7] << 24);
+            for (int j = 0; j < 16; j++) {
+                q[j] = (blk[8 + j] & 15) | (((qh >> j) & 1) << 4);
+                q[j + 16] = (blk[8 + j] >> 4) | (((qh >> (j + 16)) & 1) << 4);
+            }
+        }
+        for (int c = 0; c < nc; c++) {
+            const uint8_t *yb = B + (col0 + c) * b_row_bytes + (size_t)u * (TYPE1 ? 36 : 34);
+            float dy = h2f(*(const uint16_t *)yb);
+            const int8_t *q8 = (const int8_t *)(yb + (TYPE1 ? 4 : 2));
+            int dot = 0;
+            for (int l = 0; l < 32; l++)
+                dot += q[l] * (int)q8[l];
+            acc[c] = fmaf(d * dy, (float)dot, acc[c]);
+            if constexpr (TYPE1)
+                acc[c] += mval * h2f(*(const uint16_t *)(yb + 2));
+        }
+    }
+    for (int c = 0; c < nc; c++) {
+        float v = acc[c];
+        for (int off = 32; off > 0; off >>= 1)
+            v += __shfl_xor(v, off, 64);
+        if (lane == 0)
+            C[(col0 + c) * ldc + row] = v;
+    }
+}
+
+// float types (tinyBLAS<> F32/F16/BF16, tinyblas_cpu.h:419-613): f32 accumulate
+template <int ATYPE, int BTYPE>
+__global__ __launch_bounds__(256) void generic_float_kernel(const uint8_t *__restrict__ A, long m, long k,
+                                                            const uint8_t *__restrict__ B, size_t b_row_bytes, long n,
+                                                            float *__restrict__ C, long ldc) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long col0 = (long)blockIdx.y * 8;
+    if (row >= m)
+        return;
+    const int nc = (int)((n - col0) < 8 ? (n - col0) : 8);
+    constexpr int AS = ATYPE == LFAMD_TYPE_F32 ? 4 : 2;
+    const uint8_t *arow = A + (size_t)row * k * AS;
+    float acc[8];
+    for (int c = 0; c < 8; c++)
+        acc[c] = 0.0f;
+    auto ld = [](int type, const uint8_t *p, long idx) -> float {
+        if (type == LFAMD_TYPE_F32)
+            return ((const float *)p)[idx];
+        uint16_t h = ((const uint16_t *)p)[idx];
+        if (type == LFAMD_TYPE_F16)
+            return h2f(h);
+        return __builtin_bit_cast(float, (uint32_t)h << 16);
+    };
+    for (long l = lane; l < k; l += 64) {
+        float a = ld(ATYPE, arow, l);
+        for (int c = 0; c < nc; c++)
+            acc[c] = fmaf(a, ld(BTYPE, B + (col0 + c) * b_row_bytes, l), acc[c]);
+    }
+    for (int c = 0; c < nc; c++) {
+        float v = acc[c];
+        for (int off = 32; off > 0; off >>= 1)
+            v += __shfl_xor(v, off, 64);
+        if (lane == 0)
+            C[(col0 + c) * ldc + row] = v;
+    }
+}
+
+extern "C" hipError_t lfamd_launch_generic(int Atype, const void *A, long m, long k, int Btype, const void *B,
+                                           size_t b_row_bytes, long n, float *C, long ldc, hipStream_t s) {
+    if (m <= 0 || n <= 0)
+        return hipSuccess;
+    dim3 grid((unsigned)((m + 3) / 4), (unsigned)((n + 7) / 8));
+    const uint8_t *a = (const uint8_t *)A, *b = (const uint8_t *)B;
+    int nb256 = (int)(k / 256), nb32 = (int)(k / 32);
+#define KQ(T, TS) generic_kquant_kernel<T, TS><<<grid, 256, 0, s>>>(a, m, nb256, b, b_row_bytes, n, C, ldc)
+#define LG(T, TS, T1) generic_legacy_kernel<T, TS, T1><<<grid, 256, 0, s>>>(a, m, nb32, b, b_row_bytes, n, C, ldc)
+#define FL(TA, TB) generic_float_kernel<TA, TB><<<grid, 256, 0, s>>>(a, m, k, b, b_row_bytes, n, C, ldc)
+    switch (Atype) {
+    case LFAMD_TYPE_Q2_K:
+        KQ(LFAMD_TYPE_Q2_K, 84);
+        break;
+    case LFAMD_TYPE_Q3_K:
+        KQ(LFAMD_TYPE_Q3_K, 110);
+        break;
+    case LFAMD_TYPE_Q4_K:
+        KQ(LFAMD_TYPE_Q4_K, 144);
+        break;
+    case LFAMD_TYPE_Q5_K:
+        KQ(LFAMD_TYPE_Q5_K, 176);
+        break;
+    case LFAMD_TYPE_Q6_K:
+        KQ(LFAMD_TYPE_Q6_K, 210);
+        break;
+    case LFAMD_TYPE_IQ4_XS:
+        KQ(LFAMD_TYPE_IQ4_XS, 136);
+        break;
+    case LFAMD_TYPE_Q4_0:
+        LG(LFAMD_TYPE_Q4_0, 18, false);
+        break;
+    case LFAMD_TYPE_Q4_1:
+        LG(LFAMD_TYPE_Q4_1, 20, true);
+        break;
+    case LFAMD_TYPE_Q5_0:
+        LG(LFAMD_TYPE_Q5_0, 22, false);
+        break;
+    case LFAMD_TYPE_Q5_1:
+        LG(LFAMD_TYPE_Q5_1, 24, true);
+        break;
+    case LFAMD_TYPE_F32:
+        if (Btype != LFAMD_TYPE_F32)
+            return hipErrorInvalidValue;
+        FL(LFAMD_TYPE_F32, LFAMD_TYPE_F32);
+        break;
+    case LFAMD_TYPE_F16:
+        if (Btype == LFAMD_TYPE_F32)
+            FL(LFAMD_TYPE_F16, LFAMD_TYPE_F32);
+        else if (Btype == LFAMD_TYPE_F16)
+            FL(LFAMD_TYPE_F16, LFAMD_TYPE_F16);
+        else
+            return hipErrorInvalidValue;
+        break;
+    case LFAMD_TYPE_BF16:
+        if (Btype == LFAMD_TYPE_F32)
+            FL(LFAMD_TYPE_BF16, LFAMD_TYPE_F32);
+        else if (Btype == LFAMD_TYPE_BF16)
+            FL(LFAMD_TYPE_BF16, LFAMD_TYPE_BF16);
+        else
+            return hipErrorInvalidValue;
+        break;
+    default:
+        return hipErrorInvalidValue;
+    }
+#undef KQ
+#undef LG
+#undef FL
+    return hipGetLastError();
+}

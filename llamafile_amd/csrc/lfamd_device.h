@@ -1,0 +1,145 @@
+// lfamd_device.h — shared device-side definitions for the gfx950 kernels.
+//
+// PACKED WEIGHT LAYOUTS (DESIGN.md "Data layout in HBM").  The module owns the device copy of the
+// weights (like ggml_backend_cuda_buffer_set_tensor, ggml-cuda.cu.patch:16971-16977) and re-lays
+// it out at upload so that every kernel reads 16 contiguous bytes per lane, 1 KiB per wave
+// instruction, already in MFMA-fragment order.  No padding bytes are added inside a tile: a
+// packed tensor is exactly as large as the GGUF one (plus row/block round-up at the edges).
+//
+// P4K (Q4_K)   tile = 32 rows x 256 weights (one super-block per row) = 4608 B, stored
+//              [row-tile rt][super-block b]:
+//                qs  : 4 groups g x 64 lanes x 16 B.  lane = (i = lane&31, h = lane>>5); dword dd of
+//                      group g is K-step t = 4g+dd and holds the 8 nibbles of weights
+//                      k = 16t + 8h + j (j = 0..7) of row i, nibble j at bit 4*NIBPOS(j).
+//                hdr : 32 rows x 16 B = the block's original {d, dmin, scales[12]}.
+// P6K (Q6_K)   tile = 6720 B: ql (same as P4K qs, low 4 bits of each 6-bit code), qh (2 x 64 lanes x
+//              16 B: upper 2 bits, see QHBIT), sc (32 rows x 16 int8), d (32 x f16).
+// P80 (Q8_0)   tile = 8 rows x 4 blocks = 1088 B: qs[r][j][dd] dword = bytes 4j..4j+3 of block 4L+dd
+//              of row r (lane = r*8+j reads 16 B), then d[r][dd] f16.  Chosen for the bit-exact
+//              8-lane accumulation order of tinyBLAS_Q0_AVX2 (tinyblas_cpu.h:949-964).
+// RAW          every other type: rows of raw GGUF blocks, row stride = ggml_row_size().
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/lfamd_blocks.h"
+
+#define P4K_TILE 4608
+#define P4K_HDR 4096
+#define P6K_TILE 6720
+#define P6K_QH 4096
+#define P6K_SC 6144
+#define P6K_D 6656
+#define P80_TILE 1088
+#define P80_D 1024
+
+// nibble slot of element j (0..7) inside a K-step dword: pairs (j0,j1),(j2,j3),.. sit 16 bits apart
+// so that (x & 0x000F000F) | 0x64006400 is the f16 pair (1024+q0, 1024+q1) with no shuffling.
+#define NIBPOS(j) (((j) >> 1) + 4 * ((j)&1))
+
+// bit of the 2-bit high field of element j of K-step (dd&1) inside the qh dword of K-step pair dd>>1
+//   half (j&1)*16, field {2,4,6,0}[j>>1] + (dd&1), two bits each
+__host__ __device__ static inline int qhbit(int dd, int j) {
+    const int f[4] = {2, 4, 6, 0};
+    return 16 * (j & 1) + 2 * (f[j >> 1] + (dd & 1));
+}
+
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef float float16_t_ __attribute__((ext_vector_type(16)));
+typedef float float4_t_ __attribute__((ext_vector_type(4)));
+
+__device__ static inline float h2f(uint16_t h) {
+    return (float)__builtin_bit_cast(_Float16, h);
+}
+
+__device__ static inline uint16_t f2h_bits(float f) { // RNE, like F16C
+    return __builtin_bit_cast(uint16_t, (_Float16)f);
+}
+
+__device__ static inline int sdot4(uint32_t a, uint32_t b, int c) { // signed i8 x signed i8
+    return __builtin_amdgcn_sdot4((int)a, (int)b, c, false);
+}
+
+// get_scale_min_k4 (ggml-cuda.cu.patch:3311-3318)
+__device__ static inline void scale_min_k4(int j, const uint8_t *q, int &d, int &m) {
+    if (j < 4) {
+        d = q[j] & 63;
+        m = q[j + 4] & 63;
+    } else {
+        d = (q[j + 4] & 0xF) | ((q[j - 4] >> 6) << 4);
+        m = (q[j + 4] >> 4) | ((q[j - 0] >> 6) << 4);
+    }
+}
+
+// vector form: 12 packed bytes (3 dwords) -> sc[0..3], sc[4..7], mn[0..3], mn[4..7] as byte lanes
+// (same arithmetic as make_q4_scales, iqk_mul_mat.inc:134-143)
+__device__ static inline void q4k_scales_bytes(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t &sc03,
+                                               uint32_t &sc47, uint32_t &mn03, uint32_t &mn47) {
+    sc03 = a0 & 0x3f3f3f3f;
+    mn03 = a1 & 0x3f3f3f3f;
+    sc47 = (a2 & 0x0f0f0f0f) | ((a0 >> 2) & 0x30303030);
+    mn47 = ((a2 >> 4) & 0x0f0f0f0f) | ((a1 >> 2) & 0x30303030);
+}
+
+__device__ static inline float wave_sum_xor(float v, int mask) {
+    return v + __shfl_xor(v, mask, 64);
+}
+
+// mnpack geometry of tinyBLAS_Q0_AVX2 (tinyblas_cpu.h:794-931): is output (i, j) of an m x n
+// problem computed by a PRECISE (Kahan) tile?  vregs32: AVX512 build; precise: FLAG_precise.
+__host__ __device__ static inline bool q0_is_kahan(long i, long j, long m, long n, bool vregs32, bool precise) {
+    long m0 = 0, n0 = 0;
+    for (int depth = 0; depth < 64; ++depth) {
+        long dm = m - m0, dn = n - n0;
+        if (dm <= 0 || dn <= 0)
+            return precise;
+        long a, b, mc, nc;
+        bool pr;
+        if (vregs32) {
+            a = dm < 3 ? dm : 3;
+            b = dn < 3 ? dn : 3;
+            if (a == 3 && b == 3) {
+                mc = 3, nc = 3, pr = precise;
+            } else if (a >= 2 && b >= 2) {
+                mc = 2, nc = 2, pr = precise;
+            } else if (a >= 2) {
+                mc = 2, nc = 1, pr = true;
+            } else if (b >= 2) {
+                mc = 1, nc = 2, pr = true;
+            } else {
+                mc = 1, nc = 1, pr = true;
+            }
+        } else if (!precise) {
+            a = dm < 3 ? dm : 3;
+            b = dn < 2 ? dn : 2;
+            if (a == 3 && b == 2) {
+                mc = 3, nc = 2;
+            } else if (a == 2 && b == 2) {
+                mc = 2, nc = 2;
+            } else if (a >= 2) {
+                mc = 2, nc = 1;
+            } else if (b == 2) {
+                mc = 1, nc = 2;
+            } else {
+                mc = 1, nc = 1;
+            }
+            pr = false;
+        } else {
+            a = dm < 2 ? dm : 2;
+            mc = a == 2 ? 2 : 1, nc = 1, pr = true;
+        }
+        long mp = m0 + dm / mc * mc;
+        long np = n0 + dn / nc * nc;
+        if (i < mp && j < np)
+            return pr; // inside this level's tiled region
+        if (j < np) {  // rows [mp, m) x cols [n0, np): first recursive call
+            m0 = mp;
+            n = np;
+        } else {       // rows [m0, m) x cols [np, n): second recursive call
+            n0 = np;
+        }
+    }
+    return precise;
+}

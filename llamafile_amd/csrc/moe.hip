@@ -1,0 +1,126 @@
+// moe.hip — GGML_OP_MUL_MAT_ID (mixture of experts): llamafile_mixmul / iqk_mul_mat_moe on the GPU.
+//
+//   result[token][thinker][:] = W[plan[token][thinker]] x thought[token][thinker % tasks][:]
+//   (tinyblas_cpu_mixmul.inc:39-50; row mapping of iqk_mul_mat_moe, iqk_mul_mat.inc:84-101)
+//
+// v1 follows the reference GPU path's structure (ggml_cuda_mul_mat_id, ggml-cuda.cu.patch:18499-18635):
+// the routing table is read back to the host, rows routed to each expert are gathered
+// (k_copy_src1_to_contiguous, :18450-18475), one mat-mul per expert runs on the gathered rows, and
+// the results are scattered back (k_copy_dst_from_contiguous, :18477-18497).  Experts are visited
+// in index order and rows in (token, thinker) order, like build_row_pointers
+// (tinyblas_cpu_mixmul.inc:297-320).  Decode (one token) needs no gather: the GEMV reads its rows in
+// place.
+#include "lfamd_device.h"
+#include "../../include/lfamd_hip.h"
+
+#include <vector>
+
+extern "C" int lfamd_mul_mat(int, const void *, long, long, int, const void *, size_t, long, float *, long, void *, size_t,
+                             unsigned, void *);
+extern "C" size_t lfamd_mul_mat_workspace(int, long, long, long);
+
+__global__ void moe_gather_kernel(const uint8_t *__restrict__ src, size_t src_stride, size_t row_bytes,
+                                  const int32_t *__restrict__ src_idx, uint8_t *__restrict__ dst, long nrows) {
+    const long r = blockIdx.x;
+    if (r >= nrows)
+        return;
+    const uint8_t *s = src + (size_t)src_idx[r] * src_stride;
+    uint8_t *d = dst + (size_t)r * row_bytes;
+    // rows are multiples of 2 bytes (34 / 36 / 292-byte blocks)
+    for (size_t o = 2 * threadIdx.x; o < row_bytes; o += 2 * blockDim.x)
+        *(uint16_t *)(d + o) = *(const uint16_t *)(s + o);
+}
+
+__global__ void moe_scatter_kernel(const float *__restrict__ src, long rows, const int32_t *__restrict__ dst_idx,
+                                   float *__restrict__ dst, long nrows) {
+    const long r = blockIdx.x;
+    if (r >= nrows)
+        return;
+    const float *s = src + (size_t)r * rows;
+    float *d = dst + (size_t)dst_idx[r] * rows;
+    for (long o = threadIdx.x; o < rows; o += blockDim.x)
+        d[o] = s[o];
+}
+
+static inline size_t align_up_(size_t x, size_t a) {
+    return (x + a - 1) / a * a;
+}
+
+extern "C" size_t lfamd_moe_workspace(int type, long rows, long cols, int experts, long tokens, int thinkers) {
+    (void)experts;
+    const size_t nr = (size_t)tokens * thinkers;
+    const size_t brb = lfamd_row_size(lfamd_vec_dot_type(type), cols);
+    const size_t inner = lfamd_mul_mat_workspace(type, rows, cols, (long)nr); // monotonic in n
+    return align_up_(nr * brb, 256) + align_up_(nr * (size_t)rows * 4, 256) + align_up_(nr * 4, 256) * 2 +
+           align_up_(inner, 256);
+}
+
+extern "C" hipError_t lfamd_launch_moe(int type, const void *W, long rows, long cols, int experts, size_t expert_bytes,
+                                       int Btype, const void *thought, size_t b_row_bytes, int tasks, long tokens,
+                                       const int32_t *plan, int thinkers, float *result, void *ws, size_t ws_bytes,
+                                       unsigned flags, hipStream_t s) {
+    const size_t nr = (size_t)tokens * thinkers;
+    std::vector<int32_t> hplan(nr);
+    hipError_t e = hipMemcpyAsync(hplan.data(), plan, nr * 4, hipMemcpyDeviceToHost, s);
+    if (e != hipSuccess)
+        return e;
+    e = hipStreamSynchronize(s); // the reference syncs here too (ggml-cuda.cu.patch:18528-18531)
+    if (e != hipSuccess)
+        return e;
+
+    const size_t brb = lfamd_row_size(Btype, cols);
+    uint8_t *p = (uint8_t *)ws;
+    uint8_t *Bg = p;
+    p += align_up_(nr * brb, 256);
+    float *Cg = (float *)p;
+    p += align_up_(nr * (size_t)rows * 4, 256);
+    int32_t *d_src = (int32_t *)p;
+    p += align_up_(nr * 4, 256);
+    int32_t *d_dst = (int32_t *)p;
+    p += align_up_(nr * 4, 256);
+    void *inner_ws = p;
+    size_t inner_bytes = ws_bytes - (size_t)(p - (uint8_t *)ws);
+
+    // rows per expert in (token, thinker) order
+    std::vector<int32_t> src_idx, dst_idx;
+    std::vector<long> start(experts + 1, 0);
+    src_idx.reserve(nr);
+    dst_idx.reserve(nr);
+    for (int ex = 0; ex < experts; ex++) {
+        start[ex] = (long)src_idx.size();
+        for (long t = 0; t < tokens; t++)
+            for (int th = 0; th < thinkers; th++)
+                if (hplan[t * thinkers + th] == ex) {
+                    src_idx.push_back((int32_t)(t * tasks + th % tasks));
+                    dst_idx.push_back((int32_t)(t * thinkers + th));
+                }
+    }
+    start[experts] = (long)src_idx.size();
+    const long routed = (long)src_idx.size(); // rows whose expert id is in range
+    if (routed == 0)
+        return hipSuccess;
+    e = hipMemcpyAsync(d_src, src_idx.data(), routed * 4, hipMemcpyHostToDevice, s);
+    if (e != hipSuccess)
+        return e;
+    e = hipMemcpyAsync(d_dst, dst_idx.data(), routed * 4, hipMemcpyHostToDevice, s);
+    if (e != hipSuccess)
+        return e;
+    // the host vectors must outlive the async copies
+    e = hipStreamSynchronize(s);
+    if (e != hipSuccess)
+        return e;
+
+    moe_gather_kernel<<<(unsigned)routed, 128, 0, s>>>((const uint8_t *)thought, b_row_bytes, brb, d_src, Bg, routed);
+    for (int ex = 0; ex < experts; ex++) {
+        long cnt = start[ex + 1] - start[ex];
+        if (cnt == 0)
+            continue;
+        int r = lfamd_mul_mat(type, (const uint8_t *)W + (size_t)ex * expert_bytes, rows, cols, Btype,
+                              Bg + (size_t)start[ex] * brb, brb, cnt, Cg + (size_t)start[ex] * rows, rows, inner_ws,
+                              inner_bytes, flags, (void *)s);
+        if (r != LFAMD_OK)
+            return hipErrorUnknown;
+    }
+    moe_scatter_kernel<<<(unsigned)routed, 256, 0, s>>>(Cg, rows, d_dst, result, routed);
+    return hipGetLastError();
+}

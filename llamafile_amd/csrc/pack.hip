@@ -1,0 +1,279 @@
+// pack.hip — device-side re-layout of GGUF weight tensors into the packed tile formats
+// (lfamd_device.h) and preparation of quantised activations for the MFMA GEMM.
+//
+// Counterpart of the reference's weight upload, ggml_backend_cuda_buffer_set_tensor
+// (ggml-cuda.cu.patch:16971-16977): the backend owns the device copy, so it may choose its layout.
+#include "lfamd_device.h"
+
+// ---------------------------------------------------------------------------------------------
+// Q4_K -> P4K.  One thread per output dword of the qs part, one per 16-byte header.
+
+__global__ void pack_q4k_kernel(const uint8_t *__restrict__ raw, size_t raw_row_bytes, long rows, int nb,
+                                uint8_t *__restrict__ out, long n_tiles) {
+    long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    // per tile: 1024 qs dwords + 32 header slots (4 dwords each) = 1152 dwords
+    long tile = tid / 1152;
+    int w = (int)(tid % 1152);
+    if (tile >= n_tiles)
+        return;
+    long rt = tile / nb;
+    int b = (int)(tile % nb);
+    uint32_t *dst = (uint32_t *)(out + tile * P4K_TILE);
+    if (w < 1024) {
+        int g = w >> 8, lane = (w >> 2) & 63, dd = w & 3;
+        int i = lane & 31, h = lane >> 5;
+        long row = rt * 32 + i;
+        uint32_t v = 0;
+        if (row < rows) {
+            const lfamd_block_q4_K *blk = (const lfamd_block_q4_K *)(raw + row * raw_row_bytes) + b;
+            int t = 4 * g + dd;
+            for (int j = 0; j < 8; j++) {
+                int k = 16 * t + 8 * h + j;
+                int c = k >> 6, wi = k & 63;
+                uint8_t byte = blk->qs[32 * c + (wi & 31)];
+                uint32_t nib = wi < 32 ? (byte & 15u) : (uint32_t)(byte >> 4);
+                v |= nib << (4 * NIBPOS(j));
+            }
+        }
+        dst[w] = v;
+    } else {
+        int s = w - 1024; // 0..127: header dword
+        int i = s >> 2, q = s & 3;
+        long row = rt * 32 + i;
+        uint32_t v = 0;
+        if (row < rows) {
+            const uint8_t *blk = raw + row * raw_row_bytes + (size_t)b * sizeof(lfamd_block_q4_K);
+            // raw blocks are only 2-byte aligned in general (row strides are multiples of 144, so
+            // 4-byte here, but stay safe)
+            const uint16_t *p = (const uint16_t *)(blk + 4 * q);
+            v = (uint32_t)p[0] | ((uint32_t)p[1] << 16);
+        }
+        dst[1024 + s] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Q6_K -> P6K
+
+__device__ static inline int q6k_code(const lfamd_block_q6_K *blk, int k) { // 0..63
+    int p = k >> 7, wi = k & 127, l = wi & 31, quarter = wi >> 5;
+    uint8_t qlb = blk->ql[64 * p + (quarter & 1) * 32 + l];
+    int nib = quarter < 2 ? (qlb & 15) : (qlb >> 4);
+    int hi = (blk->qh[32 * p + l] >> (2 * quarter)) & 3;
+    return nib | (hi << 4);
+}
+
+__global__ void pack_q6k_kernel(const uint8_t *__restrict__ raw, size_t raw_row_bytes, long rows, int nb,
+                                uint8_t *__restrict__ out, long n_tiles) {
+    long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    // per tile: 1024 ql dwords + 512 qh dwords + 128 scale dwords + 16 d dwords = 1680 dwords
+    long tile = tid / 1680;
+    int w = (int)(tid % 1680);
+    if (tile >= n_tiles)
+        return;
+    long rt = tile / nb;
+    int b = (int)(tile % nb);
+    uint32_t *dst = (uint32_t *)(out + tile * P6K_TILE);
+    if (w < 1024) {
+        int g = w >> 8, lane = (w >> 2) & 63, dd = w & 3;
+        int i = lane & 31, h = lane >> 5;
+        long row = rt * 32 + i;
+        uint32_t v = 0;
+        if (row < rows) {
+            const lfamd_block_q6_K *blk = (const lfamd_block_q6_K *)(raw + row * raw_row_bytes) + b;
+            int t = 4 * g + dd;
+            for (int j = 0; j < 8; j++)
+                v |= (uint32_t)(q6k_code(blk, 16 * t + 8 * h + j) & 15) << (4 * NIBPOS(j));
+        }
+        dst[w] = v;
+    } else if (w < 1536) {
+        int s = w - 1024;
+        int gg = s >> 8, lane = (s >> 2) & 63, q = s & 3; // dword q of the lane's 16 B: group 2gg+(q>>1), pair e=q&1
+        int i = lane & 31, h = lane >> 5;
+        int g = 2 * gg + (q >> 1), e = q & 1;
+        long row = rt * 32 + i;
+        uint32_t v = 0;
+        if (row < rows) {
+            const lfamd_block_q6_K *blk = (const lfamd_block_q6_K *)(raw + row * raw_row_bytes) + b;
+            for (int ab = 0; ab < 2; ab++) {
+                int dd = 2 * e + ab, t = 4 * g + dd;
+                for (int j = 0; j < 8; j++)
+                    v |= (uint32_t)(q6k_code(blk, 16 * t + 8 * h + j) >> 4) << qhbit(dd, j);
+            }
+        }
+        dst[w] = v;
+    } else if (w < 1664) {
+        int s = w - 1536;
+        int i = s >> 2, q = s & 3;
+        long row = rt * 32 + i;
+        uint32_t v = 0;
+        if (row < rows) {
+            const lfamd_block_q6_K *blk = (const lfamd_block_q6_K *)(raw + row * raw_row_bytes) + b;
+            const uint8_t *sc = (const uint8_t *)blk->scales + 4 * q;
+            v = sc[0] | (sc[1] << 8) | (sc[2] << 16) | ((uint32_t)sc[3] << 24);
+        }
+        dst[w] = v;
+    } else {
+        int s = w - 1664; // 16 dwords = 32 f16
+        uint32_t v = 0;
+        for (int e = 0; e < 2; e++) {
+            long row = rt * 32 + 2 * s + e;
+            if (row < rows) {
+                const lfamd_block_q6_K *blk = (const lfamd_block_q6_K *)(raw + row * raw_row_bytes) + b;
+                v |= (uint32_t)blk->d << (16 * e);
+            }
+        }
+        dst[w] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Q8_0 -> P80
+
+__global__ void pack_q80_kernel(const uint8_t *__restrict__ raw, size_t raw_row_bytes, long rows, int nblocks,
+                                int nquads, uint8_t *__restrict__ out, long n_tiles) {
+    long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    // per tile: 256 qs dwords + 16 scale dwords = 272 dwords
+    long tile = tid / 272;
+    int w = (int)(tid % 272);
+    if (tile >= n_tiles)
+        return;
+    long rg = tile / nquads;
+    int L = (int)(tile % nquads);
+    uint32_t *dst = (uint32_t *)(out + tile * P80_TILE);
+    if (w < 256) {
+        int r = w >> 5, j = (w >> 2) & 7, dd = w & 3;
+        long row = rg * 8 + r;
+        int blk = 4 * L + dd;
+        uint32_t v = 0;
+        if (row < rows && blk < nblocks) {
+            const lfamd_block_q8_0 *bp = (const lfamd_block_q8_0 *)(raw + row * raw_row_bytes) + blk;
+            const uint8_t *q = (const uint8_t *)bp->qs + 4 * j;
+            v = q[0] | (q[1] << 8) | (q[2] << 16) | ((uint32_t)q[3] << 24);
+        }
+        dst[w] = v;
+    } else {
+        int s = w - 256; // 16 dwords = 32 f16 = d[r][dd]
+        uint32_t v = 0;
+        for (int e = 0; e < 2; e++) {
+            int idx = 2 * s + e;
+            int r = idx >> 2, dd = idx & 3;
+            long row = rg * 8 + r;
+            int blk = 4 * L + dd;
+            if (row < rows && blk < nblocks) {
+                const lfamd_block_q8_0 *bp = (const lfamd_block_q8_0 *)(raw + row * raw_row_bytes) + blk;
+                v |= (uint32_t)bp->d << (16 * e);
+            }
+        }
+        dst[w] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// RAW passthrough (row compaction): bytes copied row by row to stride = row_bytes.
+
+__global__ void pack_raw_kernel(const uint8_t *__restrict__ raw, size_t raw_row_bytes, long rows, size_t row_bytes,
+                                uint8_t *__restrict__ out) {
+    size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t total = (size_t)rows * row_bytes;
+    for (; tid < total; tid += (size_t)gridDim.x * blockDim.x) {
+        size_t r = tid / row_bytes, c = tid % row_bytes;
+        out[tid] = raw[r * raw_row_bytes + c];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Activation preparation for the MFMA GEMM: llamafile-order Q8_K rows ->
+//   Xh  [n_pad][k]      f16   integer codes q8 (exact in f16), zero rows beyond n
+//   d8T [nb][n_pad]     f32   block scales, transposed so a token tile's scales are contiguous
+//   Xm  [n_pad][nb][16] f16   mins operand: for the 8 pair sums S_j = bsums[2j]+bsums[2j+1]
+//                             (|S_j| <= 4096) the split S_j = 64*hi_j + lo_j, lo in [0,63]:
+//                             elements 0..7 = lo_j, 8..15 = hi_j (both exact in f16)
+
+__global__ void prep_q8k_kernel(const uint8_t *__restrict__ B, size_t b_row_bytes, long n, long n_pad, int nb,
+                                _Float16 *__restrict__ Xh, float *__restrict__ d8T, _Float16 *__restrict__ Xm) {
+    long blk = blockIdx.x; // (token, super-block)
+    long tok = blk / nb;
+    int b = (int)(blk % nb);
+    int t = threadIdx.x; // 64 threads: 4 codes each
+    _Float16 *xo = Xh + (size_t)tok * nb * 256 + (size_t)b * 256;
+    if (tok < n) {
+        const lfamd_block_q8_K *y = (const lfamd_block_q8_K *)(B + tok * b_row_bytes) + b;
+        uint32_t q = *(const uint32_t *)((const uint8_t *)y->qs + 4 * t); // 292-byte blocks are 4-aligned
+        for (int e = 0; e < 4; e++)
+            xo[4 * t + e] = (_Float16)(int)(int8_t)(q >> (8 * e));
+        if (t == 0)
+            d8T[(size_t)b * n_pad + tok] = y->d;
+        if (t < 8) {
+            int S = (int)y->bsums[2 * t] + (int)y->bsums[2 * t + 1];
+            int lo = S & 63, hi = (S - lo) / 64;
+            _Float16 *mo = Xm + ((size_t)tok * nb + b) * 16;
+            mo[t] = (_Float16)lo;
+            mo[8 + t] = (_Float16)hi;
+        }
+    } else {
+        for (int e = 0; e < 4; e++)
+            xo[4 * t + e] = (_Float16)0;
+        if (t == 0)
+            d8T[(size_t)b * n_pad + tok] = 0.0f;
+        if (t < 16)
+            Xm[((size_t)tok * nb + b) * 16 + t] = (_Float16)0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-callable launchers (used by api.hip)
+
+extern "C" {
+
+hipError_t lfamd_launch_pack_q4k(const void *raw, size_t raw_row_bytes, long rows, long cols, void *out, hipStream_t s) {
+    int nb = (int)(cols / 256);
+    long n_tiles = ((rows + 31) / 32) * nb;
+    long threads = n_tiles * 1152;
+    pack_q4k_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>((const uint8_t *)raw, raw_row_bytes, rows, nb,
+                                                                        (uint8_t *)out, n_tiles);
+    return hipGetLastError();
+}
+
+hipError_t lfamd_launch_pack_q6k(const void *raw, size_t raw_row_bytes, long rows, long cols, void *out, hipStream_t s) {
+    int nb = (int)(cols / 256);
+    long n_tiles = ((rows + 31) / 32) * nb;
+    long threads = n_tiles * 1680;
+    pack_q6k_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>((const uint8_t *)raw, raw_row_bytes, rows, nb,
+                                                                        (uint8_t *)out, n_tiles);
+    return hipGetLastError();
+}
+
+hipError_t lfamd_launch_pack_q80(const void *raw, size_t raw_row_bytes, long rows, long cols, void *out, hipStream_t s) {
+    int nblocks = (int)(cols / 32);
+    int nquads = (nblocks + 3) / 4;
+    long n_tiles = ((rows + 7) / 8) * nquads;
+    long threads = n_tiles * 272;
+    pack_q80_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>((const uint8_t *)raw, raw_row_bytes, rows, nblocks,
+                                                                        nquads, (uint8_t *)out, n_tiles);
+    return hipGetLastError();
+}
+
+hipError_t lfamd_launch_pack_raw(const void *raw, size_t raw_row_bytes, long rows, size_t row_bytes, void *out,
+                                 hipStream_t s) {
+    size_t total = (size_t)rows * row_bytes;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 65536)
+        blocks = 65536;
+    if (blocks == 0)
+        return hipSuccess;
+    pack_raw_kernel<<<(unsigned)blocks, 256, 0, s>>>((const uint8_t *)raw, raw_row_bytes, rows, row_bytes, (uint8_t *)out);
+    return hipGetLastError();
+}
+
+hipError_t lfamd_launch_prep_q8k(const void *B, size_t b_row_bytes, long n, long n_pad, long cols, void *Xh, void *d8T,
+                                 void *Xm, hipStream_t s) {
+    int nb = (int)(cols / 256);
+    long blocks = n_pad * nb;
+    if (blocks == 0)
+        return hipSuccess;
+    prep_q8k_kernel<<<(unsigned)blocks, 64, 0, s>>>((const uint8_t *)B, b_row_bytes, n, n_pad, nb, (_Float16 *)Xh,
+                                                     (float *)d8T, (_Float16 *)Xm);
+    return hipGetLastError();
+}
+}

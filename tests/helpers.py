@@ -1,0 +1,20 @@
+"""Shared helpers for the parity tests."""
+import numpy as np
+
+from llamafile_amd import ggml_types as T, synth
+
+
+def make_case(t, m, n, k, seed):
+    """Random weights of type t [m, k] + activations quantised to t's vec_dot format [n, k]."""
+    A = synth.random_weights(t, m, k, seed)
+    x = synth.random_activations(n, k, seed + 1)
+    bt = T.VEC_DOT[t]
+    B = synth.quantize_activations(bt, x)
+    return A, B, bt
+
+
+def rel_err(C, G):
+    """max |C-G| / max |G| (normwise, like the logits tolerance of the north star)."""
+    G = np.asarray(G, dtype=np.float64)
+    C = np.asarray(C, dtype=np.float64)
+    return float(np.abs(C - G).max() / max(np.abs(G).max(), 1e-30))

@@ -1,0 +1,31 @@
+"""The device pack kernels produce exactly the layout lfamd_device.h documents (numpy restatement)."""
+import numpy as np
+import pytest
+
+from llamafile_amd import ggml_types as T, synth
+import pack_ref
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("t,ref", [(T.Q4_K, pack_ref.pack_q4k), (T.Q6_K, pack_ref.pack_q6k), (T.Q8_0, pack_ref.pack_q80)],
+                         ids=["Q4_K", "Q6_K", "Q8_0"])
+@pytest.mark.parametrize("shape", [(64, 512), (37, 1024), (7, 256)], ids=str)
+def test_pack_matches_layout_spec(gpu, t, ref, shape):
+    rows, cols = shape
+    raw = synth.random_weights(t, rows, cols, seed=11)
+    W = gpu.upload_weights(t, raw, rows, cols)
+    got = W.data.cpu().numpy()
+    want = ref(raw, rows, cols)
+    assert got.shape == want.shape
+    assert np.array_equal(got, want)
+
+
+def test_pack_honours_raw_row_stride(gpu):
+    rows, cols = 40, 512
+    raw = synth.random_weights(T.Q4_K, rows, cols, seed=3)
+    padded = np.zeros((rows, raw.shape[1] + 48), dtype=np.uint8)
+    padded[:, : raw.shape[1]] = raw
+    a = gpu.upload_weights(T.Q4_K, raw, rows, cols).data.cpu().numpy()
+    b = gpu.upload_weights(T.Q4_K, padded, rows, cols).data.cpu().numpy()
+    assert np.array_equal(a, b)
