@@ -1,0 +1,344 @@
+#!/usr/bin/env python3
+"""bench.py — prefill + decode tokens/s of the quantized mat-mul path, Llama-3-8B Q4_K_M shapes.
+
+One "step" = one pass of the hot path over one batch of synthetic input: a 512-token prefill
+(every GGML_OP_MUL_MAT of the model at n=512: f32 activations -> quantise -> MFMA GEMM) followed by
+128 decode passes (the same 225 mat-muls at n=1: quantise -> wave-reduction GEMV).  Only the
+mat-mul operators are in the step (attention / norm / rope belong to the rest of the graph and are
+out of scope); weights are random blocks of the Q4_K_M tensor types, resident in HBM
+in the packed layout before the timed region starts.
+
+N GPUs: tensor parallel — q/k/v/gate/up sharded by output rows, attn_output /
+ffn_down by input columns with an all-reduce (RCCL over xGMI) of the partial residual-stream sums,
+output.weight by vocabulary rows with an all-gather of the logits.  The total work is fixed, so
+scaling is "strong".
+
+Prints ONE JSON line (rank 0).  `roofline` is the dominant kernel (the decode Q4_K GEMV) measured
+live with HIP events; `cpu_baseline` is the CPU restatement (oracle, kind "port") on the host cores.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from llamafile_amd import _hip, ggml_types as T, llama_shapes as LS, sgemm, synth  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F16_PEAK_TFLOPS = 2500.0  # dense f16/bf16 MFMA
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=3)
+    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--prefill", type=int, default=512)
+    p.add_argument("--decode", type=int, default=128)
+    p.add_argument("--no-graph", action="store_true")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--model", default="llama3-8b-q4_k_m", choices=["llama3-8b-q4_k_m", "llama3-8b-q8_0"])
+    return p.parse_args()
+
+
+class Op:
+    __slots__ = ("spec", "m", "k", "W", "args")
+
+
+class Runner:
+    """Holds the sharded weights and pre-allocated buffers; runs one pass of all mat-muls at batch n."""
+
+    def __init__(self, layers, rank, world, batches, dev):
+        self.L = _hip.lib()
+        self.rank, self.world, self.dev = rank, world, dev
+        self.flags = sgemm.host_variant_flags()
+        self.layers = []
+        seed = 0x5EED0000
+        for layer in layers:
+            ops = []
+            for spec in layer:
+                o = Op()
+                o.spec = spec
+                o.m, o.k = spec.m, spec.k
+                if world > 1:
+                    if spec.shard in ("rows", "vocab"):
+                        assert spec.m % world == 0
+                        o.m = spec.m // world
+                    else:
+                        assert spec.k % (world * T.BLCK[spec.type]) == 0, (spec.name, spec.k, world)
+                        o.k = spec.k // world
+                seed += 1
+                raw = synth.random_weights_torch(spec.type, o.m, o.k, seed * 131 + rank, dev)
+                o.W = sgemm.upload_weights(spec.type, raw, o.m, o.k, dev)
+                del raw
+                ops.append(o)
+            self.layers.append(ops)
+        torch.cuda.synchronize()
+        # buffers per batch size
+        self.buf = {}
+        for n in batches:
+            b = {"x": {}, "xq": {}, "out": {}}
+            ws = 16
+            for ops in self.layers:
+                for o in ops:
+                    key = (o.spec.input, o.k)
+                    if key not in b["x"]:
+                        g = torch.Generator(device=dev)
+                        g.manual_seed(1234 + len(b["x"]))
+                        b["x"][key] = torch.rand((n, o.k), device=dev, generator=g) * 2 - 1
+                        vdt = T.VEC_DOT[o.spec.type]
+                        b["xq"][key] = torch.empty((n, T.row_size(vdt, o.k)), dtype=torch.uint8, device=dev)
+                    mk = o.m if o.spec.shard != "vocab" else -o.m
+                    if mk not in b["out"]:
+                        b["out"][mk] = torch.empty((n, o.m), dtype=torch.float32, device=dev)
+                    ws = max(ws, sgemm.workspace_bytes(o.spec.type, o.m, o.k, n))
+            b["ws"] = torch.empty(ws, dtype=torch.uint8, device=dev)
+            if world > 1:
+                vm = [o for ops in self.layers for o in ops if o.spec.shard == "vocab"]
+                if vm:
+                    b["gather"] = torch.empty((world, n, vm[0].m), dtype=torch.float32, device=dev)
+            self.buf[n] = b
+
+    def weight_bytes(self):
+        return sum(o.W.nbytes for ops in self.layers for o in ops)
+
+    def run_pass(self, n, only_type=None, count=None):
+        """Launch every mat-mul (and the activation quantisation feeding it) at batch n on the current
+        stream.  `only_type`: restrict to GEMV/GEMM launches of one weight type, no quantise, no
+        collectives (roofline measurement)."""
+        L, b = self.L, self.buf[n]
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        ws, wsn = C.c_void_p(b["ws"].data_ptr()), b["ws"].numel()
+        launches = 0
+        for ops in self.layers:
+            done_inputs = set()
+            for o in ops:
+                key = (o.spec.input, o.k)
+                vdt = T.VEC_DOT[o.spec.type]
+                xq = b["xq"][key]
+                if only_type is None and key not in done_inputs:
+                    x = b["x"][key]
+                    rc = L.lfamd_quantize_rows(vdt, C.c_void_p(x.data_ptr()), n, o.k, o.k * 4, C.c_void_p(xq.data_ptr()),
+                                               xq.stride(0), stream)
+                    if rc:
+                        _hip.check(rc, "quantize_rows")
+                    done_inputs.add(key)
+                if only_type is not None and o.spec.type != only_type:
+                    continue
+                out = b["out"][o.m if o.spec.shard != "vocab" else -o.m]
+                rc = L.lfamd_mul_mat(o.spec.type, C.c_void_p(o.W.data.data_ptr()), o.m, o.k, vdt,
+                                     C.c_void_p(xq.data_ptr()), xq.stride(0), n, C.c_void_p(out.data_ptr()), o.m, ws, wsn,
+                                     self.flags, stream)
+                if rc:
+                    _hip.check(rc, "mul_mat " + o.spec.name)
+                launches += 1
+                if only_type is None and self.world > 1:
+                    if o.spec.shard == "cols":
+                        torch.distributed.all_reduce(out)
+                    elif o.spec.shard == "vocab":
+                        torch.distributed.all_gather_into_tensor(b["gather"], out)
+        return launches
+
+
+def cpu_baseline(layers, prefill, decode):
+    """Time the CPU restatement (oracle, scalar C + OpenMP over ith like sgemm_matmul_test.cpp:32-40)
+    on a bounded sample: one transformer layer (layer 0: 5 Q4_K + 2 Q6_K mat-muls) at n=1 and at
+    n=min(prefill, 32), extrapolated to the whole model (x n_layers, output.weight added at its byte /
+    flop share)."""
+    try:
+        from oracle import ora
+        ora.build()
+    except Exception as e:  # the oracle is test infrastructure; the bench line survives without it
+        return {"value": None, "unit": "tokens/s", "cores": 0, "kind": "port", "sample": f"unavailable: {e}"}
+    import numpy as np
+    nth = min(os.cpu_count() or 1, ora.lib().ora_max_threads())
+    layer = layers[0]
+    n_layers = len(layers) - 1
+    n_pf = min(prefill, 32)
+    t_dec = t_pf = 0.0
+    for spec in layer:
+        A = synth.random_weights(spec.type, spec.m, spec.k, 1)
+        vdt = T.VEC_DOT[spec.type]
+        B1 = synth.quantize_activations(vdt, synth.random_activations(1, spec.k, 2))
+        Bp = synth.quantize_activations(vdt, synth.random_activations(n_pf, spec.k, 3))
+        ora.sgemm_openmp(spec.type, A, vdt, B1, spec.m, 1, spec.k, nth)  # warm
+        t0 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            ora.sgemm_openmp(spec.type, A, vdt, B1, spec.m, 1, spec.k, nth)
+        t_dec += (time.perf_counter() - t0) / reps
+        t0 = time.perf_counter()
+        ora.sgemm_openmp(spec.type, A, vdt, Bp, spec.m, n_pf, spec.k, nth)
+        t_pf += time.perf_counter() - t0
+    # extrapolate: output.weight costs (its weight bytes / one layer's weight bytes) of a layer pass
+    lb = sum(LS.weight_bytes(s) for s in layer)
+    scale = n_layers + LS.weight_bytes(layers[-1][0]) / lb
+    t_decode_token = t_dec * scale
+    t_prefill = t_pf * scale * (prefill / n_pf)
+    total = t_prefill + decode * t_decode_token
+    return {
+        "value": round((prefill + decode) / total, 3), "unit": "tokens/s", "cores": nth, "kind": "port",
+        "sample": f"layer 0 (7 mat-muls) at n=1 x3 and n={n_pf} x1 on {nth} threads, extrapolated x{scale:.2f} layers "
+                  f"and x{prefill / n_pf:.0f} prefill columns; decode {1.0 / t_decode_token:.2f} tok/s, "
+                  f"prefill {prefill / t_prefill:.2f} tok/s",
+    }
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world and world == 1 and a.gpus > 1:
+        print("bench.py: --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    sgemm.init(local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.distributed.init_process_group("nccl", device_id=dev)
+
+    layers = LS.llama3_8b_q4_k_m() if a.model == "llama3-8b-q4_k_m" else LS.llama3_8b_q8_0()
+    runner = Runner(layers, rank, world, (a.prefill, 1), dev)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    use_graph = not a.no_graph and world == 1
+    graphs = {}
+    if use_graph:
+        for n in (a.prefill, 1):
+            runner.run_pass(n)  # warm (also sets any kernel attributes before capture)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                runner.run_pass(n)
+            graphs[n] = g
+
+    def one_pass(n):
+        if use_graph:
+            graphs[n].replay()
+        else:
+            runner.run_pass(n)
+
+    def step():
+        one_pass(a.prefill)
+        for _ in range(a.decode):
+            one_pass(1)
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed * 1000.0 / a.steps
+
+    # ---- phase split (informational): prefill pass and decode pass timed apart with events
+    def time_region(fn, reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        n_launch = 0
+        for _ in range(reps):
+            n_launch += fn() or 0
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3, n_launch  # microseconds
+
+    pf_us, _ = time_region(lambda: one_pass(a.prefill), 3)
+    dc_us, _ = time_region(lambda: one_pass(1), 20)
+    pf_us /= 3
+    dc_us /= 20
+
+    # ---- roofline of the dominant kernel: the decode GEMV of the dominant weight type, all its
+    # launches of one decode pass, back to back on the stream, timed with HIP events
+    dom_type = T.Q4_K if a.model == "llama3-8b-q4_k_m" else T.Q8_0
+    dom_ops = [o for ops in runner.layers for o in ops if o.spec.type == dom_type]
+    runner.run_pass(1, only_type=dom_type)
+    us, n_launch = time_region(lambda: runner.run_pass(1, only_type=dom_type), 10)
+    avg_us = us / n_launch
+    alg_bytes = sum(o.m * T.row_size(dom_type, o.k) + T.row_size(T.VEC_DOT[dom_type], o.k) + o.m * 4 for o in dom_ops)
+    avg_bytes = alg_bytes / len(dom_ops)
+    achieved = avg_bytes / (avg_us * 1e-6) / 1e9
+    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "kernel": f"gemv_{T.NAMES[dom_type].lower()}_kernel<1>", "launches_per_pass": len(dom_ops),
+                "avg_launch_us": round(avg_us, 3), "algorithmic_bytes_per_launch": int(avg_bytes)}
+
+    # ---- secondary: the prefill GEMM at the north-star shape (4096 x 4096 x 512, 1 GPU shapes only)
+    roofline_gemm = None
+    if world == 1 and a.model == "llama3-8b-q4_k_m":
+        o = runner.layers[0][0]
+        xq = runner.buf[a.prefill]["xq"][(o.spec.input, o.k)]
+        gus = sgemm.time_mul_mat(o.W, xq, T.Q8_K, a.prefill, warmup=5, iters=50)
+        fl = 2.0 * o.m * o.k * a.prefill
+        tf = fl / (gus * 1e-6) / 1e12
+        roofline_gemm = {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(tf / MFMA_F16_PEAK_TFLOPS, 4), "kernel": "prep_q8k + gemm_kq_kernel<Q4_K>",
+                         "shape": [o.m, o.k, a.prefill], "avg_launch_us": round(gus, 2)}
+
+    if rank != 0:
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
+
+    tokens = a.prefill + a.decode
+    out = {
+        "metric": "prefill + decode tokens/sec, Llama-3-8B Q4_K_M, 1/2/4/8 MI355X vs CPU tinyBLAS",
+        "value": round(tokens / (ms_per_step / 1000.0), 2),
+        "unit": "tokens/s",
+        "n_gpus": world,
+        "steps": a.steps,
+        "warmup": a.warmup,
+        "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "int8",
+        "data": "synthetic",
+        "config": {
+            "workload": f"Llama-3-8B Q4_K_M mat-muls (225 GGML_OP_MUL_MAT per pass incl. activation quantisation), "
+                        f"{a.prefill}-token prefill + {a.decode} decode, matmul-only",
+            "numerics": "exact int8 x int4/int6 block dot products with f32 scales (decode: v_dot4_i32_i8; prefill: "
+                        "f16 MFMA on the exact integer codes, f32 accumulate)",
+            "model": a.model, "prefill_tokens": a.prefill, "decode_tokens": a.decode,
+            "parallelism": "single GPU" if world == 1 else f"tp{world} (RCCL all-reduce on attn_output/ffn_down)",
+            "hip_graph": use_graph, "weight_bytes_per_gpu": runner.weight_bytes(),
+            "prefill_tokens_per_s": round(a.prefill / (pf_us * 1e-6), 1),
+            "decode_tokens_per_s": round(1.0 / (dc_us * 1e-6), 1),
+            "prefill_pass_ms": round(pf_us / 1e3, 3), "decode_pass_ms": round(dc_us / 1e3, 4),
+        },
+        "roofline": roofline,
+    }
+    if roofline_gemm:
+        out["roofline_prefill_gemm"] = roofline_gemm
+    if world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(layers, a.prefill, a.decode)
+    else:
+        out["cpu_baseline"] = None
+    print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

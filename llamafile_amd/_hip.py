@@ -56,6 +56,14 @@ def lib():
     """Load the HIP module; raises LfamdError (never falls back) when it is absent."""
     global _lib
     if _lib is None:
+        # PyTorch bundles its own libamdhip64/libhsa-runtime64; a process must not end up with two HSA
+        # runtimes, so when torch is the device-memory provider make sure ITS runtime is the one already
+        # loaded before our module's DT_NEEDED libamdhip64.so.7 is resolved.
+        if os.environ.get("LFAMD_NO_TORCH") != "1":
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         if not os.path.exists(HIP_SO):
             raise LfamdError(f"{HIP_SO} not built: the MI355X HIP module is required (no CPU fallback)")
         L = C.CDLL(HIP_SO)

@@ -1,0 +1,497 @@
+// sgemm_host.cpp — libllamafile_sgemm.so: the reference's CPU mat-mul plug-in ABI
+// (include/llamafile_sgemm.h), served by the MI355X HIP module through dlopen.
+//
+// Mirrors, on the host side:
+//   llamafile/sgemm.cpp:26-145      the dispatcher (here: "is the HIP module loaded?" instead of CPUID)
+//   llamafile/cuda.c:701-753        dlopen + symbol import of the GPU module
+//   tinyblas_cpu_sgemm.inc:45-331   which (Atype, Btype, Ctype) combinations are serviced
+//   tinyblas_cpu_mixmul.inc:77-398  llamafile_mixmul's tensor walking
+// It contains NO arithmetic: every product is computed by libllamafile_amd_hip.so.  When the module
+// or the GPU is missing every entry point answers `false` ("not serviced"), never a CPU result.
+#include "../../include/llamafile_sgemm.h"
+#include "../../include/lfamd_blocks.h"
+#include "../../include/lfamd_hip.h"
+
+#include <assert.h>
+#include <dlfcn.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+
+// ---- the imported device ABI (one pointer per include/lfamd_hip.h function) ----
+struct HipApi {
+    void *dso = nullptr;
+    decltype(&lfamd_abi_version) abi_version;
+    decltype(&lfamd_last_error) last_error;
+    decltype(&lfamd_device_count) device_count;
+    decltype(&lfamd_init) init;
+    decltype(&lfamd_malloc) malloc_;
+    decltype(&lfamd_free) free_;
+    decltype(&lfamd_memcpy_h2d) h2d;
+    decltype(&lfamd_memcpy_d2h) d2h;
+    decltype(&lfamd_stream_sync) sync;
+    decltype(&lfamd_packed_size) packed_size;
+    decltype(&lfamd_pack_weights) pack_weights;
+    decltype(&lfamd_quantize_rows) quantize_rows;
+    decltype(&lfamd_mul_mat_workspace) mul_mat_workspace;
+    decltype(&lfamd_mul_mat) mul_mat;
+    decltype(&lfamd_mul_mat_id_workspace) mul_mat_id_workspace;
+    decltype(&lfamd_mul_mat_id) mul_mat_id;
+};
+
+struct DevBuf { // grow-only device scratch
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct CachedWeights {
+    int type;
+    long rows, cols;
+    size_t row_bytes;
+    uint64_t fingerprint;
+    void *d_packed;
+    size_t bytes;
+};
+
+struct State {
+    std::once_flag once;
+    bool ok = false;
+    std::string error = "not initialised";
+    HipApi api;
+    std::mutex mu;
+    std::unordered_map<const void *, CachedWeights> cache;
+    DevBuf raw, b, c, ws, plan, x;
+    unsigned flags = 0;
+    int precise = 0;
+} g;
+
+template <typename T>
+bool import(void *dso, const char *name, T &fn, std::string &err) {
+    fn = (T)dlsym(dso, name);
+    if (!fn) {
+        err = std::string("missing symbol ") + name;
+        return false;
+    }
+    return true;
+}
+
+std::string module_path() {
+    if (const char *e = getenv("LFAMD_HIP_MODULE"))
+        return e;
+    Dl_info info;
+    if (dladdr((void *)&module_path, &info) && info.dli_fname) {
+        std::string p = info.dli_fname;
+        size_t slash = p.find_last_of('/');
+        return (slash == std::string::npos ? std::string(".") : p.substr(0, slash)) + "/libllamafile_amd_hip.so";
+    }
+    return "libllamafile_amd_hip.so";
+}
+
+void load_module() {
+    std::string path = module_path();
+    void *dso = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (!dso) {
+        g.error = std::string("dlopen failed: ") + dlerror();
+        return;
+    }
+    HipApi &a = g.api;
+    a.dso = dso;
+    std::string err;
+    bool ok = import(dso, "lfamd_abi_version", a.abi_version, err) && import(dso, "lfamd_last_error", a.last_error, err) &&
+              import(dso, "lfamd_device_count", a.device_count, err) && import(dso, "lfamd_init", a.init, err) &&
+              import(dso, "lfamd_malloc", a.malloc_, err) && import(dso, "lfamd_free", a.free_, err) &&
+              import(dso, "lfamd_memcpy_h2d", a.h2d, err) && import(dso, "lfamd_memcpy_d2h", a.d2h, err) &&
+              import(dso, "lfamd_stream_sync", a.sync, err) && import(dso, "lfamd_packed_size", a.packed_size, err) &&
+              import(dso, "lfamd_pack_weights", a.pack_weights, err) &&
+              import(dso, "lfamd_quantize_rows", a.quantize_rows, err) &&
+              import(dso, "lfamd_mul_mat_workspace", a.mul_mat_workspace, err) &&
+              import(dso, "lfamd_mul_mat", a.mul_mat, err) &&
+              import(dso, "lfamd_mul_mat_id_workspace", a.mul_mat_id_workspace, err) &&
+              import(dso, "lfamd_mul_mat_id", a.mul_mat_id, err);
+    if (!ok) {
+        g.error = err;
+        return;
+    }
+    if (a.abi_version() != LFAMD_ABI_VERSION) {
+        g.error = "HIP module ABI version mismatch";
+        return;
+    }
+    if (a.device_count() <= 0) {
+        g.error = "no HIP device";
+        return;
+    }
+    int dev = 0;
+    if (const char *e = getenv("LFAMD_DEVICE"))
+        dev = atoi(e);
+    if (a.init(dev) != LFAMD_OK) {
+        g.error = std::string("lfamd_init: ") + a.last_error();
+        return;
+    }
+    // which build of tinyBLAS_Q0 the reference would run on this host (sgemm.cpp:26-102)
+#if defined(__x86_64__)
+    if (__builtin_cpu_supports("avx512f"))
+        g.flags |= LFAMD_FLAG_Q0_VREGS32;
+#endif
+    g.ok = true;
+    g.error.clear();
+}
+
+bool available() {
+    std::call_once(g.once, load_module);
+    return g.ok;
+}
+
+bool reserve(DevBuf &b, size_t bytes) {
+    if (bytes <= b.cap)
+        return true;
+    if (b.p)
+        g.api.free_(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+    size_t want = bytes + bytes / 4 + 4096;
+    if (g.api.malloc_(&b.p, want) != LFAMD_OK)
+        return false;
+    b.cap = want;
+    return true;
+}
+
+uint64_t fingerprint(const void *p, size_t bytes) { // cheap: 3 x 64 bytes, FNV-1a
+    uint64_t h = 1469598103934665603ull;
+    const uint8_t *b = (const uint8_t *)p;
+    auto mix = [&](size_t off, size_t len) {
+        for (size_t i = 0; i < len && off + i < bytes; i++) {
+            h ^= b[off + i];
+            h *= 1099511628211ull;
+        }
+    };
+    mix(0, 64);
+    mix(bytes / 2, 64);
+    mix(bytes > 64 ? bytes - 64 : 0, 64);
+    return h ^ bytes;
+}
+
+unsigned flags_now() {
+    return g.flags | (g.precise ? LFAMD_FLAG_PRECISE : 0u);
+}
+
+// device copy of a weight matrix (rows x cols of `type`, host rows `row_bytes` apart), cached
+const CachedWeights *get_weights(int type, const void *A, long rows, long cols, size_t row_bytes) {
+    size_t total = (size_t)rows * row_bytes;
+    uint64_t fp = fingerprint(A, total);
+    auto it = g.cache.find(A);
+    if (it != g.cache.end()) {
+        CachedWeights &w = it->second;
+        if (w.type == type && w.rows == rows && w.cols == cols && w.row_bytes == row_bytes && w.fingerprint == fp)
+            return &w;
+        g.api.free_(w.d_packed);
+        g.cache.erase(it);
+    }
+    if (!reserve(g.raw, total))
+        return nullptr;
+    if (g.api.h2d(g.raw.p, A, total, nullptr) != LFAMD_OK)
+        return nullptr;
+    CachedWeights w{type, rows, cols, row_bytes, fp, nullptr, g.api.packed_size(type, rows, cols)};
+    if (g.api.malloc_(&w.d_packed, w.bytes) != LFAMD_OK)
+        return nullptr;
+    if (g.api.pack_weights(type, rows, cols, g.raw.p, row_bytes, w.d_packed, nullptr) != LFAMD_OK ||
+        g.api.sync(nullptr) != LFAMD_OK) {
+        g.api.free_(w.d_packed);
+        return nullptr;
+    }
+    return &(g.cache[A] = w);
+}
+
+bool is_quant(int t) {
+    return lfamd_blck_size(t) > 1;
+}
+
+// Which requests llamafile_sgemm services — same table as the reference's x86 builds
+// (tinyblas_cpu_sgemm.inc:45-240 + the iqk pre-dispatch :286-304).
+bool sgemm_supported(long n, int Atype, int Btype, int Ctype) {
+    if (Ctype != LFAMD_TYPE_F32)
+        return false;
+    switch (Atype) {
+    case LFAMD_TYPE_F32:
+        return Btype == LFAMD_TYPE_F32;
+    case LFAMD_TYPE_F16:
+    case LFAMD_TYPE_BF16:
+        if (Btype == LFAMD_TYPE_F32)
+            return n <= 2; // else WANT_QUANTIZATION (:70-76, :123-129)
+        return Btype == Atype;
+    case LFAMD_TYPE_Q8_0:
+    case LFAMD_TYPE_Q4_0:
+    case LFAMD_TYPE_Q5_0:
+    case LFAMD_TYPE_Q4_1:
+    case LFAMD_TYPE_Q5_1:
+    case LFAMD_TYPE_Q2_K:
+    case LFAMD_TYPE_Q3_K:
+    case LFAMD_TYPE_Q4_K:
+    case LFAMD_TYPE_Q5_K:
+    case LFAMD_TYPE_Q6_K:
+    case LFAMD_TYPE_IQ4_XS:
+        return Btype == lfamd_vec_dot_type(Atype);
+    default:
+        return false;
+    }
+}
+
+// C[j*ldc + i] for j < n from host A, B -> host C.  Caller holds g.mu.
+bool run_mul_mat(int Atype, const void *A, long m, long kelems, size_t a_row_bytes, int Btype, const void *B,
+                 size_t b_row_bytes, long n, float *C, long ldc) {
+    if (m == 0 || n == 0)
+        return true;
+    const CachedWeights *w = get_weights(Atype, A, m, kelems, a_row_bytes);
+    if (!w)
+        return false;
+    // C spans (n-1)*ldc + m floats (the last column is not padded to ldc)
+    size_t bbytes = (size_t)n * b_row_bytes, cbytes = ((size_t)(n - 1) * (size_t)ldc + (size_t)m) * 4;
+    size_t wsb = g.api.mul_mat_workspace(Atype, m, kelems, n);
+    if (!reserve(g.b, bbytes) || !reserve(g.c, cbytes) || !reserve(g.ws, wsb))
+        return false;
+    if (g.api.h2d(g.b.p, B, bbytes, nullptr) != LFAMD_OK)
+        return false;
+    if (ldc != m) // keep the caller's bytes in the gaps of C
+        if (g.api.h2d(g.c.p, C, cbytes, nullptr) != LFAMD_OK)
+            return false;
+    if (g.api.mul_mat(Atype, w->d_packed, m, kelems, Btype, g.b.p, b_row_bytes, n, (float *)g.c.p, ldc, g.ws.p, g.ws.cap,
+                      flags_now(), nullptr) != LFAMD_OK)
+        return false;
+    if (g.api.d2h(C, g.c.p, cbytes, nullptr) != LFAMD_OK)
+        return false;
+    return g.api.sync(nullptr) == LFAMD_OK;
+}
+
+[[noreturn]] void die(const char *what) {
+    fprintf(stderr, "llamafile_sgemm (MI355X): %s: %s\n", what, g.ok ? g.api.last_error() : g.error.c_str());
+    abort();
+}
+
+} // namespace
+
+extern "C" {
+
+int llamafile_sgemm_amd_available(void) {
+    return available() ? 1 : 0;
+}
+
+const char *llamafile_sgemm_amd_error(void) {
+    return g.error.c_str();
+}
+
+void llamafile_sgemm_amd_set_precise(int precise) {
+    g.precise = precise;
+}
+
+void llamafile_sgemm_amd_forget(const void *A) {
+    if (!available())
+        return;
+    std::lock_guard<std::mutex> lk(g.mu);
+    for (auto it = g.cache.begin(); it != g.cache.end();) {
+        if (it->first == A) {
+            g.api.free_(it->second.d_packed);
+            it = g.cache.erase(it);
+        } else {
+            ++it;
+        }
+    }
+}
+
+void llamafile_sgemm_amd_reset(void) {
+    if (!available())
+        return;
+    std::lock_guard<std::mutex> lk(g.mu);
+    for (auto &kv : g.cache)
+        g.api.free_(kv.second.d_packed);
+    g.cache.clear();
+}
+
+bool llamafile_sgemm(long m, long n, long k, const void *A, long lda, const void *B, long ldb, void *C, long ldc,
+                     int ith, int nth, int Atype, int Btype, int Ctype) {
+    assert(m >= 0);
+    assert(n >= 0);
+    assert(k >= 0);
+    assert(lda >= k);
+    assert(ldb >= k);
+    assert(ldc >= m);
+    assert(nth > 0);
+    assert(ith < nth);
+    if (!available() || !sgemm_supported(n, Atype, Btype, Ctype))
+        return false; // same answer on every thread: a pure function of the arguments
+    if (ith != 0)
+        return true;
+    std::lock_guard<std::mutex> lk(g.mu);
+    const long kelems = k * lfamd_blck_size(Atype);
+    const size_t a_row = (size_t)lda * lfamd_type_size(Atype), b_row = (size_t)ldb * lfamd_type_size(Btype);
+    if (!run_mul_mat(Atype, A, m, kelems, a_row, Btype, B, b_row, n, (float *)C, ldc))
+        die("device mat-mul failed after the request was accepted");
+    return true;
+}
+
+bool iqk_mul_mat(long Nx, long Ny, long ne00, int typeA, const void *A, const void *B, float *C, long stride_C, int ith,
+                 int nth) {
+    if (!available() || !is_quant(typeA) || typeA == LFAMD_TYPE_Q8_0 || ne00 % lfamd_blck_size(typeA))
+        return false; // x86 set_mul_mat has no Q8_0 case (iqk_mul_mat.inc:1408-1463)
+    const int bt = lfamd_vec_dot_type(typeA);
+    if (!sgemm_supported(Ny, typeA, bt, LFAMD_TYPE_F32))
+        return false;
+    if (ith != 0)
+        return true;
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (!run_mul_mat(typeA, A, Nx, ne00, lfamd_row_size(typeA, ne00), bt, B, lfamd_row_size(bt, ne00), Ny, C, stride_C))
+        die("device mat-mul failed after the request was accepted");
+    return true;
+}
+
+bool iqk_mul_mat_moe(long Nx, long Ny, long ne00, int ne11, int typeA, const void *A, const void *B, float *C, long nb1,
+                     long nb2, const void *vrow_mapping, int ith, int nth) {
+    assert(vrow_mapping != nullptr);
+    if (!available() || !is_quant(typeA) || typeA == LFAMD_TYPE_Q8_0 || ne00 % lfamd_blck_size(typeA))
+        return false;
+    const int bt = lfamd_vec_dot_type(typeA);
+    if (!sgemm_supported(Ny, typeA, bt, LFAMD_TYPE_F32))
+        return false;
+    if (ith != 0)
+        return true;
+    std::lock_guard<std::mutex> lk(g.mu);
+    const lfamd_mmid_row_mapping *map = (const lfamd_mmid_row_mapping *)vrow_mapping;
+    const size_t brow = lfamd_row_size(bt, ne00);
+    // gather the mapped activation rows (DataInfo::src1_row, iqk_mul_mat.inc:84-88)
+    std::vector<uint8_t> bg((size_t)Ny * brow);
+    for (long iy = 0; iy < Ny; iy++) {
+        size_t src = ((size_t)(map[iy].i1 % ne11) + (size_t)map[iy].i2 * ne11) * brow;
+        memcpy(bg.data() + (size_t)iy * brow, (const uint8_t *)B + src, brow);
+    }
+    std::vector<float> cg((size_t)Ny * (size_t)Nx);
+    if (!run_mul_mat(typeA, A, Nx, ne00, lfamd_row_size(typeA, ne00), bt, bg.data(), brow, Ny, cg.data(), Nx))
+        die("device mat-mul failed after the request was accepted");
+    for (long iy = 0; iy < Ny; iy++) { // DataInfo::dst_row, iqk_mul_mat.inc:94-101
+        float *dst = C + (size_t)map[iy].i1 * (nb1 / sizeof(float)) + (size_t)map[iy].i2 * (nb2 / sizeof(float));
+        memcpy(dst, cg.data() + (size_t)iy * Nx, (size_t)Nx * sizeof(float));
+    }
+    return true;
+}
+
+bool llamafile_mixmul_iqk(long Nx, long Ny, long ne00, int ne11, int typeA, const void *A, const void *B, float *C,
+                          long nb1, long nb2, const void *vrow_mapping, int ith, int nth) {
+    return iqk_mul_mat_moe(Nx, Ny, ne00, ne11, typeA, A, B, C, nb1, nb2, vrow_mapping, ith, nth);
+}
+
+size_t llamafile_mixmul_needs(const struct ggml_tensor *, const struct ggml_tensor *, const struct ggml_tensor *) {
+    return 0; // the device path needs none of the caller's params->wdata scratch
+}
+
+bool llamafile_mixmul(const struct ggml_compute_params *params, const struct ggml_tensor *weights,
+                      const struct ggml_tensor *thought, const struct ggml_tensor *plan, struct ggml_tensor *result) {
+    const long rows = weights->ne[1], cols = weights->ne[0], tokens = thought->ne[2];
+    const int experts = (int)weights->ne[2], thinkers = (int)plan->ne[0], tasks = (int)thought->ne[1];
+    // invariants asserted by the reference (tinyblas_cpu_mixmul.inc:112-133)
+    assert(tasks <= thinkers);
+    assert(thinkers <= experts);
+    assert(tokens == plan->ne[1]);
+    assert(rows == result->ne[0]);
+    assert(cols == thought->ne[0]);
+    assert(tokens == result->ne[2]);
+    assert(thinkers == result->ne[1]);
+    assert(params->nth > 0 && params->ith < params->nth);
+    const int wt = weights->type;
+    if (!available() || !is_quant(wt) || plan->type != LFAMD_TYPE_I32 || result->type != LFAMD_TYPE_F32)
+        return false;
+    const int bt = lfamd_vec_dot_type(wt);
+    if (bt < 0 || cols % lfamd_blck_size(wt))
+        return false;
+    if (thought->type != LFAMD_TYPE_F32 && thought->type != bt)
+        return false;
+    // no column strides (:140-146)
+    if (weights->nb[0] != lfamd_type_size(wt) || thought->nb[0] != lfamd_type_size(thought->type) ||
+        result->nb[0] != sizeof(float) || weights->nb[1] % lfamd_type_size(wt))
+        return false;
+    if (params->ith != 0)
+        return true;
+
+    std::lock_guard<std::mutex> lk(g.mu);
+    const size_t packed = g.api.packed_size(wt, rows, cols);
+    // experts packed back to back in one device allocation, cached under the tensor's data pointer
+    const CachedWeights *w = nullptr;
+    {
+        size_t span = (size_t)experts * weights->nb[2];
+        uint64_t fp = fingerprint(weights->data, span);
+        auto it = g.cache.find(weights->data);
+        if (it != g.cache.end() && it->second.type == wt && it->second.rows == rows * experts && it->second.cols == cols &&
+            it->second.fingerprint == fp) {
+            w = &it->second;
+        } else {
+            if (it != g.cache.end()) {
+                g.api.free_(it->second.d_packed);
+                g.cache.erase(it);
+            }
+            CachedWeights nw{wt, rows * experts, cols, weights->nb[1], fp, nullptr, packed * experts};
+            if (g.api.malloc_(&nw.d_packed, nw.bytes) != LFAMD_OK)
+                die("device allocation for expert weights failed");
+            for (int e = 0; e < experts; e++) {
+                size_t ebytes = (size_t)rows * weights->nb[1];
+                if (!reserve(g.raw, ebytes) ||
+                    g.api.h2d(g.raw.p, (const uint8_t *)weights->data + (size_t)e * weights->nb[2], ebytes, nullptr) ||
+                    g.api.pack_weights(wt, rows, cols, g.raw.p, weights->nb[1], (uint8_t *)nw.d_packed + (size_t)e * packed,
+                                       nullptr) ||
+                    g.api.sync(nullptr))
+                    die("expert weight upload failed");
+            }
+            w = &(g.cache[weights->data] = nw);
+        }
+    }
+    // activations: contiguous [tokens][tasks] rows on the device, quantised there if given as f32
+    const size_t brow = lfamd_row_size(bt, cols);
+    const size_t nrows = (size_t)tokens * tasks;
+    if (!reserve(g.b, nrows * brow))
+        die("device allocation failed");
+    if (thought->type == LFAMD_TYPE_F32) {
+        if (!reserve(g.x, nrows * (size_t)cols * 4))
+            die("device allocation failed");
+        for (long t = 0; t < tokens; t++)
+            for (int k = 0; k < tasks; k++)
+                if (g.api.h2d((uint8_t *)g.x.p + ((size_t)t * tasks + k) * cols * 4,
+                              (const uint8_t *)thought->data + (size_t)t * thought->nb[2] + (size_t)k * thought->nb[1],
+                              (size_t)cols * 4, nullptr))
+                    die("activation upload failed");
+        if (g.api.quantize_rows(bt, (const float *)g.x.p, (long)nrows, cols, (size_t)cols * 4, g.b.p, brow, nullptr))
+            die("activation quantisation failed");
+    } else {
+        for (long t = 0; t < tokens; t++)
+            for (int k = 0; k < tasks; k++)
+                if (g.api.h2d((uint8_t *)g.b.p + ((size_t)t * tasks + k) * brow,
+                              (const uint8_t *)thought->data + (size_t)t * thought->nb[2] + (size_t)k * thought->nb[1], brow,
+                              nullptr))
+                    die("activation upload failed");
+    }
+    // routing table, contiguous [tokens][thinkers]
+    std::vector<int32_t> hplan((size_t)tokens * thinkers);
+    for (long t = 0; t < tokens; t++)
+        for (int th = 0; th < thinkers; th++)
+            hplan[(size_t)t * thinkers + th] =
+                *(const int32_t *)((const uint8_t *)plan->data + (size_t)t * plan->nb[1] + (size_t)th * plan->nb[0]);
+    size_t rbytes = (size_t)tokens * thinkers * rows * 4;
+    size_t wsb = g.api.mul_mat_id_workspace(wt, rows, cols, experts, tokens, thinkers);
+    if (!reserve(g.plan, hplan.size() * 4) || !reserve(g.c, rbytes) || !reserve(g.ws, wsb))
+        die("device allocation failed");
+    if (g.api.h2d(g.plan.p, hplan.data(), hplan.size() * 4, nullptr) || g.api.sync(nullptr))
+        die("plan upload failed");
+    if (g.api.mul_mat_id(wt, w->d_packed, rows, cols, experts, bt, g.b.p, brow, tasks, tokens, (const int32_t *)g.plan.p,
+                         thinkers, (float *)g.c.p, g.ws.p, g.ws.cap, flags_now(), nullptr))
+        die("device mul_mat_id failed");
+    std::vector<float> hres((size_t)tokens * thinkers * rows);
+    if (g.api.d2h(hres.data(), g.c.p, rbytes, nullptr) || g.api.sync(nullptr))
+        die("result download failed");
+    for (long t = 0; t < tokens; t++)
+        for (int th = 0; th < thinkers; th++)
+            memcpy((uint8_t *)result->data + (size_t)t * result->nb[2] + (size_t)th * result->nb[1],
+                   hres.data() + ((size_t)t * thinkers + th) * rows, (size_t)rows * 4);
+    return true;
+}
+}

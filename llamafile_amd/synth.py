@@ -144,3 +144,25 @@ def quantize_activations(vec_dot_type: int, x: np.ndarray) -> np.ndarray:
     if vec_dot_type == T.BF16:
         return f32_to_bf16(x).view(np.uint8).reshape(x.shape[0], -1)
     raise ValueError(vec_dot_type)
+
+
+def random_weights_torch(t: int, rows: int, cols: int, seed: int, device="cuda"):
+    """Same recipe as random_weights() but generated on the device (bench-sized tensors: GBs).
+    Returns a torch uint8 tensor [rows, row_size]."""
+    import torch
+
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    nb = cols // T.BLCK[t]
+    ts = T.TYPE_SIZE[t]
+    raw = torch.randint(0, 256, (rows, nb, ts), dtype=torch.uint8, device=device, generator=g)
+    d_off, s_off = _SCALE_OFF[t]
+    d = torch.exp2(torch.rand((rows, nb), device=device, generator=g) * 4.0 - 10.0).to(torch.float16)
+    raw[:, :, d_off:d_off + 2] = d.view(torch.uint8).reshape(rows, nb, 2)
+    if s_off is not None:
+        s = (torch.rand((rows, nb), device=device, generator=g) * (2.0 ** -7)).to(torch.float16)
+        raw[:, :, s_off:s_off + 2] = s.view(torch.uint8).reshape(rows, nb, 2)
+    if t == T.Q8_0:
+        q = raw[:, :, 2:].view(torch.int8)
+        q[q == -128] = -127
+    return raw.reshape(rows, nb * ts)

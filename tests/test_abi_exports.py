@@ -1,0 +1,70 @@
+"""CPU-side checks of the C-ABI libraries: they load, and export every symbol the headers declare.
+No compute call is made (there is no GPU here)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+from llamafile_amd import _hip, ggml_types as T
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions(header):
+    src = open(os.path.join(ROOT, "include", header)).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"static inline[^{]*\{.*?\n\}", "", src, flags=re.S)
+    names = re.findall(r"\b([a-z_][a-z0-9_]*)\s*\([^;{]*\)\s*;", src)
+    return sorted(set(n for n in names if n.startswith(("lfamd_", "llamafile_", "iqk_"))))
+
+
+def test_hip_module_exports_every_declared_symbol():
+    assert os.path.exists(_hip.HIP_SO), "run __graft_entry__.build() first"
+    lib = C.CDLL(_hip.HIP_SO)
+    fns = declared_functions("lfamd_hip.h")
+    assert len(fns) >= 18
+    for name in fns:
+        assert hasattr(lib, name), name
+    assert set(_hip.EXPORTS) <= set(fns)
+    assert lib.lfamd_abi_version() == 1
+
+
+def test_host_plugin_exports_reference_abi():
+    lib = C.CDLL(_hip.HOST_SO)
+    fns = declared_functions("llamafile_sgemm.h")
+    for name in ("llamafile_sgemm", "llamafile_mixmul", "llamafile_mixmul_needs", "llamafile_mixmul_iqk", "iqk_mul_mat",
+                 "iqk_mul_mat_moe"):
+        assert name in fns
+    for name in fns:
+        assert hasattr(lib, name), name
+
+
+def test_packed_size_is_exactly_gguf_size_for_aligned_shapes():
+    lib = _hip.lib()
+    for t in (T.Q4_K, T.Q6_K, T.Q8_0):
+        assert lib.lfamd_packed_size(t, 4096, 4096) == 4096 * T.row_size(t, 4096)
+    assert lib.lfamd_packed_size(T.Q4_K, 33, 256) == 2 * 4608  # rows round up to 32
+    assert lib.lfamd_packed_size(T.Q4_K, 32, 100) == 0  # cols not a block multiple
+    assert lib.lfamd_packed_size(99, 32, 256) == 0  # unknown type
+
+
+def test_host_plugin_answers_false_without_a_gpu():
+    """sgemm.cpp's contract: `false` = not serviced, the caller falls back.  Without an MI355X the
+    plug-in must say false (never compute on the CPU, never crash)."""
+    import torch
+    if torch.cuda.is_available():
+        return
+    lib = C.CDLL(_hip.HOST_SO)
+    lib.llamafile_sgemm.restype = C.c_bool
+    lib.llamafile_sgemm.argtypes = [C.c_long] * 3 + [C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_void_p, C.c_long] + \
+        [C.c_int] * 5
+    A = np.zeros((4, 144), dtype=np.uint8)
+    B = np.zeros((1, 292), dtype=np.uint8)
+    Cm = np.zeros((1, 4), dtype=np.float32)
+    ok = lib.llamafile_sgemm(4, 1, 1, A.ctypes.data, 1, B.ctypes.data, 1, Cm.ctypes.data, 4, 0, 1, T.Q4_K, T.Q8_K, T.F32)
+    assert ok is False
+    lib.llamafile_sgemm_amd_available.restype = C.c_int
+    assert lib.llamafile_sgemm_amd_available() == 0
+    lib.llamafile_sgemm_amd_error.restype = C.c_char_p
+    assert lib.llamafile_sgemm_amd_error()
