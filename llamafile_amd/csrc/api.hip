@@ -15,8 +15,9 @@ hipError_t lfamd_launch_pack_q6k(const void *, size_t, long, long, void *, hipSt
 hipError_t lfamd_launch_pack_q80(const void *, size_t, long, long, void *, hipStream_t);
 hipError_t lfamd_launch_pack_raw(const void *, size_t, long, size_t, void *, hipStream_t);
 hipError_t lfamd_launch_prep_q8k(const void *, size_t, long, long, long, void *, void *, void *, hipStream_t);
+hipError_t lfamd_launch_prep_f32(const void *, size_t, long, long, long, void *, void *, void *, hipStream_t);
 hipError_t lfamd_launch_generic(int, const void *, long, long, int, const void *, size_t, long, float *, long, hipStream_t);
-hipError_t lfamd_launch_gemv(int, const void *, long, long, const void *, size_t, long, float *, long, int, int,
+hipError_t lfamd_launch_gemv(int, const void *, long, long, int, const void *, size_t, long, float *, long, int, int,
                              hipStream_t);
 hipError_t lfamd_launch_gemm_kq(int, const void *, long, long, const void *, const void *, const void *, long, long,
                                 float *, long, hipStream_t);
@@ -199,12 +200,23 @@ static bool use_gemv(int Atype, long n, unsigned flags) {
     return n <= 8 && (Atype == LFAMD_TYPE_Q4_K || Atype == LFAMD_TYPE_Q6_K);
 }
 
-size_t lfamd_mul_mat_workspace(int Atype, long m, long k, long n) {
+static bool gemv_quantise_separately(int Atype, long m) {
+    (void)Atype;
     (void)m;
-    if (!use_gemm(Atype, n, 0))
+    return false; // persistent GEMV work-groups stage the activations once each: fused is always cheaper
+}
+
+size_t lfamd_mul_mat_workspace(int Atype, long m, long k, long n) {
+    if (use_gemv(Atype, n, 0) && gemv_quantise_separately(Atype, m))
+        return align_up((size_t)n * lfamd_row_size(lfamd_vec_dot_type(Atype), k), 256);
+    if (use_gemm(Atype, n, 0)) {
+        size_t n_pad = align_up((size_t)n, 64), nb = (size_t)(k / 256);
+        return align_up(n_pad * (size_t)k * 2, 256) + align_up(nb * n_pad * 4, 256) + align_up(n_pad * nb * 32, 256);
+    }
+    if (use_gemv(Atype, n, 0) || !type_known(Atype) || lfamd_blck_size(Atype) == 1)
         return 0;
-    size_t n_pad = align_up((size_t)n, 64), nb = (size_t)(k / 256);
-    return align_up(n_pad * (size_t)k * 2, 256) + align_up(nb * n_pad * 4, 256) + align_up(n_pad * nb * 32, 256);
+    // generic kernels given f32 activations quantise them into the workspace first
+    return align_up((size_t)n * lfamd_row_size(lfamd_vec_dot_type(Atype), k), 256);
 }
 
 int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const void *d_B, size_t b_row_bytes, long n,
@@ -218,8 +230,9 @@ int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const v
     if (float_a) {
         if (!(Btype == LFAMD_TYPE_F32 || Btype == Atype))
             return fail(LFAMD_ERR_UNSUPPORTED, "mul_mat: float weights need F32 or same-type activations%s", "");
-    } else if (Btype != vdt) {
-        return fail(LFAMD_ERR_UNSUPPORTED, "mul_mat: activations must be in the weight type's vec_dot format%s", "");
+    } else if (Btype != vdt && Btype != LFAMD_TYPE_F32) {
+        // f32 activations (the GGML_OP_MUL_MAT boundary) are quantised on the device to vdt
+        return fail(LFAMD_ERR_UNSUPPORTED, "mul_mat: activations must be F32 or the weight type's vec_dot format%s", "");
     }
     if (b_row_bytes < lfamd_row_size(Btype, k))
         return fail(LFAMD_ERR_INVALID, "mul_mat: activation row stride too small%s", "");
@@ -237,16 +250,37 @@ int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const v
         void *Xh = ws;
         void *d8T = ws + align_up(n_pad * (size_t)k * 2, 256);
         void *Xm = (uint8_t *)d8T + align_up(nb * n_pad * 4, 256);
-        HIPCHK(lfamd_launch_prep_q8k(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, s), "prep_q8k");
+        if (Btype == LFAMD_TYPE_F32)
+            HIPCHK(lfamd_launch_prep_f32(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, s), "prep_f32");
+        else
+            HIPCHK(lfamd_launch_prep_q8k(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, s), "prep_q8k");
         HIPCHK(lfamd_launch_gemm_kq(Atype, d_A, m, k, Xh, d8T, Xm, n, (long)n_pad, d_C, ldc, s), "gemm_kq");
         return LFAMD_OK;
     }
     if (use_gemv(Atype, n, flags)) {
-        HIPCHK(lfamd_launch_gemv(Atype, d_A, m, k, d_B, b_row_bytes, n, d_C, ldc, vregs32, precise, s), "gemv");
+        if (Btype == LFAMD_TYPE_F32 && gemv_quantise_separately(Atype, m)) {
+            // very tall matrices (output.weight): thousands of work-groups would each re-quantise the same
+            // activation vector; quantise it once into the workspace instead
+            size_t qrow = lfamd_row_size(vdt, k), need = align_up((size_t)n * qrow, 256);
+            if (ws_bytes < need || !d_ws)
+                return fail(LFAMD_ERR_WORKSPACE, "mul_mat: workspace too small%s", "");
+            HIPCHK(lfamd_launch_quantize(vdt, (const float *)d_B, n, k, b_row_bytes, d_ws, qrow, s), "quantize_rows");
+            HIPCHK(lfamd_launch_gemv(Atype, d_A, m, k, vdt, d_ws, qrow, n, d_C, ldc, vregs32, precise, s), "gemv");
+            return LFAMD_OK;
+        }
+        HIPCHK(lfamd_launch_gemv(Atype, d_A, m, k, Btype, d_B, b_row_bytes, n, d_C, ldc, vregs32, precise, s), "gemv");
         return LFAMD_OK;
     }
     if (Atype == LFAMD_TYPE_Q4_K || Atype == LFAMD_TYPE_Q6_K || Atype == LFAMD_TYPE_Q8_0)
         return fail(LFAMD_ERR_UNSUPPORTED, "mul_mat: FORCE_GENERIC needs RAW-layout weights; this type is packed%s", "");
+    if (!float_a && Btype == LFAMD_TYPE_F32) {
+        size_t qrow = lfamd_row_size(vdt, k), need = align_up((size_t)n * qrow, 256);
+        if (ws_bytes < need || !d_ws)
+            return fail(LFAMD_ERR_WORKSPACE, "mul_mat: workspace too small%s", "");
+        HIPCHK(lfamd_launch_quantize(vdt, (const float *)d_B, n, k, b_row_bytes, d_ws, qrow, s), "quantize_rows");
+        HIPCHK(lfamd_launch_generic(Atype, d_A, m, k, vdt, d_ws, qrow, n, d_C, ldc, s), "generic");
+        return LFAMD_OK;
+    }
     HIPCHK(lfamd_launch_generic(Atype, d_A, m, k, Btype, d_B, b_row_bytes, n, d_C, ldc, s), "generic");
     return LFAMD_OK;
 }

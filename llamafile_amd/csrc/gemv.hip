@@ -1,224 +1,371 @@
 // gemv.hip — wave-reduction GEMV kernels for the batch-1 (decode) case and small batches n <= 8.
 //
-// Replaces the reference's mul_mat_vec_q (ggml-cuda.cu.patch:14428-14575: 32-wide warps, dp4a with a
-// scalar fallback on gfx950) and follows the CPU path's arithmetic:
+// Replaces the reference's mul_mat_vec_q + quantize_q8_1 pair (ggml-cuda.cu.patch:14428-14575,
+// 15259-15293: 32-wide warps, dp4a with a scalar fallback on gfx950) and follows the CPU
+// path's arithmetic:
 //   Q4_K / Q6_K x Q8_K : mul_mat_qX_K_q8_K_T (iqk_mul_mat.inc:601-643) — exact int8 block dots,
-//                        f32 scales; the -32 offset of Q6_K is folded into a bsums term like
+//                        f32 scales; the -32 offset of Q6_K is folded into a sums term like
 //                        DequantizerQ6K does (iqk_mul_mat.inc:570-599).
 //   Q8_0 x Q8_0        : tinyBLAS_Q0_AVX2::gemm (tinyblas_cpu.h:934-971) BIT-EXACT: 8 f32 lanes per
 //                        output, blocks accumulated sequentially with fma (or Kahan), same hsum tree.
 //
+// Activations may arrive already quantised (the llamafile_sgemm boundary: Btype = Q8_K / Q8_0) or as
+// f32 (the GGML_OP_MUL_MAT boundary): then every work-group quantises the (tiny) activation vector
+// itself in its prologue, bit-identically to quantize_row_q8_K / q8_0, which removes one launch and
+// one HBM round trip per mat-mul.
+//
 // These are HBM-bandwidth kernels: weights stream once from the packed layout with one
 // global_load_dwordx4 per lane (1 KiB per wave instruction) straight into VGPRs — no LDS round
-// trip for the weights (cdna_hip_programming.md §5 "GEMV / M <= 16" row); only the tiny activation
-// vector is staged in LDS, byte-permuted once so the int8 dot needs no shuffles.
+// trip for the weights (cdna_hip_programming.md §5 "GEMV / M <= 16" row).  The first chunk of
+// weight loads is issued BEFORE the activation staging so HBM latency overlaps it, and the next
+// chunk is always in flight while the current one is consumed.
 #include "lfamd_device.h"
 
-// LDS image of one Q8_K activation block for the K-quant GEMVs
-#define XBLK 336 // 256 permuted q8 + 32 half-sums (i16) + f32 d + pad
+// LDS image of one Q8_K activation block for the K-quant GEMVs.  A lane = (gsel, h) reads its 64 code
+// bytes (two groups g = 2gsel+gi, four K-steps dd each) with four ds_read_b128, its 8 half-sums with
+// one more, its 4 sub-block sums with a ds_read_b64.
+//   [0,256)    codes: 8-byte groups at position pos = 16 gsel + 8 h + 4 gi + dd
+//   [256,320)  hb  : int16 sum of each 8-byte group, same position order
+//   [320,352)  ps  : int16 sum of K-step pairs (dd = 2e, 2e+1): position 8 gsel + 4 h + 2 gi + e
+//   [352,356)  d   : f32 block scale
+#define XBLK 368
 #define XBLK_HB 256
-#define XBLK_D 320
+#define XBLK_PS 320
+#define XBLK_D 352
 
-// Stage `nc` activation rows (Q8_K, llamafile order) into LDS.  Within every aligned 8-byte group
-// the bytes (y0..y7) are stored as (y0,y4,y1,y5 | y2,y6,y3,y7): the order in which
-// (x & 0x0F0F0F0F) and ((x>>4) & 0x0F0F0F0F) expose the nibbles of a packed K-step dword.
+// Within every 8-byte group the codes (y0..y7) are stored as (y0,y4,y1,y5 | y2,y6,y3,y7): the order
+// in which (x & 0x0F0F0F0F) and ((x>>4) & 0x0F0F0F0F) expose the nibbles of a packed K-step dword.
+// grp = (k offset)/8 = 16 gsel + 8 gi + 2 dd + h.  Returns the group's code sum.
+__device__ static inline int put_group(uint8_t *dst, int grp, uint32_t y0, uint32_t y1) {
+    const uint32_t p0 = __builtin_amdgcn_perm(y1, y0, 0x05010400);
+    const uint32_t p1 = __builtin_amdgcn_perm(y1, y0, 0x07030602);
+    const int pos = (grp & 16) | ((grp & 1) << 3) | ((grp & 8) >> 1) | ((grp >> 1) & 3);
+    *(uint2 *)(dst + 8 * pos) = make_uint2(p0, p1);
+    int hs = sdot4(y0, 0x01010101u, 0);
+    hs = sdot4(y1, 0x01010101u, hs);
+    *(int16_t *)(dst + XBLK_HB + 2 * pos) = (int16_t)hs;
+    return hs;
+}
+
+// pair sum of groups grp (dd even) and grp+2 (dd odd), written by the even one
+__device__ static inline void put_pair(uint8_t *dst, int grp, int hs_even_plus_odd) {
+    const int pp = ((grp & 16) >> 1) | ((grp & 1) << 2) | ((grp & 8) >> 2) | ((grp >> 2) & 1);
+    *(int16_t *)(dst + XBLK_PS + 2 * pp) = (int16_t)hs_even_plus_odd;
+}
+
+// already-quantised Q8_K rows (llamafile field order {d, bsums[16], qs[256]}); blockDim % 32 == 0
 __device__ static inline void stage_q8k(uint8_t *lds, const uint8_t *B, size_t b_row_bytes, long col0, int nc, int nb) {
-    const int groups = nc * nb * 32; // 8-byte groups
+    const int groups = nc * nb * 32; // 8-byte groups; a block's 32 groups sit in 32 consecutive lanes
     for (int gidx = threadIdx.x; gidx < groups; gidx += blockDim.x) {
         int c = gidx / (nb * 32), r = gidx % (nb * 32);
         int b = r >> 5, grp = r & 31;
         const uint8_t *y = B + (col0 + c) * b_row_bytes + (size_t)b * 292;
         const uint32_t *src = (const uint32_t *)(y + 36 + 8 * grp);
-        uint32_t y0 = src[0], y1 = src[1];
-        uint32_t p0 = __builtin_amdgcn_perm(y1, y0, 0x05010400);
-        uint32_t p1 = __builtin_amdgcn_perm(y1, y0, 0x07030602);
         uint8_t *dst = lds + (size_t)(c * nb + b) * XBLK;
-        *(uint2 *)(dst + 8 * grp) = make_uint2(p0, p1);
-        // half-sum of these 8 codes
-        int hs = sdot4(y0, 0x01010101u, 0);
-        hs = sdot4(y1, 0x01010101u, hs);
-        *(int16_t *)(dst + XBLK_HB + 2 * grp) = (int16_t)hs;
+        const int hs = put_group(dst, grp, src[0], src[1]);
+        const int other = __shfl_xor(hs, 2, 64); // group grp ^ 2: the other K-step of the pair
+        if ((grp & 2) == 0)
+            put_pair(dst, grp, hs + other);
         if (grp == 0)
             *(float *)(dst + XBLK_D) = *(const float *)y;
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Q4_K.  Work-group = 256 threads = 4 waves, 16 weight rows (half a packed tile); wave w takes
-// super-blocks b = w, w+4, ...  lane = (i16 = lane&15, h = (lane>>4)&1, gsel = lane>>5) covers
-// groups g = 2*gsel + gi (gi = 0,1) of its row.
-
-template <int NC>
-__global__ __launch_bounds__(256) void gemv_q4k_kernel(const uint8_t *__restrict__ A, long m, int nb,
-                                                       const uint8_t *__restrict__ B, size_t b_row_bytes, long col0,
-                                                       float *__restrict__ C, long ldc) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i16 = lane & 15, h = (lane >> 4) & 1, gsel = lane >> 5;
-    const long ht = blockIdx.x; // half tile
-    const long rt = ht >> 1;
-    const int hh = (int)(ht & 1);
-    const int slot = h * 32 + hh * 16 + i16; // lane slot inside a 64-lane group image
-    const uint8_t *tile0 = A + (size_t)rt * nb * P4K_TILE;
-
-    stage_q8k(lds, B, b_row_bytes, col0, NC, nb);
-    __syncthreads();
-
-    float accd[NC], accm[NC];
+// f32 rows, quantised here exactly like quantize_row_q8_K (upstream ggml-quants.c; restated in
+// quantize.hip): first index of the largest |x| fixes the sign of iscale = -128/max, codes are
+// nearest_int (round-half-even) clamped at 127, d = 1/iscale.  One "piece" = 16 consecutive floats;
+// 16 consecutive lanes share one 256-block.
+__device__ static inline void quantise_piece_q8k(uint8_t *dst, const float (&v)[16], int l16) {
+    float amax = 0.0f, val = 0.0f;
+    int idx = l16 * 16;
 #pragma unroll
-    for (int c = 0; c < NC; c++)
-        accd[c] = accm[c] = 0.0f;
+    for (int e = 0; e < 16; e++) {
+        float ax = fabsf(v[e]);
+        if (ax > amax) {
+            amax = ax;
+            val = v[e];
+            idx = l16 * 16 + e;
+        }
+    }
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) {
+        float oa = __shfl_xor(amax, off, 64);
+        int oi = __shfl_xor(idx, off, 64);
+        float ov = __shfl_xor(val, off, 64);
+        if (oa > amax || (oa == amax && oi < idx)) {
+            amax = oa;
+            idx = oi;
+            val = ov;
+        }
+    }
+    uint32_t y[4] = {0, 0, 0, 0};
+    float d = 0.0f;
+    if (amax != 0.0f) {
+        const float iscale = -128.0f / val;
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            int q = (int)rintf(iscale * v[e]);
+            q = q > 127 ? 127 : q;
+            y[e >> 2] |= (uint32_t)(q & 0xff) << (8 * (e & 3));
+        }
+        d = 1.0f / iscale;
+    }
+    // this lane's 16 codes = groups 2*l16 (h = 0) and 2*l16+1 (h = 1) of K-step dd = l16 & 3
+    const int hs0 = put_group(dst, 2 * l16 + 0, y[0], y[1]);
+    const int hs1 = put_group(dst, 2 * l16 + 1, y[2], y[3]);
+    const int o0 = __shfl_xor(hs0, 1, 64), o1 = __shfl_xor(hs1, 1, 64); // K-step dd ^ 1
+    if ((l16 & 1) == 0) {
+        put_pair(dst, 2 * l16 + 0, hs0 + o0);
+        put_pair(dst, 2 * l16 + 1, hs1 + o1);
+    }
+    if (l16 == 0)
+        *(float *)(dst + XBLK_D) = d;
+}
 
-#pragma unroll 2
-    for (int b = wave; b < nb; b += 4) {
-        const uint8_t *tile = tile0 + (size_t)b * P4K_TILE;
-        uint4 q0 = *(const uint4 *)(tile + (2 * gsel + 0) * 1024 + slot * 16);
-        uint4 q1 = *(const uint4 *)(tile + (2 * gsel + 1) * 1024 + slot * 16);
-        uint4 hd = *(const uint4 *)(tile + P4K_HDR + (hh * 16 + i16) * 16);
+__device__ static inline void load_piece(float (&v)[16], const float *x, int p) {
+    const float4 *src = (const float4 *)(x + (size_t)p * 16);
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        float4 f = src[e];
+        v[4 * e + 0] = f.x, v[4 * e + 1] = f.y, v[4 * e + 2] = f.z, v[4 * e + 3] = f.w;
+    }
+}
+
+__device__ static inline void stage_f32_as_q8k(uint8_t *lds, const uint8_t *X, size_t x_row_bytes, long col0, int nc,
+                                               int nb) {
+    const int pieces = nb * 16;
+    const int l16 = threadIdx.x & 15;
+    for (int c = 0; c < nc; c++) {
+        const float *x = (const float *)(X + (col0 + c) * x_row_bytes);
+        for (int p = threadIdx.x; p < pieces; p += blockDim.x) {
+            float v[16];
+            load_piece(v, x, p);
+            quantise_piece_q8k(lds + (size_t)(c * nb + (p >> 4)) * XBLK, v, l16);
+        }
+    }
+}
+
+template <int BT>
+__device__ static inline void stage_x(uint8_t *lds, const uint8_t *B, size_t b_row_bytes, long col0, int nc, int nb) {
+    if constexpr (BT == LFAMD_TYPE_F32)
+        stage_f32_as_q8k(lds, B, b_row_bytes, col0, nc, nb);
+    else
+        stage_q8k(lds, B, b_row_bytes, col0, nc, nb);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K-quant GEMV skeleton.  PERSISTENT work-groups: the grid is sized to about two work-groups per CU and
+// each work-group walks half-tiles (16 weight rows) ht = blockIdx.x, +gridDim.x, ...  The activation
+// vector is quantised / staged ONCE per work-group and reused for all its tiles, and the weight
+// stream is software-pipelined across tiles: the loads of work item f+1 are issued before item f is
+// consumed, so every wave keeps 12+ KiB of HBM reads in flight for its whole life.
+//   work item = (tile, chunk of GEMV_CH super-blocks of this wave); wave w owns super-blocks w, w+NW, ...
+//   NW = 16 waves for a single activation row: a k = 4096 row (16 super-blocks) then costs each wave ONE
+//   super-block per tile, so the integer-dot phase that follows the arrival of the data is as short as it
+//   can be; unused chunk slots are never touched, so the register allocator drops them.
+//   lane = (i16 = lane&15, h = (lane>>4)&1, gsel = lane>>5) covers groups g = 2*gsel + gi (gi = 0,1).
+
+#define GEMV_CH_MAX 4
+
+struct q4k_traits {
+    static constexpr int TILE = P4K_TILE;
+    struct chunk {
+        uint4 q0[GEMV_CH_MAX], q1[GEMV_CH_MAX], hd[GEMV_CH_MAX];
+    };
+    // `off` = byte offset of the super-block's tile inside the row-tile the descriptor covers
+    __device__ static inline void load(chunk &ch, int s, lfamd_rsrc r, uint32_t off, int gsel, int slot, int hrow) {
+        ch.q0[s] = buf_ld16_nt(r, off + (2 * gsel + 0) * 1024 + slot * 16);
+        ch.q1[s] = buf_ld16_nt(r, off + (2 * gsel + 1) * 1024 + slot * 16);
+        ch.hd[s] = buf_ld16_nt(r, off + P4K_HDR + hrow * 16);
+    }
+    // one super-block of this lane against one staged activation block; returns the f32 contribution
+    __device__ static inline float dot(const chunk &ch, int s, const uint8_t *xb, int gsel, int h) {
+        const uint4 q0 = ch.q0[s], q1 = ch.q1[s], hd = ch.hd[s];
         const float d = h2f((uint16_t)(hd.x & 0xffff)), dmin = h2f((uint16_t)(hd.x >> 16));
         uint32_t sc03, sc47, mn03, mn47;
         q4k_scales_bytes(hd.y, hd.z, hd.w, sc03, sc47, mn03, mn47);
         // this lane's four sub-blocks: j = 2g + e, g = 2*gsel + gi  ->  j = 4*gsel + 2*gi + e
         const uint32_t scw = gsel ? sc47 : sc03, mnw = gsel ? mn47 : mn03;
         const uint32_t qw[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+        const uint4 *yq = (const uint4 *)(xb + 128 * gsel + 64 * h);
+        const uint4 ya = yq[0], yb = yq[1], yc = yq[2], yd = yq[3];
+        const uint32_t yw[16] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w,
+                                 yc.x, yc.y, yc.z, yc.w, yd.x, yd.y, yd.z, yd.w};
+        const uint2 psw = *(const uint2 *)(xb + XBLK_PS + 16 * gsel + 8 * h);
+        const int ps[4] = {(int)(int16_t)(psw.x & 0xffff), (int)(int16_t)(psw.x >> 16), (int)(int16_t)(psw.y & 0xffff),
+                           (int)(int16_t)(psw.y >> 16)};
+        int sumi = 0, summ = 0;
 #pragma unroll
-        for (int c = 0; c < NC; c++) {
-            const uint8_t *xb = lds + (size_t)(c * nb + b) * XBLK;
-            int sumi = 0, summ = 0;
+        for (int jj = 0; jj < 4; jj++) { // jj = 2 gi + e
+            int isum = 0;
 #pragma unroll
-            for (int gi = 0; gi < 2; gi++) {
-                const int g = 2 * gsel + gi;
-#pragma unroll
-                for (int e = 0; e < 2; e++) {
-                    const int jj = 2 * gi + e; // byte index inside scw / mnw
-                    int isum = 0, hsum = 0;
-#pragma unroll
-                    for (int d2 = 0; d2 < 2; d2++) {
-                        const int dd = 2 * e + d2;
-                        const uint32_t x = qw[4 * gi + dd];
-                        const int koff = 64 * g + 16 * dd + 8 * h;
-                        const uint2 y = *(const uint2 *)(xb + koff);
-                        isum = sdot4(x & 0x0F0F0F0F, y.x, isum);
-                        isum = sdot4((x >> 4) & 0x0F0F0F0F, y.y, isum);
-                        hsum += *(const int16_t *)(xb + XBLK_HB + 2 * (koff >> 3));
-                    }
-                    sumi += (int)((scw >> (8 * jj)) & 0xff) * isum;
-                    summ += (int)((mnw >> (8 * jj)) & 0xff) * hsum;
-                }
+            for (int d2 = 0; d2 < 2; d2++) {
+                const int t8 = 2 * jj + d2; // = 4 gi + dd
+                const uint32_t x = qw[t8];
+                isum = sdot4(x & 0x0F0F0F0F, yw[2 * t8], isum);
+                isum = sdot4((x >> 4) & 0x0F0F0F0F, yw[2 * t8 + 1], isum);
             }
-            const float d8 = *(const float *)(xb + XBLK_D);
-            accd[c] = fmaf(d * d8, (float)sumi, accd[c]);
-            accm[c] = fmaf(dmin * d8, (float)summ, accm[c]);
+            sumi += (int)((scw >> (8 * jj)) & 0xff) * isum;
+            summ += (int)((mnw >> (8 * jj)) & 0xff) * ps[jj];
         }
+        const float d8 = *(const float *)(xb + XBLK_D);
+        // d*d8*sumi - dmin*d8*summ  (iqk_mul_mat.inc:284-291, 632)
+        return fmaf(d * d8, (float)sumi, -(dmin * d8) * (float)summ);
     }
+};
 
-    // reduce: 4 lanes per row (h, gsel), then 4 waves through LDS
-    __syncthreads(); // all waves done reading the activation image
-    float *red = (float *)lds;
+// Q6_K: sub-blocks are 16 wide (one per K-step), codes are 6 bit, offset -32 handled as
+// sum sc*(dot(code,q8) - 32*sum(q8)) like DequantizerQ6K (iqk_mul_mat.inc:570-599).
+struct q6k_traits {
+    static constexpr int TILE = P6K_TILE;
+    struct chunk {
+        uint4 l0[GEMV_CH_MAX], l1[GEMV_CH_MAX], hq[GEMV_CH_MAX];
+        uint2 sc[GEMV_CH_MAX];
+        uint32_t d[GEMV_CH_MAX];
+    };
+    __device__ static inline void load(chunk &ch, int s, lfamd_rsrc r, uint32_t off, int gsel, int slot, int hrow) {
+        ch.l0[s] = buf_ld16_nt(r, off + (2 * gsel + 0) * 1024 + slot * 16);
+        ch.l1[s] = buf_ld16_nt(r, off + (2 * gsel + 1) * 1024 + slot * 16);
+        ch.hq[s] = buf_ld16_nt(r, off + P6K_QH + gsel * 1024 + slot * 16);
+        ch.sc[s] = buf_ld8(r, off + P6K_SC + hrow * 16 + gsel * 8); // scales of K-steps 8*gsel..+7
+        ch.d[s] = buf_ld2(r, off + P6K_D + hrow * 2);
+    }
+    __device__ static inline float dot(const chunk &ch, int s, const uint8_t *xb, int gsel, int h) {
+        const uint4 l0 = ch.l0[s], l1 = ch.l1[s], hq = ch.hq[s];
+        const uint2 scb = ch.sc[s];
+        const float d = h2f((uint16_t)ch.d[s]);
+        const uint32_t lw[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+        const uint32_t hw[4] = {hq.x, hq.y, hq.z, hq.w}; // [gi*2 + e]
+        const uint4 *yq = (const uint4 *)(xb + 128 * gsel + 64 * h);
+        const uint4 ya = yq[0], yb = yq[1], yc = yq[2], yd = yq[3];
+        const uint32_t yw[16] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w,
+                                 yc.x, yc.y, yc.z, yc.w, yd.x, yd.y, yd.z, yd.w};
+        const uint4 hbw = *(const uint4 *)(xb + XBLK_HB + 32 * gsel + 16 * h);
+        const uint32_t hbv[4] = {hbw.x, hbw.y, hbw.z, hbw.w};
+        int sumi = 0;
 #pragma unroll
-    for (int c = 0; c < NC; c++) {
-        float v = accd[c] - accm[c];
-        v += __shfl_xor(v, 16, 64);
-        v += __shfl_xor(v, 32, 64);
-        if (lane < 16)
-            red[(wave * NC + c) * 16 + lane] = v;
+        for (int t8 = 0; t8 < 8; t8++) { // t8 = 4 gi + dd
+            const uint32_t x = lw[t8];
+            uint32_t H = hw[t8 >> 1];
+            if (t8 & 1)
+                H >>= 2;
+            // lo bytes (j0,j4,j1,j5): high fields at bits 4-5 of each byte already
+            const uint32_t clo = (x & 0x0F0F0F0F) | (H & 0x30303030);
+            // hi bytes (j2,j6,j3,j7): fields at bits 8-9 / 0-1 / 24-25 / 16-17
+            const uint32_t chi = ((x >> 4) & 0x0F0F0F0F) | ((H >> 4) & 0x00300030) | ((H << 12) & 0x30003000);
+            int isum = sdot4(clo, yw[2 * t8], 0);
+            isum = sdot4(chi, yw[2 * t8 + 1], isum);
+            const int hs = (int)(int16_t)((hbv[t8 >> 1] >> (16 * (t8 & 1))) & 0xffff);
+            const int sc = (int)(int8_t)(((t8 < 4 ? scb.x : scb.y) >> (8 * (t8 & 3))) & 0xff);
+            sumi += sc * (isum - 32 * hs);
+        }
+        const float d8 = *(const float *)(xb + XBLK_D);
+        return (d * d8) * (float)sumi;
     }
-    __syncthreads();
-    if (threadIdx.x < 16 * NC) {
-        int c = threadIdx.x >> 4, i = threadIdx.x & 15;
-        float v = red[(0 * NC + c) * 16 + i] + red[(1 * NC + c) * 16 + i] + red[(2 * NC + c) * 16 + i] +
-                  red[(3 * NC + c) * 16 + i];
-        long row = rt * 32 + hh * 16 + i;
-        if (row < m)
-            C[(col0 + c) * ldc + row] = v;
-    }
-}
+};
 
-// ---------------------------------------------------------------------------------------------
-// Q6_K.  Same decomposition; sub-blocks are 16 wide (one per K-step), codes are 6 bit, offset -32
-// handled as  sum sc*(dot(code,q8) - 32*sum(q8)).
-
-template <int NC>
-__global__ __launch_bounds__(256) void gemv_q6k_kernel(const uint8_t *__restrict__ A, long m, int nb,
-                                                       const uint8_t *__restrict__ B, size_t b_row_bytes, long col0,
-                                                       float *__restrict__ C, long ldc) {
+template <typename TR, int NC, int BT, int NW, int GEMV_CH>
+__global__ __launch_bounds__(NW * 64) void gemv_kq_kernel(const uint8_t *__restrict__ A, long m, int nb,
+                                                          const uint8_t *__restrict__ B, size_t b_row_bytes, long col0,
+                                                          float *__restrict__ C, long ldc, int n_ht) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i16 = lane & 15, h = (lane >> 4) & 1, gsel = lane >> 5;
-    const long ht = blockIdx.x;
-    const long rt = ht >> 1;
-    const int hh = (int)(ht & 1);
-    const int slot = h * 32 + hh * 16 + i16;
-    const uint8_t *tile0 = A + (size_t)rt * nb * P6K_TILE;
+    float *red = (float *)(lds + (size_t)NC * nb * XBLK); // [2][NW][NC][16]
 
-    stage_q8k(lds, B, b_row_bytes, col0, NC, nb);
-    __syncthreads();
+    const int sb_per_wave = (nb + NW - 1) / NW;
+    const int cpt = (sb_per_wave + GEMV_CH - 1) / GEMV_CH; // chunks per tile
+    const int ntile = (n_ht - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int total = ntile * cpt;
+
+    // Loads are issued UNCONDITIONALLY through a bounds-checked buffer descriptor: a branch around a load
+    // makes hipcc fall back to s_waitcnt vmcnt(0) (the prefetch of the next item is lost), whereas a
+    // descriptor with zero records ("no item f") or an offset past the row-tile ("no super-block b")
+    // returns zeros without touching memory and keeps the counted waits exact.
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const uint32_t rt_bytes = (uint32_t)nb * TR::TILE;
+    auto issue = [&](typename TR::chunk &ch, int f) {
+        const int tile_i = f / cpt, chunk_i = f - tile_i * cpt;
+        const long ht = (long)blockIdx.x + (long)tile_i * gridDim.x;
+        const int hh = (int)(ht & 1);
+        const lfamd_rsrc r = make_rsrc(A + (size_t)(ht >> 1) * rt_bytes, f < total ? rt_bytes : 0u);
+        const int slot = h * 32 + hh * 16 + i16, hrow = hh * 16 + i16;
+#pragma unroll
+        for (int s = 0; s < GEMV_CH; s++) {
+            const int b = wave_u + NW * (chunk_i * GEMV_CH + s); // b >= nb lands past the descriptor: zeros
+            TR::load(ch, s, r, (uint32_t)b * TR::TILE, gsel, slot, hrow);
+        }
+    };
 
     float acc[NC];
 #pragma unroll
     for (int c = 0; c < NC; c++)
         acc[c] = 0.0f;
 
-#pragma unroll 2
-    for (int b = wave; b < nb; b += 4) {
-        const uint8_t *tile = tile0 + (size_t)b * P6K_TILE;
-        uint4 l0 = *(const uint4 *)(tile + (2 * gsel + 0) * 1024 + slot * 16);
-        uint4 l1 = *(const uint4 *)(tile + (2 * gsel + 1) * 1024 + slot * 16);
-        uint4 hq = *(const uint4 *)(tile + P6K_QH + gsel * 1024 + slot * 16);
-        uint2 scb = *(const uint2 *)(tile + P6K_SC + (hh * 16 + i16) * 16 + gsel * 8); // scales of K-steps 8*gsel..+7
-        const float d = h2f(*(const uint16_t *)(tile + P6K_D + (hh * 16 + i16) * 2));
-        const uint32_t lw[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
-        const uint32_t hw[4] = {hq.x, hq.y, hq.z, hq.w}; // [gi*2 + e]
+    auto consume = [&](const typename TR::chunk &ch, int f) {
+        const int tile_i = f / cpt, chunk_i = f - tile_i * cpt;
 #pragma unroll
-        for (int c = 0; c < NC; c++) {
-            const uint8_t *xb = lds + (size_t)(c * nb + b) * XBLK;
-            int sumi = 0;
+        for (int s = 0; s < GEMV_CH; s++) {
+            const int b = wave + NW * (chunk_i * GEMV_CH + s);
+            const int bc = b < nb ? b : nb - 1;
 #pragma unroll
-            for (int gi = 0; gi < 2; gi++) {
-                const int g = 2 * gsel + gi;
-#pragma unroll
-                for (int dd = 0; dd < 4; dd++) {
-                    const uint32_t x = lw[4 * gi + dd];
-                    uint32_t H = hw[2 * gi + (dd >> 1)];
-                    if (dd & 1)
-                        H >>= 2;
-                    // lo bytes (j0,j4,j1,j5): high fields at bits 4-5 of each byte already
-                    const uint32_t clo = (x & 0x0F0F0F0F) | (H & 0x30303030);
-                    // hi bytes (j2,j6,j3,j7): fields at bits 8-9 / 0-1 / 24-25 / 16-17
-                    const uint32_t chi = ((x >> 4) & 0x0F0F0F0F) | ((H >> 4) & 0x00300030) | ((H << 12) & 0x30003000);
-                    const int koff = 64 * g + 16 * dd + 8 * h;
-                    const uint2 y = *(const uint2 *)(xb + koff);
-                    int isum = sdot4(clo, y.x, 0);
-                    isum = sdot4(chi, y.y, isum);
-                    const int hs = *(const int16_t *)(xb + XBLK_HB + 2 * (koff >> 3));
-                    const int t8 = 4 * gi + dd; // K-step index inside this lane's 8
-                    const int sc = (int)(int8_t)(((t8 < 4 ? scb.x : scb.y) >> (8 * (t8 & 3))) & 0xff);
-                    sumi += sc * (isum - 32 * hs);
-                }
+            for (int c = 0; c < NC; c++) {
+                // a super-block beyond the row was loaded as zeros (d = 0): contributes exactly 0
+                acc[c] += TR::dot(ch, s, lds + (size_t)(c * nb + bc) * XBLK, gsel, h);
             }
-            const float d8 = *(const float *)(xb + XBLK_D);
-            acc[c] = fmaf(d * d8, (float)sumi, acc[c]);
         }
-    }
-
-    __syncthreads();
-    float *red = (float *)lds;
+        if (chunk_i == cpt - 1) { // tile finished: 4 lanes per row (h, gsel), then the waves through LDS
+            float *rb = red + (tile_i & 1) * (NW * NC * 16);
 #pragma unroll
-    for (int c = 0; c < NC; c++) {
-        float v = acc[c];
-        v += __shfl_xor(v, 16, 64);
-        v += __shfl_xor(v, 32, 64);
-        if (lane < 16)
-            red[(wave * NC + c) * 16 + lane] = v;
+            for (int c = 0; c < NC; c++) {
+                float v = acc[c];
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 32, 64);
+                if (lane < 16)
+                    rb[(wave * NC + c) * 16 + lane] = v;
+                acc[c] = 0.0f;
+            }
+            __syncthreads();
+            if (threadIdx.x < 16 * NC) {
+                const int c = threadIdx.x >> 4, i = threadIdx.x & 15;
+                float v = 0.0f;
+#pragma unroll
+                for (int w = 0; w < NW; w++)
+                    v += rb[(w * NC + c) * 16 + i];
+                const long ht = (long)blockIdx.x + (long)tile_i * gridDim.x;
+                const long row = (ht >> 1) * 32 + (ht & 1) * 16 + i;
+                if (row < m)
+                    C[(col0 + c) * ldc + row] = v;
+            }
+        }
+    };
+
+    typename TR::chunk bufA, bufB;
+    if (total <= 0)
+        return; // (whole work-group: total is uniform)
+    // vmcnt retires in order: whatever is loaded first is waited for first.  In the decode case (one f32
+    // row, at most one piece per thread) fetch the activations BEFORE the first weight chunk, so the
+    // quantisation below only waits for them and the weights keep flying.
+    if (BT == LFAMD_TYPE_F32 && NC == 1 && nb * 16 <= NW * 64) {
+        float v[16];
+        const bool mine = (int)threadIdx.x < nb * 16;
+        if (mine)
+            load_piece(v, (const float *)(B + col0 * b_row_bytes), threadIdx.x);
+        issue(bufA, 0);
+        if (mine)
+            quantise_piece_q8k(lds + (size_t)(threadIdx.x >> 4) * XBLK, v, threadIdx.x & 15);
+    } else {
+        issue(bufA, 0); // in flight during the staging below
+        stage_x<BT>(lds, B, b_row_bytes, col0, NC, nb);
     }
     __syncthreads();
-    if (threadIdx.x < 16 * NC) {
-        int c = threadIdx.x >> 4, i = threadIdx.x & 15;
-        float v = red[(0 * NC + c) * 16 + i] + red[(1 * NC + c) * 16 + i] + red[(2 * NC + c) * 16 + i] +
-                  red[(3 * NC + c) * 16 + i];
-        long row = rt * 32 + hh * 16 + i;
-        if (row < m)
-            C[(col0 + c) * ldc + row] = v;
+
+    for (int f = 0; f < total; f += 2) {
+        issue(bufB, f + 1);
+        consume(bufA, f);
+        issue(bufA, f + 2);
+        if (f + 1 < total)
+            consume(bufB, f + 1);
     }
 }
 
@@ -231,8 +378,9 @@ __global__ __launch_bounds__(256) void gemv_q6k_kernel(const uint8_t *__restrict
 // contraction of sub(mul(a,b),e) into fma(a,b,-e).
 
 #define X80_BLK 36 // LDS: 8 dwords of q8 + f32 d
+#define Q80_DEPTH 32 // quads (1 KiB per wave each) kept in flight: a whole k = 4096 row set
 
-template <int NC>
+template <int NC, int BT>
 __global__ __launch_bounds__(64) void gemv_q80_kernel(const uint8_t *__restrict__ A, long m, long n_total, int nblocks,
                                                       int nquads, const uint8_t *__restrict__ B, size_t b_row_bytes,
                                                       long col0, float *__restrict__ C, long ldc, int vregs32,
@@ -242,20 +390,64 @@ __global__ __launch_bounds__(64) void gemv_q80_kernel(const uint8_t *__restrict_
     const int r = lane >> 3, j = lane & 7;
     const long rg = blockIdx.x;
     const long row = rg * 8 + r;
+    const uint8_t *tile0 = A + (size_t)rg * nquads * P80_TILE;
 
-    // stage activations: [c][l] -> 8 dwords + f32 scale
-    for (int idx = lane; idx < NC * nblocks * 9; idx += 64) {
-        int c = idx / (nblocks * 9), rem = idx % (nblocks * 9);
-        int l = rem / 9, w = rem % 9;
-        const uint8_t *y = B + (col0 + c) * b_row_bytes + (size_t)l * 34;
-        uint32_t v;
-        if (w < 8) {
-            const uint16_t *p = (const uint16_t *)(y + 2 + 4 * w); // 34-byte blocks: 2-byte aligned
-            v = (uint32_t)p[0] | ((uint32_t)p[1] << 16);
-        } else {
-            v = __builtin_bit_cast(uint32_t, h2f(*(const uint16_t *)y));
+    uint4 qa[Q80_DEPTH];
+    uint2 ds[Q80_DEPTH];
+#pragma unroll
+    for (int s = 0; s < Q80_DEPTH; s++)
+        if (s < nquads) {
+            qa[s] = ld_nt16((tile0 + (size_t)s * P80_TILE + lane * 16));
+            ds[s] = *(const uint2 *)(tile0 + (size_t)s * P80_TILE + P80_D + r * 8);
         }
-        *(uint32_t *)(lds + (size_t)(c * nblocks + l) * X80_BLK + 4 * w) = v;
+
+    if constexpr (BT == LFAMD_TYPE_F32) {
+        // quantize_row_q8_0 (upstream): d = amax/127, id = 1/d, q = roundf(x*id); 16 floats per lane,
+        // two lanes per 32-block
+        const int pieces = nblocks * 2;
+        for (int c = 0; c < NC; c++) {
+            const float *x = (const float *)(B + (col0 + c) * b_row_bytes);
+            for (int p = lane; p < pieces; p += 64) {
+                const float4 *src = (const float4 *)(x + (size_t)p * 16);
+                float v[16];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    float4 f = src[e];
+                    v[4 * e + 0] = f.x, v[4 * e + 1] = f.y, v[4 * e + 2] = f.z, v[4 * e + 3] = f.w;
+                }
+                float amax = 0.0f;
+#pragma unroll
+                for (int e = 0; e < 16; e++)
+                    amax = fmaxf(amax, fabsf(v[e]));
+                amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+                const float d = amax / 127.0f;
+                const float id = d != 0.0f ? 1.0f / d : 0.0f;
+                uint32_t y[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    int q = (int)roundf(v[e] * id);
+                    y[e >> 2] |= (uint32_t)(q & 0xff) << (8 * (e & 3));
+                }
+                uint8_t *dst = lds + (size_t)(c * nblocks + (p >> 1)) * X80_BLK;
+                *(uint4 *)(dst + 16 * (p & 1)) = make_uint4(y[0], y[1], y[2], y[3]);
+                if ((p & 1) == 0)
+                    *(float *)(dst + 32) = h2f(f2h_bits(d)); // the block stores d as f16
+            }
+        }
+    } else {
+        for (int idx = lane; idx < NC * nblocks * 9; idx += 64) {
+            int c = idx / (nblocks * 9), rem = idx % (nblocks * 9);
+            int l = rem / 9, w = rem % 9;
+            const uint8_t *y = B + (col0 + c) * b_row_bytes + (size_t)l * 34;
+            uint32_t v;
+            if (w < 8) {
+                const uint16_t *p = (const uint16_t *)(y + 2 + 4 * w); // 34-byte blocks: 2-byte aligned
+                v = (uint32_t)p[0] | ((uint32_t)p[1] << 16);
+            } else {
+                v = __builtin_bit_cast(uint32_t, h2f(*(const uint16_t *)y));
+            }
+            *(uint32_t *)(lds + (size_t)(c * nblocks + l) * X80_BLK + 4 * w) = v;
+        }
     }
     __syncthreads();
 
@@ -269,31 +461,39 @@ __global__ __launch_bounds__(64) void gemv_q80_kernel(const uint8_t *__restrict_
     for (int c = 0; c < NC; c++)
         Cv[c] = Ce[c] = 0.0f;
 
-    const uint8_t *tile0 = A + (size_t)rg * nquads * P80_TILE;
-#pragma unroll 4
-    for (int L = 0; L < nquads; L++) {
-        const uint8_t *tile = tile0 + (size_t)L * P80_TILE;
-        const uint4 qa = *(const uint4 *)(tile + lane * 16);
-        const uint2 ds = *(const uint2 *)(tile + P80_D + r * 8);
-        const uint32_t qw[4] = {qa.x, qa.y, qa.z, qa.w};
-        const float da[4] = {h2f((uint16_t)(ds.x & 0xffff)), h2f((uint16_t)(ds.x >> 16)), h2f((uint16_t)(ds.y & 0xffff)),
-                             h2f((uint16_t)(ds.y >> 16))};
+    for (int L0 = 0; L0 < nquads; L0 += Q80_DEPTH) {
 #pragma unroll
-        for (int dd = 0; dd < 4; dd++) {
-            const int l = 4 * L + dd;
-            if (l < nblocks) {
+        for (int s = 0; s < Q80_DEPTH; s++) {
+            const int L = L0 + s;
+            if (L < nquads) {
+                const uint4 q4 = qa[s];
+                const uint2 d2 = ds[s];
+                // refill this slot with the quad DEPTH ahead
+                if (L + Q80_DEPTH < nquads) {
+                    qa[s] = ld_nt16(tile0 + (size_t)(L + Q80_DEPTH) * P80_TILE + lane * 16);
+                    ds[s] = *(const uint2 *)(tile0 + (size_t)(L + Q80_DEPTH) * P80_TILE + P80_D + r * 8);
+                }
+                const uint32_t qw[4] = {q4.x, q4.y, q4.z, q4.w};
+                const float da[4] = {h2f((uint16_t)(d2.x & 0xffff)), h2f((uint16_t)(d2.x >> 16)),
+                                     h2f((uint16_t)(d2.y & 0xffff)), h2f((uint16_t)(d2.y >> 16))};
 #pragma unroll
-                for (int c = 0; c < NC; c++) {
-                    const uint8_t *xb = lds + (size_t)(c * nblocks + l) * X80_BLK;
-                    const float a = da[dd] * *(const float *)(xb + 32);
-                    const float bq = (float)sdot4(qw[dd], *(const uint32_t *)(xb + 4 * j), 0);
-                    if (kahan[c]) {
-                        const float y = __builtin_fmaf(a, bq, -Ce[c]);
-                        const float t = Cv[c] + y;
-                        Ce[c] = (t - Cv[c]) - y;
-                        Cv[c] = t;
-                    } else {
-                        Cv[c] = __builtin_fmaf(a, bq, Cv[c]);
+                for (int dd = 0; dd < 4; dd++) {
+                    const int l = 4 * L + dd;
+                    if (l < nblocks) {
+#pragma unroll
+                        for (int c = 0; c < NC; c++) {
+                            const uint8_t *xb = lds + (size_t)(c * nblocks + l) * X80_BLK;
+                            const float a = da[dd] * *(const float *)(xb + 32);
+                            const float bq = (float)sdot4(qw[dd], *(const uint32_t *)(xb + 4 * j), 0);
+                            if (kahan[c]) {
+                                const float y = __builtin_fmaf(a, bq, -Ce[c]);
+                                const float t = Cv[c] + y;
+                                Ce[c] = (t - Cv[c]) - y;
+                                Cv[c] = t;
+                            } else {
+                                Cv[c] = __builtin_fmaf(a, bq, Cv[c]);
+                            }
+                        }
                     }
                 }
             }
@@ -313,56 +513,81 @@ __global__ __launch_bounds__(64) void gemv_q80_kernel(const uint8_t *__restrict_
 
 // ---------------------------------------------------------------------------------------------
 
-template <int NC>
+static int g_num_cus = 0;
+
+static int num_cus() {
+    if (!g_num_cus) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess)
+            g_num_cus = p.multiProcessorCount;
+        if (g_num_cus <= 0)
+            g_num_cus = 256;
+    }
+    return g_num_cus;
+}
+
+template <typename TR, int NC, int BT, int NW, int CH>
+static hipError_t launch_kq(const void *A, long m, long k, const void *B, size_t brb, long col0, float *C, long ldc,
+                            hipStream_t s) {
+    int nb = (int)(k / 256);
+    size_t smem = (size_t)NC * nb * XBLK + 2 * NW * NC * 16 * sizeof(float);
+    auto kernel = gemv_kq_kernel<TR, NC, BT, NW, CH>;
+    if (smem > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess)
+            return e;
+    }
+    // persistent grid: 16 waves per CU, every work-group the same number of half-tiles
+    const int n_ht = (int)(((m + 31) / 32) * 2);
+    const int max_wg = (16 / NW) * num_cus();
+    const int per_wg = (n_ht + max_wg - 1) / max_wg;
+    const int grid = (n_ht + per_wg - 1) / per_wg;
+    kernel<<<grid, NW * 64, smem, s>>>((const uint8_t *)A, m, nb, (const uint8_t *)B, brb, col0, C, ldc, n_ht);
+    return hipGetLastError();
+}
+
+template <typename TR, int NC, int BT>
+static hipError_t launch_kq_pick(const void *A, long m, long k, const void *B, size_t brb, long col0, float *C, long ldc,
+                                 hipStream_t s) {
+    const long nb = k / 256;
+    if constexpr (NC == 1) {
+        if (nb <= 16)
+            return launch_kq<TR, NC, BT, 16, 1>(A, m, k, B, brb, col0, C, ldc, s);
+        return launch_kq<TR, NC, BT, 16, 2>(A, m, k, B, brb, col0, C, ldc, s);
+    } else {
+        if (nb <= 16)
+            return launch_kq<TR, NC, BT, 8, 2>(A, m, k, B, brb, col0, C, ldc, s);
+        return launch_kq<TR, NC, BT, 8, 4>(A, m, k, B, brb, col0, C, ldc, s);
+    }
+}
+
+template <int NC, int BT>
 static hipError_t launch_q4k(const void *A, long m, long k, const void *B, size_t brb, long col0, float *C, long ldc,
                              hipStream_t s) {
-    int nb = (int)(k / 256);
-    size_t smem = (size_t)NC * nb * XBLK;
-    if (smem < 4 * NC * 16 * sizeof(float))
-        smem = 4 * NC * 16 * sizeof(float);
-    if (smem > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)gemv_q4k_kernel<NC>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)smem);
-        if (e != hipSuccess)
-            return e;
-    }
-    unsigned grid = (unsigned)(((m + 31) / 32) * 2);
-    gemv_q4k_kernel<NC><<<grid, 256, smem, s>>>((const uint8_t *)A, m, nb, (const uint8_t *)B, brb, col0, C, ldc);
-    return hipGetLastError();
+    return launch_kq_pick<q4k_traits, NC, BT>(A, m, k, B, brb, col0, C, ldc, s);
 }
 
-template <int NC>
+template <int NC, int BT>
 static hipError_t launch_q6k(const void *A, long m, long k, const void *B, size_t brb, long col0, float *C, long ldc,
                              hipStream_t s) {
-    int nb = (int)(k / 256);
-    size_t smem = (size_t)NC * nb * XBLK;
-    if (smem < 4 * NC * 16 * sizeof(float))
-        smem = 4 * NC * 16 * sizeof(float);
-    if (smem > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)gemv_q6k_kernel<NC>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)smem);
-        if (e != hipSuccess)
-            return e;
-    }
-    unsigned grid = (unsigned)(((m + 31) / 32) * 2);
-    gemv_q6k_kernel<NC><<<grid, 256, smem, s>>>((const uint8_t *)A, m, nb, (const uint8_t *)B, brb, col0, C, ldc);
-    return hipGetLastError();
+    return launch_kq_pick<q6k_traits, NC, BT>(A, m, k, B, brb, col0, C, ldc, s);
 }
 
-template <int NC>
+template <int NC, int BT>
 static hipError_t launch_q80(const void *A, long m, long n_total, long k, const void *B, size_t brb, long col0, float *C,
                              long ldc, int vregs32, int precise, hipStream_t s) {
     int nblocks = (int)(k / 32), nquads = (nblocks + 3) / 4;
     size_t smem = (size_t)NC * nblocks * X80_BLK;
     if (smem > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)gemv_q80_kernel<NC>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)smem);
+        hipError_t e = hipFuncSetAttribute((const void *)gemv_q80_kernel<NC, BT>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess)
             return e;
     }
     unsigned grid = (unsigned)((m + 7) / 8);
-    gemv_q80_kernel<NC><<<grid, 64, smem, s>>>((const uint8_t *)A, m, n_total, nblocks, nquads, (const uint8_t *)B, brb,
-                                                col0, C, ldc, vregs32, precise);
+    gemv_q80_kernel<NC, BT><<<grid, 64, smem, s>>>((const uint8_t *)A, m, n_total, nblocks, nquads, (const uint8_t *)B,
+                                                    brb, col0, C, ldc, vregs32, precise);
     return hipGetLastError();
 }
 
@@ -373,36 +598,38 @@ static int max_cols_for(size_t per_col_bytes) {
     return nc < 1 ? 0 : (nc > 8 ? 8 : nc);
 }
 
-#define DISPATCH_NC(FN, nc, ...)                                                                                       \
+#define DISPATCH_NC(FN, BT, nc, ...)                                                                                   \
     switch (nc) {                                                                                                      \
     case 1:                                                                                                            \
-        e = FN<1>(__VA_ARGS__);                                                                                        \
+        e = FN<1, BT>(__VA_ARGS__);                                                                                    \
         break;                                                                                                         \
     case 2:                                                                                                            \
-        e = FN<2>(__VA_ARGS__);                                                                                        \
+        e = FN<2, BT>(__VA_ARGS__);                                                                                    \
         break;                                                                                                         \
     case 3:                                                                                                            \
-        e = FN<3>(__VA_ARGS__);                                                                                        \
+        e = FN<3, BT>(__VA_ARGS__);                                                                                    \
         break;                                                                                                         \
     case 4:                                                                                                            \
-        e = FN<4>(__VA_ARGS__);                                                                                        \
+        e = FN<4, BT>(__VA_ARGS__);                                                                                    \
         break;                                                                                                         \
     case 5:                                                                                                            \
-        e = FN<5>(__VA_ARGS__);                                                                                        \
+        e = FN<5, BT>(__VA_ARGS__);                                                                                    \
         break;                                                                                                         \
     case 6:                                                                                                            \
-        e = FN<6>(__VA_ARGS__);                                                                                        \
+        e = FN<6, BT>(__VA_ARGS__);                                                                                    \
         break;                                                                                                         \
     case 7:                                                                                                            \
-        e = FN<7>(__VA_ARGS__);                                                                                        \
+        e = FN<7, BT>(__VA_ARGS__);                                                                                    \
         break;                                                                                                         \
     default:                                                                                                           \
-        e = FN<8>(__VA_ARGS__);                                                                                        \
+        e = FN<8, BT>(__VA_ARGS__);                                                                                    \
         break;                                                                                                         \
     }
 
-extern "C" hipError_t lfamd_launch_gemv(int Atype, const void *A, long m, long k, const void *B, size_t b_row_bytes, long n,
-                                        float *C, long ldc, int vregs32, int precise, hipStream_t s) {
+// Btype: the weight type's vec_dot type (pre-quantised rows) or LFAMD_TYPE_F32 (quantise in-kernel)
+extern "C" hipError_t lfamd_launch_gemv(int Atype, const void *A, long m, long k, int Btype, const void *B,
+                                        size_t b_row_bytes, long n, float *C, long ldc, int vregs32, int precise,
+                                        hipStream_t s) {
     if (m <= 0 || n <= 0)
         return hipSuccess;
     size_t per_col;
@@ -413,15 +640,28 @@ extern "C" hipError_t lfamd_launch_gemv(int Atype, const void *A, long m, long k
     int step = max_cols_for(per_col);
     if (step == 0)
         return hipErrorInvalidValue;
+    const bool f32in = Btype == LFAMD_TYPE_F32;
     hipError_t e = hipSuccess;
     for (long col0 = 0; col0 < n && e == hipSuccess; col0 += step) {
         int nc = (int)((n - col0) < step ? (n - col0) : step);
         if (Atype == LFAMD_TYPE_Q4_K) {
-            DISPATCH_NC(launch_q4k, nc, A, m, k, B, b_row_bytes, col0, C, ldc, s)
+            if (f32in) {
+                DISPATCH_NC(launch_q4k, LFAMD_TYPE_F32, nc, A, m, k, B, b_row_bytes, col0, C, ldc, s)
+            } else {
+                DISPATCH_NC(launch_q4k, LFAMD_TYPE_Q8_K, nc, A, m, k, B, b_row_bytes, col0, C, ldc, s)
+            }
         } else if (Atype == LFAMD_TYPE_Q6_K) {
-            DISPATCH_NC(launch_q6k, nc, A, m, k, B, b_row_bytes, col0, C, ldc, s)
+            if (f32in) {
+                DISPATCH_NC(launch_q6k, LFAMD_TYPE_F32, nc, A, m, k, B, b_row_bytes, col0, C, ldc, s)
+            } else {
+                DISPATCH_NC(launch_q6k, LFAMD_TYPE_Q8_K, nc, A, m, k, B, b_row_bytes, col0, C, ldc, s)
+            }
         } else if (Atype == LFAMD_TYPE_Q8_0) {
-            DISPATCH_NC(launch_q80, nc, A, m, n, k, B, b_row_bytes, col0, C, ldc, vregs32, precise, s)
+            if (f32in) {
+                DISPATCH_NC(launch_q80, LFAMD_TYPE_F32, nc, A, m, n, k, B, b_row_bytes, col0, C, ldc, vregs32, precise, s)
+            } else {
+                DISPATCH_NC(launch_q80, LFAMD_TYPE_Q8_0, nc, A, m, n, k, B, b_row_bytes, col0, C, ldc, vregs32, precise, s)
+            }
         } else {
             return hipErrorInvalidValue;
         }

@@ -50,6 +50,38 @@ typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 typedef float float16_t_ __attribute__((ext_vector_type(16)));
 typedef float float4_t_ __attribute__((ext_vector_type(4)));
 
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+
+// streamed-once weights: non-temporal 16-byte load (MI355X_MICROARCH.md "nt-weights": -18% issue->landed)
+__device__ static inline uint4 ld_nt16(const void *p) {
+    u32x4_t v = __builtin_nontemporal_load((const u32x4_t *)p);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+// Bounds-checked buffer loads (T8): out-of-range lanes return 0 and make NO memory request, but the
+// instruction still counts in vmcnt — so a software pipeline can issue its prefetch unconditionally
+// (a descriptor with 0 records for "nothing left to fetch") and keep exact counted waits.
+typedef __amdgpu_buffer_rsrc_t lfamd_rsrc;
+
+__device__ static inline lfamd_rsrc make_rsrc(const void *p, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, bytes, 0x00020000);
+}
+
+__device__ static inline uint4 buf_ld16_nt(lfamd_rsrc r, uint32_t off) {
+    u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 2 /* nt */);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+__device__ static inline uint2 buf_ld8(lfamd_rsrc r, uint32_t off) {
+    typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+    u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
+    return make_uint2(v.x, v.y);
+}
+
+__device__ static inline uint32_t buf_ld2(lfamd_rsrc r, uint32_t off) {
+    return (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(r, off, 0, 0);
+}
+
 __device__ static inline float h2f(uint16_t h) {
     return (float)__builtin_bit_cast(_Float16, h);
 }

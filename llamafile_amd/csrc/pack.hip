@@ -221,6 +221,79 @@ __global__ void prep_q8k_kernel(const uint8_t *__restrict__ B, size_t b_row_byte
     }
 }
 
+// Same outputs straight from f32 activations: quantise exactly like quantize_row_q8_K (first index of
+// the largest |x|, iscale = -128/max, nearest-even, clamp 127, d = 1/iscale) without materialising
+// the Q8_K blocks.  One wave per (token, super-block), 4 values per lane.
+__global__ __launch_bounds__(64) void prep_f32_kernel(const uint8_t *__restrict__ X, size_t x_row_bytes, long n, long n_pad,
+                                                      int nb, _Float16 *__restrict__ Xh, float *__restrict__ d8T,
+                                                      _Float16 *__restrict__ Xm) {
+    long blk = blockIdx.x;
+    long tok = blk / nb;
+    int b = (int)(blk % nb);
+    int t = threadIdx.x;
+    _Float16 *xo = Xh + (size_t)tok * nb * 256 + (size_t)b * 256;
+    typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+    if (tok >= n) {
+        half4_t z = {(_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0};
+        *(half4_t *)(xo + 4 * t) = z;
+        if (t == 0)
+            d8T[(size_t)b * n_pad + tok] = 0.0f;
+        if (t < 16)
+            Xm[((size_t)tok * nb + b) * 16 + t] = (_Float16)0;
+        return;
+    }
+    const float4 f = *(const float4 *)((const float *)(X + tok * x_row_bytes) + (size_t)b * 256 + 4 * t);
+    const float v[4] = {f.x, f.y, f.z, f.w};
+    float amax = 0.0f, val = 0.0f;
+    int idx = 4 * t;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        float ax = fabsf(v[e]);
+        if (ax > amax) {
+            amax = ax;
+            val = v[e];
+            idx = 4 * t + e;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        float oa = __shfl_xor(amax, off, 64);
+        int oi = __shfl_xor(idx, off, 64);
+        float ov = __shfl_xor(val, off, 64);
+        if (oa > amax || (oa == amax && oi < idx)) {
+            amax = oa;
+            idx = oi;
+            val = ov;
+        }
+    }
+    int q[4] = {0, 0, 0, 0};
+    float d = 0.0f;
+    if (amax != 0.0f) {
+        const float iscale = -128.0f / val;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            int c = (int)rintf(iscale * v[e]);
+            q[e] = c > 127 ? 127 : c;
+        }
+        d = 1.0f / iscale;
+    }
+    half4_t h4 = {(_Float16)q[0], (_Float16)q[1], (_Float16)q[2], (_Float16)q[3]};
+    *(half4_t *)(xo + 4 * t) = h4;
+    int S = q[0] + q[1] + q[2] + q[3]; // pair sum j = t/8 covers codes 32j..32j+31 = lanes 8j..8j+7
+    S += __shfl_xor(S, 1, 64);
+    S += __shfl_xor(S, 2, 64);
+    S += __shfl_xor(S, 4, 64);
+    if ((t & 7) == 0) {
+        int j = t >> 3;
+        int lo = S & 63, hi = (S - lo) / 64;
+        _Float16 *mo = Xm + ((size_t)tok * nb + b) * 16;
+        mo[j] = (_Float16)lo;
+        mo[8 + j] = (_Float16)hi;
+    }
+    if (t == 0)
+        d8T[(size_t)b * n_pad + tok] = d;
+}
+
 // ---------------------------------------------------------------------------------------------
 // host-callable launchers (used by api.hip)
 
@@ -263,6 +336,17 @@ hipError_t lfamd_launch_pack_raw(const void *raw, size_t raw_row_bytes, long row
     if (blocks == 0)
         return hipSuccess;
     pack_raw_kernel<<<(unsigned)blocks, 256, 0, s>>>((const uint8_t *)raw, raw_row_bytes, rows, row_bytes, (uint8_t *)out);
+    return hipGetLastError();
+}
+
+hipError_t lfamd_launch_prep_f32(const void *X, size_t x_row_bytes, long n, long n_pad, long cols, void *Xh, void *d8T,
+                                 void *Xm, hipStream_t s) {
+    int nb = (int)(cols / 256);
+    long blocks = n_pad * nb;
+    if (blocks == 0)
+        return hipSuccess;
+    prep_f32_kernel<<<(unsigned)blocks, 64, 0, s>>>((const uint8_t *)X, x_row_bytes, n, n_pad, nb, (_Float16 *)Xh,
+                                                     (float *)d8T, (_Float16 *)Xm);
     return hipGetLastError();
 }
 

@@ -84,3 +84,37 @@ def test_generic_large_n(gpu, oracle, t):
     assert ok == 1
     C = run_gpu(gpu, t, A, B, bt, m, n, k)
     assert rel_err(C, G) <= DEFAULT_TOL
+
+
+@pytest.mark.parametrize("vdt", [T.Q8_0, T.Q8_1, T.Q8_K], ids=lambda t: T.NAMES[t])
+def test_device_quantiser_bit_exact(gpu, oracle, vdt):
+    """lfamd_quantize_rows == the scalar reference quantisers (restated in the oracle), byte for byte,
+    including an all-zero block and a tie between +max and -max (first occurrence wins in q8_K)."""
+    from llamafile_amd import synth
+    x = synth.random_activations(7, 1024, 17)
+    x[2, 256:512] = 0.0
+    x[3, 5] = 0.75
+    x[3, 9] = -0.75
+    x[3, :256] = np.clip(x[3, :256], -0.75, 0.75)
+    got = gpu.quantize_rows(vdt, torch.from_numpy(x).cuda()).cpu().numpy()
+    want = oracle.quantize(vdt, x)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("t", [T.Q4_K, T.Q6_K, T.Q8_0, T.Q4_0, T.Q5_1, T.Q3_K], ids=lambda t: T.NAMES[t])
+@pytest.mark.parametrize("n", [1, 3, 8, 70])
+def test_f32_activations_equal_prequantised(gpu, t, n):
+    """GGML_OP_MUL_MAT boundary (f32 src1): quantisation fused into the kernels must give bit-identical
+    results to quantising first (the llamafile_sgemm boundary)."""
+    from llamafile_amd import synth
+    m, k = 96, 1536
+    A = synth.random_weights(t, m, k, 21)
+    x = synth.random_activations(n, k, 22)
+    x[0, :256] = 0.0
+    bt = T.VEC_DOT[t]
+    W = gpu.upload_weights(t, A, m, k)
+    xd = torch.from_numpy(x).cuda()
+    c_f32 = gpu.mul_mat(W, xd.view(torch.uint8), T.F32).cpu().numpy()
+    c_q = gpu.mul_mat(W, gpu.quantize_rows(bt, xd), bt).cpu().numpy()
+    assert not np.isnan(c_f32).any()
+    assert np.array_equal(c_f32.view(np.uint32), c_q.view(np.uint32))
