@@ -96,9 +96,6 @@ class Runner:
                         b["x"][key] = torch.rand((n, o.k), device=dev, generator=g) * 2 - 1
                         vdt = T.VEC_DOT[o.spec.type]
                         b["xq"][key] = torch.empty((n, T.row_size(vdt, o.k)), dtype=torch.uint8, device=dev)
-                    mk = o.m if o.spec.shard != "vocab" else -o.m
-                    if mk not in b["out"]:
-                        b["out"][mk] = torch.empty((n, o.m), dtype=torch.float32, device=dev)
                     ws = max(ws, sgemm.workspace_bytes(o.spec.type, o.m, o.k, n))
             b["ws"] = torch.empty(ws, dtype=torch.uint8, device=dev)
             if world > 1:
@@ -110,35 +107,68 @@ class Runner:
     def weight_bytes(self):
         return sum(o.W.nbytes for ops in self.layers for o in ops)
 
-    def run_pass(self, n, only_type=None, count=None):
-        """Launch every mat-mul (and the activation quantisation feeding it) at batch n on the current
-        stream.  `only_type`: restrict to GEMV/GEMM launches of one weight type, no quantise, no
-        collectives (roofline measurement)."""
+    def _groups(self, ops):
+        """Consecutive ops of one layer that read the same activations with the same weight type and k:
+        what a backend's graph_compute fuses into one launch (lfamd_mul_mat_multi)."""
+        groups = []
+        for o in ops:
+            g = groups[-1] if groups else None
+            if g and g[0].spec.input == o.spec.input and g[0].spec.type == o.spec.type and g[0].k == o.k and \
+                    g[0].spec.shard == o.spec.shard and len(g) < 4:
+                g.append(o)
+            else:
+                groups.append([o])
+        return groups
+
+    def prepare(self, n):
+        """Pre-build the ctypes argument arrays of every launch of a pass at batch n."""
+        b = self.buf[n]
+        calls = []
+        for ops in self.layers:
+            for g in self._groups(ops):
+                o0 = g[0]
+                x = b["x"][(o0.spec.input, o0.k)]
+                cnt = len(g)
+                outs = []
+                for j, o in enumerate(g):
+                    key = (o.m if o.spec.shard != "vocab" else -o.m, j)
+                    if key not in b["out"]:
+                        b["out"][key] = torch.empty((n, o.m), dtype=torch.float32, device=self.dev)
+                    outs.append(b["out"][key])
+                A_arr = (C.c_void_p * cnt)(*[o.W.data.data_ptr() for o in g])
+                C_arr = (C.c_void_p * cnt)(*[t.data_ptr() for t in outs])
+                m_arr = (C.c_long * cnt)(*[o.m for o in g])
+                calls.append((g, x, outs, A_arr, C_arr, m_arr))
+        b["calls"] = calls
+
+    def run_pass(self, n, only_type=None):
+        """Launch every GGML_OP_MUL_MAT of the model at batch n on the current stream: f32 activations in
+        (quantisation is fused into the kernels), sibling ops sharing an input fused per layer.
+        `only_type`: restrict to the launches of one weight type, no collectives (roofline measurement).
+        Returns (launches, ops)."""
         L, b = self.L, self.buf[n]
+        if "calls" not in b:
+            self.prepare(n)
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         ws, wsn = C.c_void_p(b["ws"].data_ptr()), b["ws"].numel()
-        launches = 0
-        for ops in self.layers:
-            for o in ops:
-                key = (o.spec.input, o.k)
-                if only_type is not None and o.spec.type != only_type:
-                    continue
-                # GGML_OP_MUL_MAT boundary: f32 activations in; the GEMV quantises them in its prologue and
-                # the GEMM path in its fused prep kernel (no separate quantise launch)
-                x = b["x"][key]
-                out = b["out"][o.m if o.spec.shard != "vocab" else -o.m]
-                rc = L.lfamd_mul_mat(o.spec.type, C.c_void_p(o.W.data.data_ptr()), o.m, o.k, T.F32,
-                                     C.c_void_p(x.data_ptr()), x.stride(0) * 4, n, C.c_void_p(out.data_ptr()), o.m, ws, wsn,
-                                     self.flags, stream)
-                if rc:
-                    _hip.check(rc, "mul_mat " + o.spec.name)
-                launches += 1
-                if only_type is None and self.world > 1:
+        launches = nops = 0
+        for g, x, outs, A_arr, C_arr, m_arr in b["calls"]:
+            o0 = g[0]
+            if only_type is not None and o0.spec.type != only_type:
+                continue
+            rc = L.lfamd_mul_mat_multi(o0.spec.type, len(g), A_arr, m_arr, o0.k, T.F32, C.c_void_p(x.data_ptr()),
+                                       x.stride(0) * 4, n, C_arr, m_arr, ws, wsn, self.flags, stream)
+            if rc:
+                _hip.check(rc, "mul_mat_multi " + o0.spec.name)
+            launches += 1 if n <= 8 else len(g)
+            nops += len(g)
+            if only_type is None and self.world > 1:
+                for o, out in zip(g, outs):
                     if o.spec.shard == "cols":
                         torch.distributed.all_reduce(out)
                     elif o.spec.shard == "vocab":
                         torch.distributed.all_gather_into_tensor(b["gather"], out)
-        return launches
+        return launches, nops
 
 
 def cpu_baseline(layers, prefill, decode):
@@ -252,7 +282,8 @@ def main():
         e0.record()
         n_launch = 0
         for _ in range(reps):
-            n_launch += fn() or 0
+            r = fn()
+            n_launch += r[0] if isinstance(r, tuple) else (r or 0)
         e1.record()
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) * 1e3, n_launch  # microseconds
@@ -266,16 +297,18 @@ def main():
     # launches of one decode pass, back to back on the stream, timed with HIP events
     dom_type = T.Q4_K if a.model == "llama3-8b-q4_k_m" else T.Q8_0
     dom_ops = [o for ops in runner.layers for o in ops if o.spec.type == dom_type]
-    runner.run_pass(1, only_type=dom_type)
+    launches_per_pass, _ = runner.run_pass(1, only_type=dom_type)
     us, n_launch = time_region(lambda: runner.run_pass(1, only_type=dom_type), 10)
     avg_us = us / n_launch
-    # algorithmic bytes per launch: weights once + f32 activations + f32 outputs
-    alg_bytes = sum(o.m * T.row_size(dom_type, o.k) + o.k * 4 + o.m * 4 for o in dom_ops)
-    avg_bytes = alg_bytes / len(dom_ops)
+    # algorithmic bytes per launch: weights once + f32 activations (once per launch: sibling
+    # ops fused into a launch share them) + f32 outputs
+    groups = [g for ops in runner.layers for g in runner._groups(ops) if g[0].spec.type == dom_type]
+    alg_bytes = sum(sum(o.m * T.row_size(dom_type, o.k) + o.m * 4 for o in g) + g[0].k * 4 for g in groups)
+    avg_bytes = alg_bytes / launches_per_pass
     achieved = avg_bytes / (avg_us * 1e-6) / 1e9
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                "kernel": f"gemv_{T.NAMES[dom_type].lower()}_kernel<1>", "launches_per_pass": len(dom_ops),
+                "kernel": f"gemv_{T.NAMES[dom_type].lower()}_kernel<1>", "launches_per_pass": launches_per_pass, "mat_muls_per_pass": len(dom_ops),
                 "avg_launch_us": round(avg_us, 3), "algorithmic_bytes_per_launch": int(avg_bytes)}
 
     # ---- secondary: the prefill GEMM at the north-star shape (4096 x 4096 x 512, 1 GPU shapes only)
@@ -310,7 +343,7 @@ def main():
         "dtype": "int8",
         "data": "synthetic",
         "config": {
-            "workload": f"Llama-3-8B Q4_K_M mat-muls (225 GGML_OP_MUL_MAT per pass, f32 activations in, quantisation fused), "
+            "workload": f"Llama-3-8B Q4_K_M mat-muls (225 GGML_OP_MUL_MAT per pass, f32 activations in, quantisation fused, sibling ops fused at decode), "
                         f"{a.prefill}-token prefill + {a.decode} decode, matmul-only",
             "numerics": "exact int8 x int4/int6 block dot products with f32 scales (decode: v_dot4_i32_i8; prefill: "
                         "f16 MFMA on the exact integer codes, f32 accumulate)",

@@ -80,7 +80,9 @@ int lfamd_quantize_rows(int vec_dot_type, const float *d_x, long nrows, long col
 /* ---- GGML_OP_MUL_MAT -----------------------------------------------------------------------
  * C[j*ldc + i] = sum_l A[i][l] * B[j][l]   (C = A^T B, column-major C like llamafile_sgemm)
  *   A: packed weights (lfamd_pack_weights), m rows x k elements, type Atype
- *   B: n rows in the reference's activation format Btype (= vec_dot_type of Atype), row stride
+ *   B: n rows, either in the reference's activation format Btype (= vec_dot_type of Atype; the
+ *      llamafile_sgemm boundary) or F32 (the GGML_OP_MUL_MAT boundary: quantised on the device,
+ *      bit-identically to quantize_row_q8_K / q8_0 / q8_1, fused into the kernels); row stride
  *      b_row_bytes
  *   C: f32, ldc >= m
  * Policy (cf. ggml_cuda_mul_mat): n <= 8 -> wave-reduction GEMV kernels, else dequant-to-MFMA
@@ -89,6 +91,15 @@ size_t lfamd_mul_mat_workspace(int Atype, long m, long k, long n);
 int lfamd_mul_mat(int Atype, const void *d_A_packed, long m, long k, int Btype, const void *d_B,
                   size_t b_row_bytes, long n, float *d_C, long ldc, void *d_workspace,
                   size_t workspace_bytes, unsigned flags, void *stream);
+
+/* Several GGML_OP_MUL_MAT nodes that read the SAME activations (attn_q/k/v; ffn_gate/up) with weights
+ * of one type and row length: what a backend's graph_compute may fuse (ggml_backend_cuda_graph_compute,
+ * ggml-cuda.cu.patch:18945, walks the node list and is free to).  For n <= 8 and Q4_K / Q6_K weights
+ * this is ONE kernel launch over the concatenated rows; otherwise it runs lfamd_mul_mat per matrix
+ * (workspace: the largest lfamd_mul_mat_workspace of the set).  Results are identical either way. */
+int lfamd_mul_mat_multi(int Atype, int count, const void *const *d_A_packed, const long *m, long k, int Btype,
+                        const void *d_B, size_t b_row_bytes, long n, float *const *d_C, const long *ldc,
+                        void *d_workspace, size_t workspace_bytes, unsigned flags, void *stream);
 
 /* ---- GGML_OP_MUL_MAT_ID (mixture of experts) -------------------------------------------------
  * For every (token, thinker): result[token][thinker][:] = W[plan[token][thinker]] x

@@ -19,6 +19,8 @@ hipError_t lfamd_launch_prep_f32(const void *, size_t, long, long, long, void *,
 hipError_t lfamd_launch_generic(int, const void *, long, long, int, const void *, size_t, long, float *, long, hipStream_t);
 hipError_t lfamd_launch_gemv(int, const void *, long, long, int, const void *, size_t, long, float *, long, int, int,
                              hipStream_t);
+hipError_t lfamd_launch_gemv_multi(int, int, const void *const *, const long *, long, int, const void *, size_t, long,
+                                   float *const *, const long *, int, int, hipStream_t);
 hipError_t lfamd_launch_gemm_kq(int, const void *, long, long, const void *, const void *, const void *, long, long,
                                 float *, long, hipStream_t);
 hipError_t lfamd_launch_quantize(int, const float *, long, long, size_t, void *, size_t, hipStream_t);
@@ -282,6 +284,34 @@ int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const v
         return LFAMD_OK;
     }
     HIPCHK(lfamd_launch_generic(Atype, d_A, m, k, Btype, d_B, b_row_bytes, n, d_C, ldc, s), "generic");
+    return LFAMD_OK;
+}
+
+int lfamd_mul_mat_multi(int Atype, int count, const void *const *d_A, const long *m, long k, int Btype, const void *d_B,
+                        size_t b_row_bytes, long n, float *const *d_C, const long *ldc, void *d_ws, size_t ws_bytes,
+                        unsigned flags, void *stream) {
+    if (count <= 0)
+        return LFAMD_OK;
+    // one fused launch when the GEMV path applies to every matrix; otherwise one mul_mat per matrix
+    bool fuse = count <= 4 && n <= 8 && (Atype == LFAMD_TYPE_Q4_K || Atype == LFAMD_TYPE_Q6_K) &&
+                !(flags & LFAMD_FLAG_FORCE_GENERIC) && (Btype == LFAMD_TYPE_F32 || Btype == lfamd_vec_dot_type(Atype)) &&
+                k > 0 && k % 256 == 0 && b_row_bytes >= lfamd_row_size(Btype, k);
+    for (int j = 0; j < count && fuse; j++)
+        fuse = m[j] >= 0 && ldc[j] >= m[j];
+    if (fuse) {
+        if (n == 0)
+            return LFAMD_OK;
+        HIPCHK(lfamd_launch_gemv_multi(Atype, count, d_A, m, k, Btype, d_B, b_row_bytes, n, d_C, ldc,
+                                       (flags & LFAMD_FLAG_Q0_VREGS32) ? 1 : 0, (flags & LFAMD_FLAG_PRECISE) ? 1 : 0,
+                                       (hipStream_t)stream),
+               "gemv_multi");
+        return LFAMD_OK;
+    }
+    for (int j = 0; j < count; j++) {
+        int r = lfamd_mul_mat(Atype, d_A[j], m[j], k, Btype, d_B, b_row_bytes, n, d_C[j], ldc[j], d_ws, ws_bytes, flags, stream);
+        if (r != LFAMD_OK)
+            return r;
+    }
     return LFAMD_OK;
 }
 

@@ -264,10 +264,21 @@ struct q6k_traits {
     }
 };
 
+// Up to GEMV_MAX_MATS weight matrices of one type and row length that consume the SAME activations
+// (attn_q/k/v, ffn_gate/up) are served by one launch: their half-tiles are concatenated.
+#define GEMV_MAX_MATS 4
+struct gemv_mats {
+    const uint8_t *A[GEMV_MAX_MATS];
+    float *C[GEMV_MAX_MATS];
+    long m[GEMV_MAX_MATS];
+    long ldc[GEMV_MAX_MATS];
+    int ht_end[GEMV_MAX_MATS]; // exclusive prefix of half-tile counts
+    int count;
+};
+
 template <typename TR, int NC, int BT, int NW, int GEMV_CH>
-__global__ __launch_bounds__(NW * 64) void gemv_kq_kernel(const uint8_t *__restrict__ A, long m, int nb,
-                                                          const uint8_t *__restrict__ B, size_t b_row_bytes, long col0,
-                                                          float *__restrict__ C, long ldc, int n_ht) {
+__global__ __launch_bounds__(NW * 64) void gemv_kq_kernel(const gemv_mats mats, int nb, const uint8_t *__restrict__ B,
+                                                          size_t b_row_bytes, long col0, int n_ht) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i16 = lane & 15, h = (lane >> 4) & 1, gsel = lane >> 5;
@@ -286,7 +297,15 @@ __global__ __launch_bounds__(NW * 64) void gemv_kq_kernel(const uint8_t *__restr
     const uint32_t rt_bytes = (uint32_t)nb * TR::TILE;
     auto issue = [&](typename TR::chunk &ch, int f) {
         const int tile_i = f / cpt, chunk_i = f - tile_i * cpt;
-        const long ht = (long)blockIdx.x + (long)tile_i * gridDim.x;
+        long ht = (long)blockIdx.x + (long)tile_i * gridDim.x;
+        int j = 0;
+#pragma unroll
+        for (int jj = 1; jj < GEMV_MAX_MATS; jj++)
+            if (jj < mats.count && ht >= mats.ht_end[jj - 1])
+                j = jj;
+        const uint8_t *A = mats.A[j];
+        if (j > 0)
+            ht -= mats.ht_end[j - 1];
         const int hh = (int)(ht & 1);
         const lfamd_rsrc r = make_rsrc(A + (size_t)(ht >> 1) * rt_bytes, f < total ? rt_bytes : 0u);
         const int slot = h * 32 + hh * 16 + i16, hrow = hh * 16 + i16;
@@ -332,10 +351,17 @@ __global__ __launch_bounds__(NW * 64) void gemv_kq_kernel(const uint8_t *__restr
 #pragma unroll
                 for (int w = 0; w < NW; w++)
                     v += rb[(w * NC + c) * 16 + i];
-                const long ht = (long)blockIdx.x + (long)tile_i * gridDim.x;
+                long ht = (long)blockIdx.x + (long)tile_i * gridDim.x;
+                int j = 0;
+#pragma unroll
+                for (int jj = 1; jj < GEMV_MAX_MATS; jj++)
+                    if (jj < mats.count && ht >= mats.ht_end[jj - 1])
+                        j = jj;
+                if (j > 0)
+                    ht -= mats.ht_end[j - 1];
                 const long row = (ht >> 1) * 32 + (ht & 1) * 16 + i;
-                if (row < m)
-                    C[(col0 + c) * ldc + row] = v;
+                if (row < mats.m[j])
+                    mats.C[j][(col0 + c) * mats.ldc[j] + row] = v;
             }
         }
     };
@@ -528,8 +554,7 @@ static int num_cus() {
 }
 
 template <typename TR, int NC, int BT, int NW, int CH>
-static hipError_t launch_kq(const void *A, long m, long k, const void *B, size_t brb, long col0, float *C, long ldc,
-                            hipStream_t s) {
+static hipError_t launch_kq(const gemv_mats &mats, int n_ht, long k, const void *B, size_t brb, long col0, hipStream_t s) {
     int nb = (int)(k / 256);
     size_t smem = (size_t)NC * nb * XBLK + 2 * NW * NC * 16 * sizeof(float);
     auto kernel = gemv_kq_kernel<TR, NC, BT, NW, CH>;
@@ -539,39 +564,36 @@ static hipError_t launch_kq(const void *A, long m, long k, const void *B, size_t
             return e;
     }
     // persistent grid: 16 waves per CU, every work-group the same number of half-tiles
-    const int n_ht = (int)(((m + 31) / 32) * 2);
     const int max_wg = (16 / NW) * num_cus();
     const int per_wg = (n_ht + max_wg - 1) / max_wg;
     const int grid = (n_ht + per_wg - 1) / per_wg;
-    kernel<<<grid, NW * 64, smem, s>>>((const uint8_t *)A, m, nb, (const uint8_t *)B, brb, col0, C, ldc, n_ht);
+    kernel<<<grid, NW * 64, smem, s>>>(mats, nb, (const uint8_t *)B, brb, col0, n_ht);
     return hipGetLastError();
 }
 
 template <typename TR, int NC, int BT>
-static hipError_t launch_kq_pick(const void *A, long m, long k, const void *B, size_t brb, long col0, float *C, long ldc,
+static hipError_t launch_kq_pick(const gemv_mats &mats, int n_ht, long k, const void *B, size_t brb, long col0,
                                  hipStream_t s) {
     const long nb = k / 256;
     if constexpr (NC == 1) {
         if (nb <= 16)
-            return launch_kq<TR, NC, BT, 16, 1>(A, m, k, B, brb, col0, C, ldc, s);
-        return launch_kq<TR, NC, BT, 16, 2>(A, m, k, B, brb, col0, C, ldc, s);
+            return launch_kq<TR, NC, BT, 16, 1>(mats, n_ht, k, B, brb, col0, s);
+        return launch_kq<TR, NC, BT, 16, 2>(mats, n_ht, k, B, brb, col0, s);
     } else {
         if (nb <= 16)
-            return launch_kq<TR, NC, BT, 8, 2>(A, m, k, B, brb, col0, C, ldc, s);
-        return launch_kq<TR, NC, BT, 8, 4>(A, m, k, B, brb, col0, C, ldc, s);
+            return launch_kq<TR, NC, BT, 8, 2>(mats, n_ht, k, B, brb, col0, s);
+        return launch_kq<TR, NC, BT, 8, 4>(mats, n_ht, k, B, brb, col0, s);
     }
 }
 
 template <int NC, int BT>
-static hipError_t launch_q4k(const void *A, long m, long k, const void *B, size_t brb, long col0, float *C, long ldc,
-                             hipStream_t s) {
-    return launch_kq_pick<q4k_traits, NC, BT>(A, m, k, B, brb, col0, C, ldc, s);
+static hipError_t launch_q4k(const gemv_mats &mats, int n_ht, long k, const void *B, size_t brb, long col0, hipStream_t s) {
+    return launch_kq_pick<q4k_traits, NC, BT>(mats, n_ht, k, B, brb, col0, s);
 }
 
 template <int NC, int BT>
-static hipError_t launch_q6k(const void *A, long m, long k, const void *B, size_t brb, long col0, float *C, long ldc,
-                             hipStream_t s) {
-    return launch_kq_pick<q6k_traits, NC, BT>(A, m, k, B, brb, col0, C, ldc, s);
+static hipError_t launch_q6k(const gemv_mats &mats, int n_ht, long k, const void *B, size_t brb, long col0, hipStream_t s) {
+    return launch_kq_pick<q6k_traits, NC, BT>(mats, n_ht, k, B, brb, col0, s);
 }
 
 template <int NC, int BT>
@@ -626,11 +648,12 @@ static int max_cols_for(size_t per_col_bytes) {
         break;                                                                                                         \
     }
 
-// Btype: the weight type's vec_dot type (pre-quantised rows) or LFAMD_TYPE_F32 (quantise in-kernel)
-extern "C" hipError_t lfamd_launch_gemv(int Atype, const void *A, long m, long k, int Btype, const void *B,
-                                        size_t b_row_bytes, long n, float *C, long ldc, int vregs32, int precise,
-                                        hipStream_t s) {
-    if (m <= 0 || n <= 0)
+// Btype: the weight type's vec_dot type (pre-quantised rows) or LFAMD_TYPE_F32 (quantise in-kernel).
+// `count` matrices (<= GEMV_MAX_MATS for the K-quants, 1 for Q8_0) of the same type and k share B.
+extern "C" hipError_t lfamd_launch_gemv_multi(int Atype, int count, const void *const *A, const long *m, long k, int Btype,
+                                              const void *B, size_t b_row_bytes, long n, float *const *C, const long *ldc,
+                                              int vregs32, int precise, hipStream_t s) {
+    if (count <= 0 || n <= 0)
         return hipSuccess;
     size_t per_col;
     if (Atype == LFAMD_TYPE_Q8_0)
@@ -642,29 +665,65 @@ extern "C" hipError_t lfamd_launch_gemv(int Atype, const void *A, long m, long k
         return hipErrorInvalidValue;
     const bool f32in = Btype == LFAMD_TYPE_F32;
     hipError_t e = hipSuccess;
+    if (Atype == LFAMD_TYPE_Q8_0) {
+        for (int j = 0; j < count && e == hipSuccess; j++) {
+            if (m[j] <= 0)
+                continue;
+            for (long col0 = 0; col0 < n && e == hipSuccess; col0 += step) {
+                int nc = (int)((n - col0) < step ? (n - col0) : step);
+                if (f32in) {
+                    DISPATCH_NC(launch_q80, LFAMD_TYPE_F32, nc, A[j], m[j], n, k, B, b_row_bytes, col0, C[j], ldc[j], vregs32,
+                                precise, s)
+                } else {
+                    DISPATCH_NC(launch_q80, LFAMD_TYPE_Q8_0, nc, A[j], m[j], n, k, B, b_row_bytes, col0, C[j], ldc[j],
+                                vregs32, precise, s)
+                }
+            }
+        }
+        return e;
+    }
+    if (count > GEMV_MAX_MATS || (Atype != LFAMD_TYPE_Q4_K && Atype != LFAMD_TYPE_Q6_K))
+        return hipErrorInvalidValue;
+    gemv_mats mats;
+    int n_ht = 0;
+    mats.count = 0;
+    for (int j = 0; j < count; j++) {
+        if (m[j] <= 0)
+            continue;
+        int i = mats.count++;
+        mats.A[i] = (const uint8_t *)A[j];
+        mats.C[i] = C[j];
+        mats.m[i] = m[j];
+        mats.ldc[i] = ldc[j];
+        n_ht += (int)(((m[j] + 31) / 32) * 2);
+        mats.ht_end[i] = n_ht;
+    }
+    if (mats.count == 0)
+        return hipSuccess;
+    for (int i = mats.count; i < GEMV_MAX_MATS; i++) {
+        mats.A[i] = mats.A[0], mats.C[i] = mats.C[0], mats.m[i] = 0, mats.ldc[i] = 0, mats.ht_end[i] = n_ht;
+    }
     for (long col0 = 0; col0 < n && e == hipSuccess; col0 += step) {
         int nc = (int)((n - col0) < step ? (n - col0) : step);
         if (Atype == LFAMD_TYPE_Q4_K) {
             if (f32in) {
-                DISPATCH_NC(launch_q4k, LFAMD_TYPE_F32, nc, A, m, k, B, b_row_bytes, col0, C, ldc, s)
+                DISPATCH_NC(launch_q4k, LFAMD_TYPE_F32, nc, mats, n_ht, k, B, b_row_bytes, col0, s)
             } else {
-                DISPATCH_NC(launch_q4k, LFAMD_TYPE_Q8_K, nc, A, m, k, B, b_row_bytes, col0, C, ldc, s)
-            }
-        } else if (Atype == LFAMD_TYPE_Q6_K) {
-            if (f32in) {
-                DISPATCH_NC(launch_q6k, LFAMD_TYPE_F32, nc, A, m, k, B, b_row_bytes, col0, C, ldc, s)
-            } else {
-                DISPATCH_NC(launch_q6k, LFAMD_TYPE_Q8_K, nc, A, m, k, B, b_row_bytes, col0, C, ldc, s)
-            }
-        } else if (Atype == LFAMD_TYPE_Q8_0) {
-            if (f32in) {
-                DISPATCH_NC(launch_q80, LFAMD_TYPE_F32, nc, A, m, n, k, B, b_row_bytes, col0, C, ldc, vregs32, precise, s)
-            } else {
-                DISPATCH_NC(launch_q80, LFAMD_TYPE_Q8_0, nc, A, m, n, k, B, b_row_bytes, col0, C, ldc, vregs32, precise, s)
+                DISPATCH_NC(launch_q4k, LFAMD_TYPE_Q8_K, nc, mats, n_ht, k, B, b_row_bytes, col0, s)
             }
         } else {
-            return hipErrorInvalidValue;
+            if (f32in) {
+                DISPATCH_NC(launch_q6k, LFAMD_TYPE_F32, nc, mats, n_ht, k, B, b_row_bytes, col0, s)
+            } else {
+                DISPATCH_NC(launch_q6k, LFAMD_TYPE_Q8_K, nc, mats, n_ht, k, B, b_row_bytes, col0, s)
+            }
         }
     }
     return e;
+}
+
+extern "C" hipError_t lfamd_launch_gemv(int Atype, const void *A, long m, long k, int Btype, const void *B,
+                                        size_t b_row_bytes, long n, float *C, long ldc, int vregs32, int precise,
+                                        hipStream_t s) {
+    return lfamd_launch_gemv_multi(Atype, 1, &A, &m, k, Btype, B, b_row_bytes, n, &C, &ldc, vregs32, precise, s);
 }

@@ -122,6 +122,31 @@ def mul_mat(W: PackedWeights, B: torch.Tensor, Btype: int, n: int | None = None,
     return out
 
 
+def mul_mat_multi(Ws: list, B: torch.Tensor, Btype: int, n: int | None = None, flags: int | None = None,
+                  workspace: torch.Tensor | None = None) -> list:
+    """Several GGML_OP_MUL_MAT nodes sharing the activations B (same weight type and k): one fused launch
+    where the module can (decode GEMV), else one per matrix.  Returns the list of f32 [n, m_j] outputs."""
+    L = _hip.lib()
+    assert len(Ws) >= 1 and all(w.type == Ws[0].type and w.cols == Ws[0].cols for w in Ws)
+    n = B.shape[0] if n is None else n
+    flags = host_variant_flags() if flags is None else flags
+    outs = [torch.empty((n, w.rows), dtype=torch.float32, device=B.device) for w in Ws]
+    need = max(L.lfamd_mul_mat_workspace(w.type, w.rows, w.cols, n) for w in Ws)
+    if need and (workspace is None or workspace.numel() < need):
+        workspace = torch.empty(need, dtype=torch.uint8, device=B.device)
+    cnt = len(Ws)
+    A_arr = (C.c_void_p * cnt)(*[w.data.data_ptr() for w in Ws])
+    C_arr = (C.c_void_p * cnt)(*[o.data_ptr() for o in outs])
+    m_arr = (C.c_long * cnt)(*[w.rows for w in Ws])
+    ldc_arr = (C.c_long * cnt)(*[w.rows for w in Ws])
+    ws_ptr = _ptr(workspace) if workspace is not None else C.c_void_p(0)
+    ws_len = workspace.numel() if workspace is not None else 0
+    rc = L.lfamd_mul_mat_multi(Ws[0].type, cnt, A_arr, m_arr, Ws[0].cols, Btype, _ptr(B), B.stride(0) * B.element_size(), n,
+                               C_arr, ldc_arr, ws_ptr, ws_len, flags, _stream())
+    _hip.check(rc, "lfamd_mul_mat_multi")
+    return outs
+
+
 def llamafile_sgemm(m: int, n: int, k: int, A: PackedWeights, lda: int, B: torch.Tensor, ldb: int, Cout: torch.Tensor,
                     ldc: int, ith: int, nth: int, Atype: int, Btype: int, Ctype: int, flags: int | None = None) -> bool:
     """Device-resident mirror of llamafile_sgemm (sgemm.h:23-24).  k, lda, ldb are in BLOCKS for

@@ -118,3 +118,19 @@ def test_f32_activations_equal_prequantised(gpu, t, n):
     c_q = gpu.mul_mat(W, gpu.quantize_rows(bt, xd), bt).cpu().numpy()
     assert not np.isnan(c_f32).any()
     assert np.array_equal(c_f32.view(np.uint32), c_q.view(np.uint32))
+
+
+@pytest.mark.parametrize("t", [T.Q4_K, T.Q6_K], ids=lambda t: T.NAMES[t])
+@pytest.mark.parametrize("n", [1, 4, 20])
+def test_mul_mat_multi_equals_separate(gpu, t, n):
+    """Sibling mat-muls fused into one launch (attn_q/k/v, ffn_gate/up) give bit-identical results to
+    separate lfamd_mul_mat calls — including odd row counts and a matrix smaller than a tile."""
+    from llamafile_amd import synth
+    k = 1024
+    ms = [96, 40, 7, 130]
+    Ws = [gpu.upload_weights(t, synth.random_weights(t, m, k, 60 + i), m, k) for i, m in enumerate(ms)]
+    x = torch.from_numpy(synth.random_activations(n, k, 70)).cuda()
+    fused = gpu.mul_mat_multi(Ws, x.view(torch.uint8), T.F32, n=n)
+    for W, f in zip(Ws, fused):
+        sep = gpu.mul_mat(W, x.view(torch.uint8), T.F32, n=n)
+        assert np.array_equal(f.cpu().numpy().view(np.uint32), sep.cpu().numpy().view(np.uint32))
