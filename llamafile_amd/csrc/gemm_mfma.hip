@@ -16,9 +16,10 @@
 // rows), so a lane owns one weight row (its d/dmin are per-lane scalars) and the C store is 32
 // consecutive floats per half-wave.
 //
-// v1 structure: work-group = 4 waves; wave w owns weight row-tile 4*blockIdx.x + w (32 rows) and all
-// 64 tokens of the block's token tile; weights go HBM -> VGPR -> fragment (no LDS), activations go
-// through one XOR-swizzled LDS tile per super-block.
+// Structure: work-group = 4 waves; wave w owns weight row-tile 4*blockIdx.x + w (32 rows) and all 64
+// tokens of the block's token tile; weights go HBM -> VGPR -> fragment (no LDS, one super-block
+// prefetched ahead), activations go global -> LDS directly (global_load_lds) into two XOR-swizzled
+// tiles, one barrier per super-block.
 #include "lfamd_device.h"
 
 #define TOK_TILE 64
@@ -75,14 +76,27 @@ __device__ static inline half8_t dequant_q6(uint32_t x, uint32_t H, half2_t S) {
     return f.v;
 }
 
+// per-super-block operands a wave keeps in registers
+template <int TYPE>
+struct wregs {
+    uint4 qs[4];
+    uint4 hd;    // Q4_K: {d, dmin, scales[12]};  Q6_K: 16 int8 scales
+    uint4 qh[2]; // Q6_K only
+    float dw;    // Q6_K only
+    float4_t_ d8[2][4];
+    half8_t xm[2]; // Q4_K only
+};
+
 template <int TYPE>
 __global__ __launch_bounds__(256) void gemm_kq_kernel(const uint8_t *__restrict__ A, long m, int nb,
                                                       const _Float16 *__restrict__ Xh, const float *__restrict__ d8T,
                                                       const _Float16 *__restrict__ Xm, long n, long n_pad,
                                                       float *__restrict__ C, long ldc) {
-    __shared__ __attribute__((aligned(16))) uint8_t xt[TOK_TILE * XT_ROW_BYTES]; // 32 KiB
+    // two activation tiles (64 tokens x 256 codes, f16) so the global->LDS copy of super-block b+1 runs
+    // under the MFMAs of super-block b
+    __shared__ __attribute__((aligned(16))) uint8_t xt[2][TOK_TILE * XT_ROW_BYTES]; // 64 KiB
     constexpr int TILE = TYPE == LFAMD_TYPE_Q4_K ? P4K_TILE : P6K_TILE;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 31, h = lane >> 5;
     const long n_row_tiles = (m + 31) / 32;
     const long rt = (long)blockIdx.x * 4 + wave;
@@ -91,6 +105,40 @@ __global__ __launch_bounds__(256) void gemm_kq_kernel(const uint8_t *__restrict_
     const long k = (long)nb * 256;
     const uint8_t *tile0 = A + (size_t)(active ? rt : 0) * nb * TILE;
 
+    // ---- issue everything super-block b needs: activations straight into LDS (global_load_lds, the XOR
+    // swizzle applied on the SOURCE address since the LDS side is lane-linear), weights / scales to VGPRs
+    auto prefetch = [&](int b, wregs<TYPE> &w) {
+        uint8_t *dst = xt[b & 1];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const int wi = wave * 8 + e;      // wave-instruction: rows 2wi, 2wi+1 of the tile (1 KiB)
+            const int nn = 2 * wi + h, p = i; // this lane fills slot p of row nn with logical chunk p ^ (nn & 15)
+            const uint8_t *src = (const uint8_t *)Xh + ((size_t)(n0 + nn) * k + (size_t)b * 256) * 2 + ((p ^ (nn & 15)) * 16);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(dst + wi * 1024), 16, 0, 0);
+        }
+        const uint8_t *tile = tile0 + (size_t)b * TILE;
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+            w.qs[g] = *(const uint4 *)(tile + g * 1024 + lane * 16);
+        if constexpr (TYPE == LFAMD_TYPE_Q4_K) {
+            w.hd = *(const uint4 *)(tile + P4K_HDR + i * 16);
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++)
+                w.xm[nt] = *(const half8_t *)(Xm + ((size_t)(n0 + nt * 32 + i) * nb + b) * 16 + 8 * h);
+        } else {
+            w.qh[0] = *(const uint4 *)(tile + P6K_QH + 0 * 1024 + lane * 16);
+            w.qh[1] = *(const uint4 *)(tile + P6K_QH + 1 * 1024 + lane * 16);
+            w.hd = *(const uint4 *)(tile + P6K_SC + i * 16);
+            w.dw = h2f(*(const uint16_t *)(tile + P6K_D + i * 2));
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; r4++)
+                w.d8[nt][r4] = *(const float4_t_ *)(d8T + (size_t)b * n_pad + n0 + nt * 32 + 8 * r4 + 4 * h);
+    };
+
     float16_t_ acc[2];
 #pragma unroll
     for (int nt = 0; nt < 2; nt++)
@@ -98,50 +146,21 @@ __global__ __launch_bounds__(256) void gemm_kq_kernel(const uint8_t *__restrict_
         for (int r = 0; r < 16; r++)
             acc[nt][r] = 0.0f;
 
-    for (int b = 0; b < nb; b++) {
-        const uint8_t *tile = tile0 + (size_t)b * TILE;
-        // ---- weights: HBM -> VGPR (issued first so the loads fly during the LDS staging)
-        uint4 qs[4];
-#pragma unroll
-        for (int g = 0; g < 4; g++)
-            qs[g] = *(const uint4 *)(tile + g * 1024 + lane * 16);
-        uint4 hd;
-        uint4 qh[2];
-        float dw = 0.0f;
-        if constexpr (TYPE == LFAMD_TYPE_Q4_K) {
-            hd = *(const uint4 *)(tile + P4K_HDR + i * 16);
-        } else {
-            qh[0] = *(const uint4 *)(tile + P6K_QH + 0 * 1024 + lane * 16);
-            qh[1] = *(const uint4 *)(tile + P6K_QH + 1 * 1024 + lane * 16);
-            hd = *(const uint4 *)(tile + P6K_SC + i * 16);
-            dw = h2f(*(const uint16_t *)(tile + P6K_D + i * 2));
-        }
-
-        // ---- activations: stage this super-block's 64 x 256 codes into LDS (XOR swizzle on the
-        // 16-byte chunk index so the ds_read_b128 of a fragment is bank-conflict free)
-        __syncthreads(); // previous iteration's fragment reads are done
-#pragma unroll
-        for (int e = 0; e < 8; e++) {
-            const int q = threadIdx.x + 256 * e;
-            const int nn = q >> 5, c = q & 31;
-            const uint4 v = *(const uint4 *)((const uint8_t *)Xh + ((size_t)(n0 + nn) * k + (size_t)b * 256) * 2 + c * 16);
-            *(uint4 *)(xt + nn * XT_ROW_BYTES + ((c ^ (nn & 15)) * 16)) = v;
-        }
-        __syncthreads();
-
+    auto compute = [&](int b, const wregs<TYPE> &w) {
+        const uint8_t *xb = xt[b & 1];
         float16_t_ tmp[2];
 #pragma unroll
         for (int nt = 0; nt < 2; nt++)
 #pragma unroll
             for (int r = 0; r < 16; r++)
                 tmp[nt][r] = 0.0f;
-
+        const uint32_t qw[16] = {w.qs[0].x, w.qs[0].y, w.qs[0].z, w.qs[0].w, w.qs[1].x, w.qs[1].y, w.qs[1].z, w.qs[1].w,
+                                 w.qs[2].x, w.qs[2].y, w.qs[2].z, w.qs[2].w, w.qs[3].x, w.qs[3].y, w.qs[3].z, w.qs[3].w};
         if constexpr (TYPE == LFAMD_TYPE_Q4_K) {
+            const uint4 hd = w.hd;
             const float d = h2f((uint16_t)(hd.x & 0xffff)), dmin = h2f((uint16_t)(hd.x >> 16));
             uint32_t sc03, sc47, mn03, mn47;
             q4k_scales_bytes(hd.y, hd.z, hd.w, sc03, sc47, mn03, mn47);
-            const uint32_t qw[16] = {qs[0].x, qs[0].y, qs[0].z, qs[0].w, qs[1].x, qs[1].y, qs[1].z, qs[1].w,
-                                     qs[2].x, qs[2].y, qs[2].z, qs[2].w, qs[3].x, qs[3].y, qs[3].z, qs[3].w};
 #pragma unroll
             for (int j = 0; j < 8; j++) { // 32-wide sub-block = K-steps 2j, 2j+1
                 const float scf = (float)(((j < 4 ? sc03 : sc47) >> (8 * (j & 3))) & 0xff);
@@ -154,7 +173,7 @@ __global__ __launch_bounds__(256) void gemm_kq_kernel(const uint8_t *__restrict_
 #pragma unroll
                     for (int nt = 0; nt < 2; nt++) {
                         const int c = 2 * t + h;
-                        const half8_t xf = *(const half8_t *)(xt + (nt * 32 + i) * XT_ROW_BYTES + ((c ^ (i & 15)) * 16));
+                        const half8_t xf = *(const half8_t *)(xb + (nt * 32 + i) * XT_ROW_BYTES + ((c ^ (i & 15)) * 16));
                         tmp[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xf, wf, tmp[nt], 0, 0, 0);
                     }
                 }
@@ -171,55 +190,66 @@ __global__ __launch_bounds__(256) void gemm_kq_kernel(const uint8_t *__restrict_
             }
 #pragma unroll
             for (int nt = 0; nt < 2; nt++) {
-                const half8_t xm = *(const half8_t *)(Xm + ((size_t)(n0 + nt * 32 + i) * nb + b) * 16 + 8 * h);
                 float16_t_ tm;
 #pragma unroll
                 for (int r = 0; r < 16; r++)
                     tm[r] = 0.0f;
-                tm = __builtin_amdgcn_mfma_f32_32x32x16_f16(xm, wm.v, tm, 0, 0, 0);
+                tm = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.xm[nt], wm.v, tm, 0, 0, 0);
                 // ---- per-super-block scaling: acc += d8[n] * (d * tmp - dmin * tm)
 #pragma unroll
-                for (int r4 = 0; r4 < 4; r4++) {
-                    const float4_t_ d8 = *(const float4_t_ *)(d8T + (size_t)b * n_pad + n0 + nt * 32 + 8 * r4 + 4 * h);
+                for (int r4 = 0; r4 < 4; r4++)
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
                         const int r = 4 * r4 + e;
                         const float u = fmaf(-dmin, tm[r], d * tmp[nt][r]);
-                        acc[nt][r] = fmaf(u, d8[e], acc[nt][r]);
+                        acc[nt][r] = fmaf(u, w.d8[nt][r4][e], acc[nt][r]);
                     }
-                }
             }
         } else { // Q6_K: 16-wide sub-blocks, one per K-step; no mins
-            const uint32_t qw[16] = {qs[0].x, qs[0].y, qs[0].z, qs[0].w, qs[1].x, qs[1].y, qs[1].z, qs[1].w,
-                                     qs[2].x, qs[2].y, qs[2].z, qs[2].w, qs[3].x, qs[3].y, qs[3].z, qs[3].w};
-            const uint32_t hw[8] = {qh[0].x, qh[0].y, qh[0].z, qh[0].w, qh[1].x, qh[1].y, qh[1].z, qh[1].w};
-            const uint32_t scw[4] = {hd.x, hd.y, hd.z, hd.w};
+            const uint32_t hw[8] = {w.qh[0].x, w.qh[0].y, w.qh[0].z, w.qh[0].w, w.qh[1].x, w.qh[1].y, w.qh[1].z, w.qh[1].w};
+            const uint32_t scw[4] = {w.hd.x, w.hd.y, w.hd.z, w.hd.w};
 #pragma unroll
             for (int t = 0; t < 16; t++) {
                 const float scf = (float)(int)(int8_t)((scw[t >> 2] >> (8 * (t & 3))) & 0xff);
                 const half2_t S = bcast_h2(scf);
-                uint32_t H = hw[t >> 1]; // group g = t>>2 -> hw[2*(g>>1)*... see pack: dword q=(g&1)*2+e of qh[g>>1]
+                uint32_t H = hw[t >> 1];
                 if (t & 1)
                     H >>= 2;
                 const half8_t wf = dequant_q6(qw[t], H, S);
 #pragma unroll
                 for (int nt = 0; nt < 2; nt++) {
                     const int c = 2 * t + h;
-                    const half8_t xf = *(const half8_t *)(xt + (nt * 32 + i) * XT_ROW_BYTES + ((c ^ (i & 15)) * 16));
+                    const half8_t xf = *(const half8_t *)(xb + (nt * 32 + i) * XT_ROW_BYTES + ((c ^ (i & 15)) * 16));
                     tmp[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xf, wf, tmp[nt], 0, 0, 0);
                 }
             }
 #pragma unroll
             for (int nt = 0; nt < 2; nt++)
 #pragma unroll
-                for (int r4 = 0; r4 < 4; r4++) {
-                    const float4_t_ d8 = *(const float4_t_ *)(d8T + (size_t)b * n_pad + n0 + nt * 32 + 8 * r4 + 4 * h);
+                for (int r4 = 0; r4 < 4; r4++)
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
                         const int r = 4 * r4 + e;
-                        acc[nt][r] = fmaf(dw * tmp[nt][r], d8[e], acc[nt][r]);
+                        acc[nt][r] = fmaf(w.dw * tmp[nt][r], w.d8[nt][r4][e], acc[nt][r]);
                     }
-                }
+        }
+    };
+
+    // ---- software pipeline, two register sets (no copies): super-block b+1 is in flight while b computes.
+    // __syncthreads() drains the LDS-DMA (vmcnt(0)) before the tile is read one iteration later.
+    wregs<TYPE> wa, wb;
+    prefetch(0, wa);
+    __syncthreads();
+    for (int b = 0; b < nb; b += 2) {
+        if (b + 1 < nb)
+            prefetch(b + 1, wb);
+        compute(b, wa);
+        __syncthreads();
+        if (b + 1 < nb) {
+            if (b + 2 < nb)
+                prefetch(b + 2, wa);
+            compute(b + 1, wb);
+            __syncthreads();
         }
     }
 
