@@ -16,10 +16,12 @@
 // rows), so a lane owns one weight row (its d/dmin are per-lane scalars) and the C store is 32
 // consecutive floats per half-wave.
 //
-// Structure: work-group = 4 waves; wave w owns weight row-tile 4*blockIdx.x + w (32 rows) and all 64
-// tokens of the block's token tile; weights go HBM -> VGPR -> fragment (no LDS, one super-block
-// prefetched ahead), activations go global -> LDS directly (global_load_lds) into two XOR-swizzled
-// tiles, one barrier per super-block.
+// Structure: work-group = 8 waves = 2 K-groups x 4 row-tiles on a 128-row x 64-token output tile (intra-
+// work-group split-K: two waves per SIMD, so one wave's dequant VALU work runs under the other's MFMAs, and
+// the K loop is half as long); weights go HBM -> VGPR -> fragment (no LDS, one super-block prefetched ahead),
+// activations go global -> LDS directly (global_load_lds) into two XOR-swizzled tiles per K-group, one
+// barrier per super-block; the two partial accumulators meet in LDS at the end.  Tiles are assigned to
+// work-groups XCD-aware so an XCD's work-groups share a token tile.
 #include "lfamd_device.h"
 
 #define TOK_TILE 64
@@ -76,42 +78,60 @@ __device__ static inline half8_t dequant_q6(uint32_t x, uint32_t H, half2_t S) {
     return f.v;
 }
 
-// per-super-block operands a wave keeps in registers
+// per-super-block weight operands a wave keeps in registers
 template <int TYPE>
 struct wregs {
     uint4 qs[4];
     uint4 hd;    // Q4_K: {d, dmin, scales[12]};  Q6_K: 16 int8 scales
     uint4 qh[2]; // Q6_K only
-    float dw;    // Q6_K only
+    uint32_t dw; // Q6_K only (f16 bits)
+};
+
+struct sregs { // per-super-block activation-side scales
     float4_t_ d8[2][4];
     half8_t xm[2]; // Q4_K only
 };
 
+#define GEMM_KG 2 // K-groups per work-group (intra-work-group split-K)
+
 template <int TYPE>
-__global__ __launch_bounds__(256) void gemm_kq_kernel(const uint8_t *__restrict__ A, long m, int nb,
+__global__ __launch_bounds__(512) void gemm_kq_kernel(const uint8_t *__restrict__ A, long m, int nb,
                                                       const _Float16 *__restrict__ Xh, const float *__restrict__ d8T,
                                                       const _Float16 *__restrict__ Xm, long n, long n_pad,
-                                                      float *__restrict__ C, long ldc) {
-    // two activation tiles (64 tokens x 256 codes, f16) so the global->LDS copy of super-block b+1 runs
-    // under the MFMAs of super-block b
-    __shared__ __attribute__((aligned(16))) uint8_t xt[2][TOK_TILE * XT_ROW_BYTES]; // 64 KiB
+                                                      float *__restrict__ C, long ldc, int n_rb, int n_wg) {
+    // per K-group two activation tiles (64 tokens x 256 codes, f16): the global->LDS copy of the next
+    // super-block runs under the MFMAs of the current one.  2 x 2 x 32 KiB = 128 KiB.
+    __shared__ __attribute__((aligned(16))) uint8_t xt[GEMM_KG][2][TOK_TILE * XT_ROW_BYTES];
     constexpr int TILE = TYPE == LFAMD_TYPE_Q4_K ? P4K_TILE : P6K_TILE;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int kg = wave >> 2, rw = wave & 3; // K-group, row-tile inside the work-group
     const int i = lane & 31, h = lane >> 5;
+
+    // XCD-aware tile assignment (T1): consecutive block ids go round-robin over the 8 XCDs, so give every
+    // XCD one contiguous run of the linear tile order (row-blocks fastest): the work-groups of an XCD then
+    // share a token tile (512 KiB of activation codes stays in that XCD's L2) and stream distinct weights.
+    const int id = blockIdx.x, q8 = n_wg >> 3, r8 = n_wg & 7, xcd = id & 7;
+    const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3);
+    const int tt = L / n_rb, rb = L - tt * n_rb;
+
     const long n_row_tiles = (m + 31) / 32;
-    const long rt = (long)blockIdx.x * 4 + wave;
+    const long rt = (long)rb * 4 + rw;
     const bool active = rt < n_row_tiles;
-    const long n0 = (long)blockIdx.y * TOK_TILE;
+    const long n0 = (long)tt * TOK_TILE;
     const long k = (long)nb * 256;
     const uint8_t *tile0 = A + (size_t)(active ? rt : 0) * nb * TILE;
+    const int nit = (nb - kg + GEMM_KG - 1) / GEMM_KG; // this K-group's super-blocks: kg, kg+2, ...
+    const int nit_max = (nb + GEMM_KG - 1) / GEMM_KG;
 
-    // ---- issue everything super-block b needs: activations straight into LDS (global_load_lds, the XOR
-    // swizzle applied on the SOURCE address since the LDS side is lane-linear), weights / scales to VGPRs
-    auto prefetch = [&](int b, wregs<TYPE> &w) {
-        uint8_t *dst = xt[b & 1];
+    // ---- issue the operands of super-block it of this K-group: activations straight into LDS
+    // (global_load_lds, the XOR swizzle applied on the SOURCE address since the LDS side is lane-linear),
+    // weights to VGPRs
+    auto prefetch = [&](int it, wregs<TYPE> &w) {
+        const int b = it * GEMM_KG + kg;
+        uint8_t *dst = xt[kg][it & 1];
 #pragma unroll
         for (int e = 0; e < 8; e++) {
-            const int wi = wave * 8 + e;      // wave-instruction: rows 2wi, 2wi+1 of the tile (1 KiB)
+            const int wi = rw * 8 + e;        // wave-instruction: rows 2wi, 2wi+1 of the tile (1 KiB)
             const int nn = 2 * wi + h, p = i; // this lane fills slot p of row nn with logical chunk p ^ (nn & 15)
             const uint8_t *src = (const uint8_t *)Xh + ((size_t)(n0 + nn) * k + (size_t)b * 256) * 2 + ((p ^ (nn & 15)) * 16);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
@@ -123,20 +143,42 @@ __global__ __launch_bounds__(256) void gemm_kq_kernel(const uint8_t *__restrict_
             w.qs[g] = *(const uint4 *)(tile + g * 1024 + lane * 16);
         if constexpr (TYPE == LFAMD_TYPE_Q4_K) {
             w.hd = *(const uint4 *)(tile + P4K_HDR + i * 16);
-#pragma unroll
-            for (int nt = 0; nt < 2; nt++)
-                w.xm[nt] = *(const half8_t *)(Xm + ((size_t)(n0 + nt * 32 + i) * nb + b) * 16 + 8 * h);
         } else {
             w.qh[0] = *(const uint4 *)(tile + P6K_QH + 0 * 1024 + lane * 16);
             w.qh[1] = *(const uint4 *)(tile + P6K_QH + 1 * 1024 + lane * 16);
             w.hd = *(const uint4 *)(tile + P6K_SC + i * 16);
-            w.dw = h2f(*(const uint16_t *)(tile + P6K_D + i * 2));
+            w.dw = *(const uint16_t *)(tile + P6K_D + i * 2);
+        }
+    };
+    // hipcc's waitcnt pass does not count LDS-DMA: beside it, the first use of ANY register load waits
+    // vmcnt(0) (cdna_hip_programming.md §5 trap (b)).  The weights of the current super-block landed before
+    // the previous barrier, so "use" every register of the set here — an empty asm, no instruction — and
+    // only THEN issue the next super-block's loads: the wait is paid while nothing is outstanding, and the
+    // MFMAs below run with the prefetch genuinely in flight.
+    auto touch = [&](wregs<TYPE> &w) {
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+            asm volatile("" : "+v"(w.qs[g].x), "+v"(w.qs[g].y), "+v"(w.qs[g].z), "+v"(w.qs[g].w));
+        asm volatile("" : "+v"(w.hd.x), "+v"(w.hd.y), "+v"(w.hd.z), "+v"(w.hd.w));
+        if constexpr (TYPE == LFAMD_TYPE_Q6_K) {
+            asm volatile("" : "+v"(w.qh[0].x), "+v"(w.qh[0].y), "+v"(w.qh[0].z), "+v"(w.qh[0].w));
+            asm volatile("" : "+v"(w.qh[1].x), "+v"(w.qh[1].y), "+v"(w.qh[1].z), "+v"(w.qh[1].w));
+            asm volatile("" : "+v"(w.dw));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto load_scales = [&](int it, sregs &sr) {
+        const int b = it * GEMM_KG + kg;
+        if constexpr (TYPE == LFAMD_TYPE_Q4_K) {
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++)
+                sr.xm[nt] = *(const half8_t *)(Xm + ((size_t)(n0 + nt * 32 + i) * nb + b) * 16 + 8 * h);
         }
 #pragma unroll
         for (int nt = 0; nt < 2; nt++)
 #pragma unroll
             for (int r4 = 0; r4 < 4; r4++)
-                w.d8[nt][r4] = *(const float4_t_ *)(d8T + (size_t)b * n_pad + n0 + nt * 32 + 8 * r4 + 4 * h);
+                sr.d8[nt][r4] = *(const float4_t_ *)(d8T + (size_t)b * n_pad + n0 + nt * 32 + 8 * r4 + 4 * h);
     };
 
     float16_t_ acc[2];
@@ -146,8 +188,8 @@ __global__ __launch_bounds__(256) void gemm_kq_kernel(const uint8_t *__restrict_
         for (int r = 0; r < 16; r++)
             acc[nt][r] = 0.0f;
 
-    auto compute = [&](int b, const wregs<TYPE> &w) {
-        const uint8_t *xb = xt[b & 1];
+    auto compute = [&](int it, const wregs<TYPE> &w, const sregs &sr) {
+        const uint8_t *xb = xt[kg][it & 1];
         float16_t_ tmp[2];
 #pragma unroll
         for (int nt = 0; nt < 2; nt++)
@@ -194,7 +236,7 @@ __global__ __launch_bounds__(256) void gemm_kq_kernel(const uint8_t *__restrict_
 #pragma unroll
                 for (int r = 0; r < 16; r++)
                     tm[r] = 0.0f;
-                tm = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.xm[nt], wm.v, tm, 0, 0, 0);
+                tm = __builtin_amdgcn_mfma_f32_32x32x16_f16(sr.xm[nt], wm.v, tm, 0, 0, 0);
                 // ---- per-super-block scaling: acc += d8[n] * (d * tmp - dmin * tm)
 #pragma unroll
                 for (int r4 = 0; r4 < 4; r4++)
@@ -202,12 +244,13 @@ __global__ __launch_bounds__(256) void gemm_kq_kernel(const uint8_t *__restrict_
                     for (int e = 0; e < 4; e++) {
                         const int r = 4 * r4 + e;
                         const float u = fmaf(-dmin, tm[r], d * tmp[nt][r]);
-                        acc[nt][r] = fmaf(u, w.d8[nt][r4][e], acc[nt][r]);
+                        acc[nt][r] = fmaf(u, sr.d8[nt][r4][e], acc[nt][r]);
                     }
             }
         } else { // Q6_K: 16-wide sub-blocks, one per K-step; no mins
             const uint32_t hw[8] = {w.qh[0].x, w.qh[0].y, w.qh[0].z, w.qh[0].w, w.qh[1].x, w.qh[1].y, w.qh[1].z, w.qh[1].w};
             const uint32_t scw[4] = {w.hd.x, w.hd.y, w.hd.z, w.hd.w};
+            const float dw = h2f((uint16_t)w.dw);
 #pragma unroll
             for (int t = 0; t < 16; t++) {
                 const float scf = (float)(int)(int8_t)((scw[t >> 2] >> (8 * (t & 3))) & 0xff);
@@ -230,31 +273,52 @@ __global__ __launch_bounds__(256) void gemm_kq_kernel(const uint8_t *__restrict_
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
                         const int r = 4 * r4 + e;
-                        acc[nt][r] = fmaf(w.dw * tmp[nt][r], w.d8[nt][r4][e], acc[nt][r]);
+                        acc[nt][r] = fmaf(dw * tmp[nt][r], sr.d8[nt][r4][e], acc[nt][r]);
                     }
         }
     };
 
-    // ---- software pipeline, two register sets (no copies): super-block b+1 is in flight while b computes.
-    // __syncthreads() drains the LDS-DMA (vmcnt(0)) before the tile is read one iteration later.
+    // ---- software pipeline, two weight register sets (no copies): super-block it+1 is in flight while it
+    // computes.  __syncthreads() drains the LDS-DMA (vmcnt(0)) before the tile is read one iteration later.
+    // Both K-groups run the same number of barriers (nit_max); a group without a super-block left idles.
     wregs<TYPE> wa, wb;
-    prefetch(0, wa);
+    sregs sr;
+    if (0 < nit)
+        prefetch(0, wa);
     __syncthreads();
-    for (int b = 0; b < nb; b += 2) {
-        if (b + 1 < nb)
-            prefetch(b + 1, wb);
-        compute(b, wa);
+    for (int it = 0; it < nit_max; it += 2) {
+        if (it < nit) {
+            touch(wa);
+            // unconditional (index clamped): a branch around the loads ends in register copies at the join,
+            // i.e. a use, i.e. a vmcnt(0) right after the issue
+            prefetch(it + 1 < nit ? it + 1 : nit - 1, wb);
+            load_scales(it, sr); // consumed after the MFMAs
+            compute(it, wa, sr);
+        }
         __syncthreads();
-        if (b + 1 < nb) {
-            if (b + 2 < nb)
-                prefetch(b + 2, wa);
-            compute(b + 1, wb);
+        if (it + 1 < nit_max) {
+            if (it + 1 < nit) {
+                touch(wb);
+                prefetch(it + 2 < nit ? it + 2 : nit - 1, wa);
+                load_scales(it + 1, sr);
+                compute(it + 1, wb, sr);
+            }
             __syncthreads();
         }
     }
 
-    // ---- store: reg r of token tile nt is token n0 + 32nt + (r&3) + 8(r>>2) + 4h, weight row 32rt + i
-    if (active) {
+    // ---- combine the two K-groups through LDS (the activation tiles are dead now), then store:
+    // reg r of token tile nt is token n0 + 32nt + (r&3) + 8(r>>2) + 4h, weight row 32rt + i
+    float *red = (float *)&xt[0][0][0]; // [rw][nt][r][lane] : 4 x 2 x 16 x 64 floats = 32 KiB
+    if (kg == 1) {
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                red[((rw * 2 + nt) * 16 + r) * 64 + lane] = acc[nt][r];
+    }
+    __syncthreads();
+    if (kg == 0 && active) {
         const long row = rt * 32 + i;
         if (row < m) {
 #pragma unroll
@@ -263,7 +327,7 @@ __global__ __launch_bounds__(256) void gemm_kq_kernel(const uint8_t *__restrict_
                 for (int r = 0; r < 16; r++) {
                     const long tok = n0 + nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                     if (tok < n)
-                        C[tok * ldc + row] = acc[nt][r];
+                        C[tok * ldc + row] = acc[nt][r] + red[((rw * 2 + nt) * 16 + r) * 64 + lane];
                 }
         }
     }
@@ -275,13 +339,16 @@ extern "C" hipError_t lfamd_launch_gemm_kq(int Atype, const void *A, long m, lon
         return hipSuccess;
     int nb = (int)(k / 256);
     long n_row_tiles = (m + 31) / 32;
-    dim3 grid((unsigned)((n_row_tiles + 3) / 4), (unsigned)(n_pad / TOK_TILE));
+    const int n_rb = (int)((n_row_tiles + 3) / 4), n_tt = (int)(n_pad / TOK_TILE);
+    const int n_wg = n_rb * n_tt;
     if (Atype == LFAMD_TYPE_Q4_K)
-        gemm_kq_kernel<LFAMD_TYPE_Q4_K><<<grid, 256, 0, s>>>((const uint8_t *)A, m, nb, (const _Float16 *)Xh,
-                                                               (const float *)d8T, (const _Float16 *)Xm, n, n_pad, C, ldc);
+        gemm_kq_kernel<LFAMD_TYPE_Q4_K><<<n_wg, 512, 0, s>>>((const uint8_t *)A, m, nb, (const _Float16 *)Xh,
+                                                               (const float *)d8T, (const _Float16 *)Xm, n, n_pad, C, ldc,
+                                                               n_rb, n_wg);
     else if (Atype == LFAMD_TYPE_Q6_K)
-        gemm_kq_kernel<LFAMD_TYPE_Q6_K><<<grid, 256, 0, s>>>((const uint8_t *)A, m, nb, (const _Float16 *)Xh,
-                                                               (const float *)d8T, (const _Float16 *)Xm, n, n_pad, C, ldc);
+        gemm_kq_kernel<LFAMD_TYPE_Q6_K><<<n_wg, 512, 0, s>>>((const uint8_t *)A, m, nb, (const _Float16 *)Xh,
+                                                               (const float *)d8T, (const _Float16 *)Xm, n, n_pad, C, ldc,
+                                                               n_rb, n_wg);
     else
         return hipErrorInvalidValue;
     return hipGetLastError();

@@ -72,6 +72,11 @@ __device__ static inline uint4 buf_ld16_nt(lfamd_rsrc r, uint32_t off) {
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 
+__device__ static inline uint4 buf_ld16(lfamd_rsrc r, uint32_t off) {
+    u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 __device__ static inline uint2 buf_ld8(lfamd_rsrc r, uint32_t off) {
     typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
     u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
