@@ -404,64 +404,77 @@ __global__ __launch_bounds__(NW * 64) void gemv_kq_kernel(const gemv_mats mats, 
 // contraction of sub(mul(a,b),e) into fma(a,b,-e).
 
 #define X80_BLK 36 // LDS: 8 dwords of q8 + f32 d
-#define Q80_DEPTH 32 // quads (1 KiB per wave each) kept in flight: a whole k = 4096 row set
+#define Q80_DEPTH 16 // quads (1 KiB per wave each) kept in flight per wave
+#define Q80_WAVES 2  // waves per work-group (8 rows each) sharing one staged activation image
 
-template <int NC, int BT>
-__global__ __launch_bounds__(64) void gemv_q80_kernel(const uint8_t *__restrict__ A, long m, long n_total, int nblocks,
-                                                      int nquads, const uint8_t *__restrict__ B, size_t b_row_bytes,
-                                                      long col0, float *__restrict__ C, long ldc, int vregs32,
-                                                      int precise) {
+// MODE: 0 = every output plain fma, 1 = every output Kahan (uniform for n = 1: tinyblas_cpu.h:797-925),
+// 2 = per-output choice from the mnpack geometry (small batches n > 1)
+template <int NC, int BT, int MODE>
+__global__ __launch_bounds__(Q80_WAVES * 64) void gemv_q80_kernel(const uint8_t *__restrict__ A, long m, long n_total,
+                                                                 int nblocks, int nquads, const uint8_t *__restrict__ B,
+                                                                 size_t b_row_bytes, long col0, float *__restrict__ C,
+                                                                 long ldc, int vregs32, int precise) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane >> 3, j = lane & 7;
-    const long rg = blockIdx.x;
+    const long rg = (long)blockIdx.x * Q80_WAVES + wave;
+    const long n_rg = (m + 7) / 8;
     const long row = rg * 8 + r;
-    const uint8_t *tile0 = A + (size_t)rg * nquads * P80_TILE;
+    // bounds-checked, unconditional weight loads (zeros past the row group / for an idle wave): keeps
+    // hipcc's counted vmcnt exact so Q80_DEPTH KiB per wave really stay in flight
+    const uint32_t rg_bytes = (uint32_t)nquads * P80_TILE;
+    const lfamd_rsrc rA = make_rsrc(A + (size_t)(rg < n_rg ? rg : 0) * rg_bytes, rg < n_rg ? rg_bytes : 0u);
 
     uint4 qa[Q80_DEPTH];
     uint2 ds[Q80_DEPTH];
-#pragma unroll
-    for (int s = 0; s < Q80_DEPTH; s++)
-        if (s < nquads) {
-            qa[s] = ld_nt16((tile0 + (size_t)s * P80_TILE + lane * 16));
-            ds[s] = *(const uint2 *)(tile0 + (size_t)s * P80_TILE + P80_D + r * 8);
-        }
+    auto issue = [&](int s, int L) {
+        qa[s] = buf_ld16_nt(rA, (uint32_t)L * P80_TILE + lane * 16);
+        ds[s] = buf_ld8(rA, (uint32_t)L * P80_TILE + P80_D + r * 8);
+    };
 
     if constexpr (BT == LFAMD_TYPE_F32) {
         // quantize_row_q8_0 (upstream): d = amax/127, id = 1/d, q = roundf(x*id); 16 floats per lane,
-        // two lanes per 32-block
-        const int pieces = nblocks * 2;
+        // two lanes per 32-block.  The first piece of each thread is fetched BEFORE the weights (vmcnt
+        // retires in order), the weights are issued, then the activations are quantised under their flight.
+        const int pieces = nblocks * 2, nthr = Q80_WAVES * 64;
         for (int c = 0; c < NC; c++) {
             const float *x = (const float *)(B + (col0 + c) * b_row_bytes);
-            for (int p = lane; p < pieces; p += 64) {
-                const float4 *src = (const float4 *)(x + (size_t)p * 16);
+            for (int p0 = 0; p0 < pieces; p0 += nthr) {
+                const int p = p0 + threadIdx.x;
                 float v[16];
+                if (p < pieces)
+                    load_piece(v, x, p);
+                if (c == 0 && p0 == 0) {
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    float4 f = src[e];
-                    v[4 * e + 0] = f.x, v[4 * e + 1] = f.y, v[4 * e + 2] = f.z, v[4 * e + 3] = f.w;
+                    for (int s = 0; s < Q80_DEPTH; s++)
+                        issue(s, s);
                 }
-                float amax = 0.0f;
+                if (p < pieces) {
+                    float amax = 0.0f;
 #pragma unroll
-                for (int e = 0; e < 16; e++)
-                    amax = fmaxf(amax, fabsf(v[e]));
-                amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
-                const float d = amax / 127.0f;
-                const float id = d != 0.0f ? 1.0f / d : 0.0f;
-                uint32_t y[4] = {0, 0, 0, 0};
+                    for (int e = 0; e < 16; e++)
+                        amax = fmaxf(amax, fabsf(v[e]));
+                    amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+                    const float d = amax / 127.0f;
+                    const float id = d != 0.0f ? 1.0f / d : 0.0f;
+                    uint32_t y[4] = {0, 0, 0, 0};
 #pragma unroll
-                for (int e = 0; e < 16; e++) {
-                    int q = (int)roundf(v[e] * id);
-                    y[e >> 2] |= (uint32_t)(q & 0xff) << (8 * (e & 3));
+                    for (int e = 0; e < 16; e++) {
+                        int q = (int)roundf(v[e] * id);
+                        y[e >> 2] |= (uint32_t)(q & 0xff) << (8 * (e & 3));
+                    }
+                    uint8_t *dst = lds + (size_t)(c * nblocks + (p >> 1)) * X80_BLK;
+                    *(uint4 *)(dst + 16 * (p & 1)) = make_uint4(y[0], y[1], y[2], y[3]);
+                    if ((p & 1) == 0)
+                        *(float *)(dst + 32) = h2f(f2h_bits(d)); // the block stores d as f16
                 }
-                uint8_t *dst = lds + (size_t)(c * nblocks + (p >> 1)) * X80_BLK;
-                *(uint4 *)(dst + 16 * (p & 1)) = make_uint4(y[0], y[1], y[2], y[3]);
-                if ((p & 1) == 0)
-                    *(float *)(dst + 32) = h2f(f2h_bits(d)); // the block stores d as f16
             }
         }
     } else {
-        for (int idx = lane; idx < NC * nblocks * 9; idx += 64) {
+#pragma unroll
+        for (int s = 0; s < Q80_DEPTH; s++)
+            issue(s, s);
+        for (int idx = threadIdx.x; idx < NC * nblocks * 9; idx += Q80_WAVES * 64) {
             int c = idx / (nblocks * 9), rem = idx % (nblocks * 9);
             int l = rem / 9, w = rem % 9;
             const uint8_t *y = B + (col0 + c) * b_row_bytes + (size_t)l * 34;
@@ -480,48 +493,60 @@ __global__ __launch_bounds__(64) void gemv_q80_kernel(const uint8_t *__restrict_
     bool kahan[NC];
 #pragma unroll
     for (int c = 0; c < NC; c++)
-        kahan[c] = q0_is_kahan(row < m ? row : m - 1, col0 + c, m, n_total, vregs32 != 0, precise != 0);
+        kahan[c] = MODE == 2 ? q0_is_kahan(row < m ? row : m - 1, col0 + c, m, n_total, vregs32 != 0, precise != 0) : MODE == 1;
 
     float Cv[NC], Ce[NC];
 #pragma unroll
     for (int c = 0; c < NC; c++)
         Cv[c] = Ce[c] = 0.0f;
 
+    // one block: a = f32(dA)*f32(dB), b = f32(int dot of bytes 4j..4j+3), then the reference's update
+    auto step = [&](float da, uint32_t qwd, int l) {
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            const uint8_t *xb = lds + (size_t)(c * nblocks + l) * X80_BLK;
+            const float a = da * *(const float *)(xb + 32);
+            const float bq = (float)sdot4(qwd, *(const uint32_t *)(xb + 4 * j), 0);
+            if constexpr (MODE == 0) {
+                Cv[c] = __builtin_fmaf(a, bq, Cv[c]);
+            } else if constexpr (MODE == 1) {
+                const float y = __builtin_fmaf(a, bq, -Ce[c]);
+                const float t = Cv[c] + y;
+                Ce[c] = (t - Cv[c]) - y;
+                Cv[c] = t;
+            } else { // branch-free select so the loads of later blocks are scheduled ahead of the f32 chain
+                const float plain = __builtin_fmaf(a, bq, Cv[c]);
+                const float y = __builtin_fmaf(a, bq, -Ce[c]);
+                const float t = Cv[c] + y;
+                const float e2 = (t - Cv[c]) - y;
+                Cv[c] = kahan[c] ? t : plain;
+                Ce[c] = kahan[c] ? e2 : 0.0f;
+            }
+        }
+    };
+
+    // Blocks past the row (zero padding of the last quad, zero-filled prefetch slots) must NOT run: a Kahan
+    // step with a*b = 0 still folds the pending compensation into the sum.  Full quads run unguarded.
+    const int nq_full = nblocks >> 2;
     for (int L0 = 0; L0 < nquads; L0 += Q80_DEPTH) {
 #pragma unroll
         for (int s = 0; s < Q80_DEPTH; s++) {
             const int L = L0 + s;
-            if (L < nquads) {
-                const uint4 q4 = qa[s];
-                const uint2 d2 = ds[s];
-                // refill this slot with the quad DEPTH ahead
-                if (L + Q80_DEPTH < nquads) {
-                    qa[s] = ld_nt16(tile0 + (size_t)(L + Q80_DEPTH) * P80_TILE + lane * 16);
-                    ds[s] = *(const uint2 *)(tile0 + (size_t)(L + Q80_DEPTH) * P80_TILE + P80_D + r * 8);
-                }
-                const uint32_t qw[4] = {q4.x, q4.y, q4.z, q4.w};
-                const float da[4] = {h2f((uint16_t)(d2.x & 0xffff)), h2f((uint16_t)(d2.x >> 16)),
-                                     h2f((uint16_t)(d2.y & 0xffff)), h2f((uint16_t)(d2.y >> 16))};
+            const uint4 q4 = qa[s];
+            const uint2 d2 = ds[s];
+            issue(s, L + Q80_DEPTH); // refill this slot (past the end: zeros, no traffic)
+            const uint32_t qw[4] = {q4.x, q4.y, q4.z, q4.w};
+            const float da[4] = {h2f((uint16_t)(d2.x & 0xffff)), h2f((uint16_t)(d2.x >> 16)), h2f((uint16_t)(d2.y & 0xffff)),
+                                 h2f((uint16_t)(d2.y >> 16))};
+            if (L < nq_full) {
 #pragma unroll
-                for (int dd = 0; dd < 4; dd++) {
-                    const int l = 4 * L + dd;
-                    if (l < nblocks) {
+                for (int dd = 0; dd < 4; dd++)
+                    step(da[dd], qw[dd], 4 * L + dd);
+            } else if (L == nq_full) {
 #pragma unroll
-                        for (int c = 0; c < NC; c++) {
-                            const uint8_t *xb = lds + (size_t)(c * nblocks + l) * X80_BLK;
-                            const float a = da[dd] * *(const float *)(xb + 32);
-                            const float bq = (float)sdot4(qw[dd], *(const uint32_t *)(xb + 4 * j), 0);
-                            if (kahan[c]) {
-                                const float y = __builtin_fmaf(a, bq, -Ce[c]);
-                                const float t = Cv[c] + y;
-                                Ce[c] = (t - Cv[c]) - y;
-                                Cv[c] = t;
-                            } else {
-                                Cv[c] = __builtin_fmaf(a, bq, Cv[c]);
-                            }
-                        }
-                    }
-                }
+                for (int dd = 0; dd < 3; dd++)
+                    if (4 * L + dd < nblocks)
+                        step(da[dd], qw[dd], 4 * L + dd);
             }
         }
     }
@@ -536,6 +561,8 @@ __global__ __launch_bounds__(64) void gemv_q80_kernel(const uint8_t *__restrict_
             C[(col0 + c) * ldc + row] = v;
     }
 }
+
+// ---------------------------------------------------------------------------------------------
 
 // ---------------------------------------------------------------------------------------------
 
@@ -601,15 +628,27 @@ static hipError_t launch_q80(const void *A, long m, long n_total, long k, const 
                              long ldc, int vregs32, int precise, hipStream_t s) {
     int nblocks = (int)(k / 32), nquads = (nblocks + 3) / 4;
     size_t smem = (size_t)NC * nblocks * X80_BLK;
-    if (smem > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)gemv_q80_kernel<NC, BT>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess)
-            return e;
-    }
-    unsigned grid = (unsigned)((m + 7) / 8);
-    gemv_q80_kernel<NC, BT><<<grid, 64, smem, s>>>((const uint8_t *)A, m, n_total, nblocks, nquads, (const uint8_t *)B,
-                                                    brb, col0, C, ldc, vregs32, precise);
+    unsigned grid = (unsigned)(((m + 7) / 8 + Q80_WAVES - 1) / Q80_WAVES);
+    // n = 1: the whole problem is one column of 2x1 / 1x1 tiles, so the summation mode is uniform
+    const int mode = n_total == 1 ? ((vregs32 || precise) ? 1 : 0) : 2;
+#define Q80_GO(MODE)                                                                                                   \
+    do {                                                                                                               \
+        auto kernel = gemv_q80_kernel<NC, BT, MODE>;                                                                   \
+        if (smem > 64 * 1024) {                                                                                        \
+            hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+            if (e != hipSuccess)                                                                                       \
+                return e;                                                                                              \
+        }                                                                                                              \
+        kernel<<<grid, Q80_WAVES * 64, smem, s>>>((const uint8_t *)A, m, n_total, nblocks, nquads, (const uint8_t *)B, brb, \
+                                                  col0, C, ldc, vregs32, precise);                                     \
+    } while (0)
+    if (mode == 0)
+        Q80_GO(0);
+    else if (mode == 1)
+        Q80_GO(1);
+    else
+        Q80_GO(2);
+#undef Q80_GO
     return hipGetLastError();
 }
 
