@@ -45,6 +45,8 @@ def parse():
     p.add_argument("--decode", type=int, default=128)
     p.add_argument("--no-graph", action="store_true")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--force-dist", action="store_true",
+                   help="rehearsal: initialise the process group and issue the collectives even at world size 1")
     p.add_argument("--model", default="llama3-8b-q4_k_m", choices=["llama3-8b-q4_k_m", "llama3-8b-q8_0"])
     return p.parse_args()
 
@@ -56,9 +58,10 @@ class Op:
 class Runner:
     """Holds the sharded weights and pre-allocated buffers; runs one pass of all mat-muls at batch n."""
 
-    def __init__(self, layers, rank, world, batches, dev):
+    def __init__(self, layers, rank, world, batches, dev, collectives=False):
         self.L = _hip.lib()
         self.rank, self.world, self.dev = rank, world, dev
+        self.collectives = collectives
         self.flags = sgemm.host_variant_flags()
         self.layers = []
         seed = 0x5EED0000
@@ -98,10 +101,10 @@ class Runner:
                         b["xq"][key] = torch.empty((n, T.row_size(vdt, o.k)), dtype=torch.uint8, device=dev)
                     ws = max(ws, sgemm.workspace_bytes(o.spec.type, o.m, o.k, n))
             b["ws"] = torch.empty(ws, dtype=torch.uint8, device=dev)
-            if world > 1:
+            if collectives:
                 vm = [o for ops in self.layers for o in ops if o.spec.shard == "vocab"]
                 if vm:
-                    b["gather"] = torch.empty((world, n, vm[0].m), dtype=torch.float32, device=dev)
+                    b["gather"] = [torch.empty((n, vm[0].m), dtype=torch.float32, device=dev) for _ in range(world)]
             self.buf[n] = b
 
     def weight_bytes(self):
@@ -162,12 +165,12 @@ class Runner:
                 _hip.check(rc, "mul_mat_multi " + o0.spec.name)
             launches += 1 if n <= 8 else len(g)
             nops += len(g)
-            if only_type is None and self.world > 1:
+            if only_type is None and self.collectives:
                 for o, out in zip(g, outs):
                     if o.spec.shard == "cols":
                         torch.distributed.all_reduce(out)
                     elif o.spec.shard == "vocab":
-                        torch.distributed.all_gather_into_tensor(b["gather"], out)
+                        torch.distributed.all_gather(b["gather"], out)
         return launches, nops
 
 
@@ -223,32 +226,57 @@ def main():
     if a.gpus != world and world == 1 and a.gpus > 1:
         print("bench.py: --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)", file=sys.stderr)
         sys.exit(2)
+    # one rank per GPU (the driver's launch); for a rehearsal on a 1-GPU box ranks may share device 0 with
+    # LFAMD_DIST_BACKEND=gloo (RCCL refuses two ranks on one device)
+    local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     sgemm.init(local)
-    if world > 1:
+    dist_on = world > 1 or a.force_dist
+    if dist_on:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.distributed.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        backend = os.environ.get("LFAMD_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        else:
+            torch.distributed.init_process_group(backend, rank=rank, world_size=world)
 
     layers = LS.llama3_8b_q4_k_m() if a.model == "llama3-8b-q4_k_m" else LS.llama3_8b_q8_0()
-    runner = Runner(layers, rank, world, (a.prefill, 1), dev)
+    runner = Runner(layers, rank, world, (a.prefill, 1), dev, collectives=dist_on)
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    use_graph = not a.no_graph and world == 1
+    # hipGraph capture of a whole pass (kernels + RCCL collectives).  If capturing the collectives is not
+    # possible on this stack, fall back to eager launches rather than fail.
+    use_graph = not a.no_graph
     graphs = {}
     if use_graph:
-        for n in (a.prefill, 1):
-            runner.run_pass(n)  # warm (also sets any kernel attributes before capture)
+        try:
+            for n in (a.prefill, 1):
+                runner.run_pass(n)  # warm (also sets any kernel attributes before capture)
+                barrier()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    runner.run_pass(n)
+                graphs[n] = g
+            barrier()
+            for n in (a.prefill, 1):
+                graphs[n].replay()
+            barrier()
+        except Exception as e:  # noqa: BLE001
+            if rank == 0:
+                print(f"bench.py: graph capture unavailable ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            graphs = {}
+            use_graph = False
             torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                runner.run_pass(n)
-            graphs[n] = g
 
     def one_pass(n):
         if use_graph:
@@ -269,7 +297,7 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -324,7 +352,7 @@ def main():
                          "shape": [o.m, o.k, a.prefill], "avg_launch_us": round(gus, 2)}
 
     if rank != 0:
-        if world > 1:
+        if dist_on:
             torch.distributed.destroy_process_group()
         return
 
@@ -363,7 +391,7 @@ def main():
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         torch.distributed.destroy_process_group()
 
 
