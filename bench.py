@@ -334,9 +334,21 @@ def main():
     alg_bytes = sum(sum(o.m * T.row_size(dom_type, o.k) + o.m * 4 for o in g) + g[0].k * 4 for g in groups)
     avg_bytes = alg_bytes / launches_per_pass
     achieved = avg_bytes / (avg_us * 1e-6) / 1e9
+    # HBM traffic per launch: from the rocprofv3 PMC passes of this same workload (tools/profile_round.sh:
+    # FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM), stored
+    # under profiles/ — counters cannot be read from inside this process
+    traffic, traffic_src = None, None
+    tfile = os.path.join(ROOT, "profiles", "r01_v2_pmc_traffic.json")
+    if dom_type == T.Q4_K and world == 1 and os.path.exists(tfile):
+        try:
+            traffic = json.load(open(tfile))["gemv_q4k"]["hbm_bytes_per_launch"]
+            traffic_src = "profiles/r01_v2_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2)"
+        except (KeyError, ValueError):
+            pass
+    kname = "gemv_kq_kernel<q4k_traits, 1, F32, 16, {1,2}>" if dom_type == T.Q4_K else "gemv_q80_kernel<1, F32, mode>"
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                "kernel": f"gemv_{T.NAMES[dom_type].lower()}_kernel<1>", "launches_per_pass": launches_per_pass, "mat_muls_per_pass": len(dom_ops),
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "kernel": kname, "launches_per_pass": launches_per_pass, "mat_muls_per_pass": len(dom_ops),
                 "avg_launch_us": round(avg_us, 3), "algorithmic_bytes_per_launch": int(avg_bytes)}
 
     # ---- secondary: the prefill GEMM at the north-star shape (4096 x 4096 x 512, 1 GPU shapes only)
