@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-HIP_SO = os.path.join(_HERE, "libllamafile_amd_hip.so")
+HIP_SO = os.environ.get("LFAMD_HIP_SO") or os.path.join(_HERE, "libllamafile_amd_hip.so")  # override: development builds
 HOST_SO = os.path.join(_HERE, "libllamafile_sgemm.so")
 
 FLAG_Q0_VREGS32 = 1

@@ -23,6 +23,9 @@
 // barrier per super-block; the two partial accumulators meet in LDS at the end.  Tiles are assigned to
 // work-groups XCD-aware so an XCD's work-groups share a token tile.
 #include "lfamd_device.h"
+#ifndef GEMM_DIAG
+#define GEMM_DIAG 0
+#endif
 
 #include <stdlib.h>
 
@@ -51,14 +54,22 @@ union frag_u {
 
 // One K-step (8 nibbles of this lane) of a Q4_K-family dword -> f16x8 of sc*q.
 // S = (sc,sc), O = (-1024 sc), S16 = sc/16, O16 = -64 sc.
-__device__ static inline half8_t dequant_q4(uint32_t x, half2_t S, half2_t O, half2_t S16, half2_t O16) {
+// `magic` = 0x64006400 held in a VGPR: gfx9 VOP3 encodes one literal/SGPR only, so with both constants as
+// literals hipcc splits (x & m) | magic into v_and + v_or; with the magic in a register it is one v_and_or_b32.
+__device__ static inline half8_t dequant_q4(uint32_t x, half2_t S, half2_t O, half2_t S16, half2_t O16, uint32_t magic) {
     frag_u f;
     const uint32_t y = x >> 8;
-    f.p[0] = pk_fma(as_half2((x & 0x000F000Fu) | 0x64006400u), S, O);
-    f.p[1] = pk_fma(as_half2((x & 0x00F000F0u) | 0x64006400u), S16, O16);
-    f.p[2] = pk_fma(as_half2((y & 0x000F000Fu) | 0x64006400u), S, O);
-    f.p[3] = pk_fma(as_half2((y & 0x00F000F0u) | 0x64006400u), S16, O16);
+    f.p[0] = pk_fma(as_half2((x & 0x000F000Fu) | magic), S, O);
+    f.p[1] = pk_fma(as_half2((x & 0x00F000F0u) | magic), S16, O16);
+    f.p[2] = pk_fma(as_half2((y & 0x000F000Fu) | magic), S, O);
+    f.p[3] = pk_fma(as_half2((y & 0x00F000F0u) | magic), S16, O16);
     return f.v;
+}
+
+__device__ static inline uint32_t opaque_magic() {
+    uint32_t magic = 0x64006400u;
+    asm volatile("" : "+v"(magic)); // keep it a register value (see dequant_q4)
+    return magic;
 }
 
 // Q6_K: codes are 6 bit (ql nibble | qh field), value sc*(code-32).  (code-32) is formed exactly,
@@ -96,6 +107,24 @@ struct sregs { // per-super-block activation-side scales
 
 #define GEMM_KG 2 // K-groups per work-group (intra-work-group split-K)
 
+// Linear tile order -> (row-block, token tile).  Tiles are walked in SUPER-TILES of 8 row-blocks x 4 token tiles
+// (ragged at the edges): an XCD's 32 resident work-groups then share 8 x 128 weight rows (8 x 72 B/row/256k) and
+// 4 x 64 activation rows in its L2, instead of each XCD streaming every weight row (measured: 6x the algorithmic
+// HBM bytes with the row-blocks-fastest order).  72a + 128b bytes per K element is minimal at a x b = 8 x 4.
+__device__ static inline void tile_of(int L, int n_rb, int n_tt, int &rb, int &tt) {
+    constexpr int SA = 8, SB = 4;
+    const int grp = n_rb * SB;                    // tiles in one group of SB token tiles
+    const int g = L / grp;
+    const int idx = L - g * grp;
+    const int w = min(SB, n_tt - g * SB);         // token tiles in this group (last group may be narrower)
+    const int run = idx / (SA * w);
+    const int rem = idx - run * SA * w;
+    const int hgt = min(SA, n_rb - run * SA);     // row-blocks in this run (last run may be shorter)
+    const int tl = rem / hgt;
+    rb = run * SA + (rem - tl * hgt);
+    tt = g * SB + tl;
+}
+
 template <int TYPE>
 __global__ __launch_bounds__(512) void gemm_kq_kernel(const uint8_t *__restrict__ A, long m, int nb,
                                                       const _Float16 *__restrict__ Xh, const float *__restrict__ d8T,
@@ -114,7 +143,8 @@ __global__ __launch_bounds__(512) void gemm_kq_kernel(const uint8_t *__restrict_
     // share a token tile (512 KiB of activation codes stays in that XCD's L2) and stream distinct weights.
     const int id = blockIdx.x, q8 = n_wg >> 3, r8 = n_wg & 7, xcd = id & 7;
     const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3);
-    const int tt = L / n_rb, rb = L - tt * n_rb;
+    int tt, rb;
+    tile_of(L, n_rb, n_wg / n_rb, rb, tt);
 
     const long n_row_tiles = (m + 31) / 32;
     const long rt = (long)rb * 4 + rw;
@@ -129,6 +159,10 @@ __global__ __launch_bounds__(512) void gemm_kq_kernel(const uint8_t *__restrict_
     // (global_load_lds, the XOR swizzle applied on the SOURCE address since the LDS side is lane-linear),
     // weights to VGPRs
     auto prefetch = [&](int it, wregs<TYPE> &w) {
+#if GEMM_DIAG == 2 // development: compute chain only (operands loaded once)
+        if (it > 1)
+            return;
+#endif
         const int b = it * GEMM_KG + kg;
         uint8_t *dst = xt[kg][it & 1];
 #pragma unroll
@@ -190,14 +224,22 @@ __global__ __launch_bounds__(512) void gemm_kq_kernel(const uint8_t *__restrict_
         for (int r = 0; r < 16; r++)
             acc[nt][r] = 0.0f;
 
+    // byte offset of this lane's fragment chunk inside the tile: row i, chunk (c ^ (i & 15)) with c = 2t + h.
+    // c & 15 takes 8 values per lane (t & 7); bit 4 of c and the token tile are immediates.
+    uint32_t xoff[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+        xoff[u] = (uint32_t)(i * XT_ROW_BYTES + ((((2 * u + h) & 15) ^ (i & 15)) * 16));
+    const float16_t_ zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const uint32_t magic = opaque_magic();
+
     auto compute = [&](int it, const wregs<TYPE> &w, const sregs &sr) {
+#if GEMM_DIAG == 1 // development: memory + barrier chain only
+        acc[0][0] += (float)(w.qs[0].x ^ w.qs[1].y ^ w.qs[2].z ^ w.qs[3].w ^ w.hd.x) + sr.d8[0][0][0] + sr.d8[1][3][3];
+        return;
+#endif
         const uint8_t *xb = xt[kg][it & 1];
-        float16_t_ tmp[2];
-#pragma unroll
-        for (int nt = 0; nt < 2; nt++)
-#pragma unroll
-            for (int r = 0; r < 16; r++)
-                tmp[nt][r] = 0.0f;
+        float16_t_ tmp[2]; // first K-step accumulates onto the constant 0 (an inline operand, no register init)
         const uint32_t qw[16] = {w.qs[0].x, w.qs[0].y, w.qs[0].z, w.qs[0].w, w.qs[1].x, w.qs[1].y, w.qs[1].z, w.qs[1].w,
                                  w.qs[2].x, w.qs[2].y, w.qs[2].z, w.qs[2].w, w.qs[3].x, w.qs[3].y, w.qs[3].z, w.qs[3].w};
         if constexpr (TYPE == LFAMD_TYPE_Q4_K) {
@@ -213,12 +255,11 @@ __global__ __launch_bounds__(512) void gemm_kq_kernel(const uint8_t *__restrict_
 #pragma unroll
                 for (int e = 0; e < 2; e++) {
                     const int t = 2 * j + e;
-                    const half8_t wf = dequant_q4(qw[t], S, O, S16, O16);
+                    const half8_t wf = dequant_q4(qw[t], S, O, S16, O16, magic);
 #pragma unroll
                     for (int nt = 0; nt < 2; nt++) {
-                        const int c = 2 * t + h;
-                        const half8_t xf = *(const half8_t *)(xb + (nt * 32 + i) * XT_ROW_BYTES + ((c ^ (i & 15)) * 16));
-                        tmp[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xf, wf, tmp[nt], 0, 0, 0);
+                        const half8_t xf = *(const half8_t *)(xb + xoff[t & 7] + nt * 32 * XT_ROW_BYTES + ((2 * t) & 16) * 16);
+                        tmp[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xf, wf, t == 0 ? zero16 : tmp[nt], 0, 0, 0);
                     }
                 }
             }
@@ -234,11 +275,7 @@ __global__ __launch_bounds__(512) void gemm_kq_kernel(const uint8_t *__restrict_
             }
 #pragma unroll
             for (int nt = 0; nt < 2; nt++) {
-                float16_t_ tm;
-#pragma unroll
-                for (int r = 0; r < 16; r++)
-                    tm[r] = 0.0f;
-                tm = __builtin_amdgcn_mfma_f32_32x32x16_f16(sr.xm[nt], wm.v, tm, 0, 0, 0);
+                const float16_t_ tm = __builtin_amdgcn_mfma_f32_32x32x16_f16(sr.xm[nt], wm.v, zero16, 0, 0, 0);
                 // ---- per-super-block scaling: acc += d8[n] * (d * tmp - dmin * tm)
 #pragma unroll
                 for (int r4 = 0; r4 < 4; r4++)
@@ -263,9 +300,8 @@ __global__ __launch_bounds__(512) void gemm_kq_kernel(const uint8_t *__restrict_
                 const half8_t wf = dequant_q6(qw[t], H, S);
 #pragma unroll
                 for (int nt = 0; nt < 2; nt++) {
-                    const int c = 2 * t + h;
-                    const half8_t xf = *(const half8_t *)(xb + (nt * 32 + i) * XT_ROW_BYTES + ((c ^ (i & 15)) * 16));
-                    tmp[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xf, wf, tmp[nt], 0, 0, 0);
+                    const half8_t xf = *(const half8_t *)(xb + xoff[t & 7] + nt * 32 * XT_ROW_BYTES + ((2 * t) & 16) * 16);
+                    tmp[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xf, wf, t == 0 ? zero16 : tmp[nt], 0, 0, 0);
                 }
             }
 #pragma unroll
@@ -391,7 +427,8 @@ __global__ __launch_bounds__(256) void gemm_q4k_lds3_kernel(const uint8_t *__res
     // XCD-aware tile assignment (see gemm_kq_kernel)
     const int id = blockIdx.x, q8 = n_wg >> 3, r8 = n_wg & 7, xcd = id & 7;
     const int Lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3);
-    const int tt = Lin / n_rb, rb = Lin - tt * n_rb;
+    int tt, rb;
+    tile_of(Lin, n_rb, n_wg / n_rb, rb, tt);
 
     const long n_row_tiles = (m + 31) / 32;
     const long rt = (long)rb * 4 + wave;
@@ -446,6 +483,7 @@ __global__ __launch_bounds__(256) void gemm_q4k_lds3_kernel(const uint8_t *__res
 #pragma unroll
     for (int u = 0; u < 8; u++)
         xoff[u] = (uint32_t)(i * XT_ROW_BYTES + ((((2 * u + h) & 15) ^ (i & 15)) * 16));
+    const uint32_t magic = opaque_magic();
 
     auto compute = [&](const uint8_t *st) {
         const uint8_t *xb = st + G3_X;
@@ -473,7 +511,7 @@ __global__ __launch_bounds__(256) void gemm_q4k_lds3_kernel(const uint8_t *__res
 #pragma unroll
                 for (int e = 0; e < 2; e++) {
                     const int t = 4 * g + 2 * e2 + e;
-                    const half8_t wf = dequant_q4(qw[2 * e2 + e], S, O, S16, O16);
+                    const half8_t wf = dequant_q4(qw[2 * e2 + e], S, O, S16, O16, magic);
                     // chunk c = 2t + h: bit 4 of c is an immediate (256 B), the low 4 bits come from xoff
 #pragma unroll
                     for (int nt = 0; nt < 2; nt++) {

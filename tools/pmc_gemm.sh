@@ -2,12 +2,13 @@
 # development helper: PMC counters for the prefill GEMM kernel (rocprofv3, counters only)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/pmc_gemm; mkdir -p $OUT
-rocprofv3 -L 2>/dev/null | grep -oE "(SQ_[A-Z_0-9]+|TCC_[A-Z_0-9]+|TCP_[A-Z_0-9]+|GRBM_[A-Z_0-9]+|FETCH_SIZE|WRITE_SIZE|MfmaUtil|VALUBusy|LDSBankConflict)" | sort -u > $OUT/counters.txt
-wc -l $OUT/counters.txt
-CASE="Q4_K,4096,4096,512"
-for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_MFMA" "SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU" "GRBM_GUI_ACTIVE FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; do
+CASE="${1:-Q4_K,4096,4096,512}"
+SETS_FROM=${2:-0}; n=0
+for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_MFMA" "SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU" "GRBM_GUI_ACTIVE FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "TCC_REQ_sum TCC_EA0_RDREQ_sum" "TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum"; do
+  n=$((n+1)); [ $n -le $SETS_FROM ] && continue
   tag=$(echo $set | cut -d' ' -f1)
-  rocprofv3 --pmc $set --output-format csv -d $OUT/$tag -- python3 tools/kbench.py --cases $CASE --iters 2 --copies 4 > $OUT/$tag.log 2>&1
+  echo "== $set"
+  timeout -k 10 100 rocprofv3 --pmc $set --output-format csv -d $OUT/$tag -- python3 tools/kbench.py --cases $CASE --iters 2 --copies 4 > $OUT/$tag.log 2>&1 || { echo "set failed: $set"; continue; }
   f=$(find $OUT/$tag -name "*counter_collection.csv" | head -1)
   python3 - "$f" <<'PY'
 import csv, sys, collections
