@@ -21,6 +21,8 @@ hipError_t lfamd_launch_gemv(int, const void *, long, long, int, const void *, s
                              hipStream_t);
 hipError_t lfamd_launch_gemv_multi(int, int, const void *const *, const long *, long, int, const void *, size_t, long,
                                    float *const *, const long *, int, int, hipStream_t);
+hipError_t lfamd_launch_gemm_wide(int, const void *, long, long, const void *, const void *, const void *, long, long,
+                                  float *, long, hipStream_t);
 hipError_t lfamd_launch_gemm_kq(int, const void *, long, long, const void *, const void *, const void *, long, long,
                                 float *, long, hipStream_t);
 hipError_t lfamd_launch_quantize(int, const float *, long, long, size_t, void *, size_t, hipStream_t);
@@ -212,7 +214,7 @@ size_t lfamd_mul_mat_workspace(int Atype, long m, long k, long n) {
     if (use_gemv(Atype, n, 0) && gemv_quantise_separately(Atype, m))
         return align_up((size_t)n * lfamd_row_size(lfamd_vec_dot_type(Atype), k), 256);
     if (use_gemm(Atype, n, 0)) {
-        size_t n_pad = align_up((size_t)n, 64), nb = (size_t)(k / 256);
+        size_t n_pad = align_up((size_t)n, 128), nb = (size_t)(k / 256);
         return align_up(n_pad * (size_t)k * 2, 256) + align_up(nb * n_pad * 4, 256) + align_up(n_pad * nb * 32, 256);
     }
     if (use_gemv(Atype, n, 0) || !type_known(Atype) || lfamd_blck_size(Atype) == 1)
@@ -247,7 +249,7 @@ int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const v
         size_t need = lfamd_mul_mat_workspace(Atype, m, k, n);
         if (ws_bytes < need || !d_ws)
             return fail(LFAMD_ERR_WORKSPACE, "mul_mat: workspace too small%s", "");
-        size_t n_pad = align_up((size_t)n, 64), nb = (size_t)(k / 256);
+        size_t n_pad = align_up((size_t)n, 128), nb = (size_t)(k / 256);
         uint8_t *ws = (uint8_t *)d_ws;
         void *Xh = ws;
         void *d8T = ws + align_up(n_pad * (size_t)k * 2, 256);
@@ -256,7 +258,15 @@ int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const v
             HIPCHK(lfamd_launch_prep_f32(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, s), "prep_f32");
         else
             HIPCHK(lfamd_launch_prep_q8k(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, s), "prep_q8k");
-        HIPCHK(lfamd_launch_gemm_kq(Atype, d_A, m, k, Xh, d8T, Xm, n, (long)n_pad, d_C, ldc, s), "gemm_kq");
+        // two bodies: 128 x 128 tiles, K streamed once (gemm_wide.hip) when that grid fills the 256 CUs; the
+        // 128 x 64 split-K body (gemm_mfma.hip) for smaller grids.  LFAMD_GEMM_BODY=narrow|wide forces one.
+        static const char *body = getenv("LFAMD_GEMM_BODY");
+        const long tiles128 = ((m + 127) / 128) * (long)(n_pad / 128);
+        const bool narrow = body ? body[0] == 'n' : tiles128 < 192;
+        if (narrow)
+            HIPCHK(lfamd_launch_gemm_kq(Atype, d_A, m, k, Xh, d8T, Xm, n, (long)n_pad, d_C, ldc, s), "gemm_kq");
+        else
+            HIPCHK(lfamd_launch_gemm_wide(Atype, d_A, m, k, Xh, d8T, Xm, n, (long)n_pad, d_C, ldc, s), "gemm_wide");
         return LFAMD_OK;
     }
     if (use_gemv(Atype, n, flags)) {

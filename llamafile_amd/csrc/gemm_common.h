@@ -1,0 +1,84 @@
+// gemm_common.h — pieces shared by the MFMA GEMM kernels (gemm_mfma.hip, gemm_wide.hip): exact-integer
+// dequantisation of packed K-quant dwords into f16 MFMA fragments, and the XCD-aware tile order.
+#pragma once
+#include "lfamd_device.h"
+
+#define XT_ROW_BYTES 512 // 256 f16 codes of one token for one super-block
+
+__device__ static inline half2_t as_half2(uint32_t u) {
+    return __builtin_bit_cast(half2_t, u);
+}
+
+__device__ static inline half2_t pk_fma(half2_t a, half2_t b, half2_t c) {
+    return __builtin_elementwise_fma(a, b, c);
+}
+
+__device__ static inline half2_t bcast_h2(float v) {
+    _Float16 h = (_Float16)v;
+    half2_t r = {h, h};
+    return r;
+}
+
+union frag_u {
+    half8_t v;
+    half2_t p[4];
+    uint4 u;
+};
+
+// One K-step (8 nibbles of this lane) of a Q4_K-family dword -> f16x8 of sc*q.
+// S = (sc,sc), O = (-1024 sc), S16 = sc/16, O16 = -64 sc.
+// `magic` = 0x64006400 held in a VGPR: gfx9 VOP3 encodes one literal/SGPR only, so with both constants as
+// literals hipcc splits (x & m) | magic into v_and + v_or; with the magic in a register it is one v_and_or_b32.
+__device__ static inline half8_t dequant_q4(uint32_t x, half2_t S, half2_t O, half2_t S16, half2_t O16, uint32_t magic) {
+    frag_u f;
+    const uint32_t y = x >> 8;
+    f.p[0] = pk_fma(as_half2((x & 0x000F000Fu) | magic), S, O);
+    f.p[1] = pk_fma(as_half2((x & 0x00F000F0u) | magic), S16, O16);
+    f.p[2] = pk_fma(as_half2((y & 0x000F000Fu) | magic), S, O);
+    f.p[3] = pk_fma(as_half2((y & 0x00F000F0u) | magic), S16, O16);
+    return f.v;
+}
+
+__device__ static inline uint32_t opaque_magic() {
+    uint32_t magic = 0x64006400u;
+    asm volatile("" : "+v"(magic)); // keep it a register value (see dequant_q4)
+    return magic;
+}
+
+// Q6_K: codes are 6 bit (ql nibble | qh field), value sc*(code-32).  (code-32) is formed exactly,
+// the product with the int8 scale is rounded to f16 (exact up to 2048; RNE to even above).
+__device__ static inline half8_t dequant_q6(uint32_t x, uint32_t H, half2_t S) {
+    frag_u f;
+    const uint32_t y = x >> 8;
+    const half2_t m1056 = {(_Float16)-1056.0f, (_Float16)-1056.0f};
+    const half2_t m96 = {(_Float16)-96.0f, (_Float16)-96.0f};
+    const half2_t r16 = {(_Float16)0.0625f, (_Float16)0.0625f};
+    half2_t c0 = as_half2((x & 0x000F000Fu) | (H & 0x00300030u) | 0x64006400u) + m1056;
+    half2_t c1 = pk_fma(as_half2((x & 0x00F000F0u) | (H & 0x03000300u) | 0x64006400u), r16, m96);
+    half2_t c2 = as_half2((y & 0x000F000Fu) | ((H >> 8) & 0x00300030u) | 0x64006400u) + m1056;
+    half2_t c3 = pk_fma(as_half2((y & 0x00F000F0u) | ((H << 8) & 0x03000300u) | 0x64006400u), r16, m96);
+    f.p[0] = c0 * S;
+    f.p[1] = c1 * S;
+    f.p[2] = c2 * S;
+    f.p[3] = c3 * S;
+    return f.v;
+}
+
+// Linear tile order -> (row-block, token tile).  Tiles are walked in SUPER-TILES of 8 row-blocks x 4 token tiles
+// (ragged at the edges): an XCD's 32 resident work-groups then share 8 x 128 weight rows (8 x 72 B/row/256k) and
+// 4 x 64 activation rows in its L2, instead of each XCD streaming every weight row (measured: 6x the algorithmic
+// HBM bytes with the row-blocks-fastest order).  72a + 128b bytes per K element is minimal at a x b = 8 x 4.
+__device__ static inline void tile_of(int L, int n_rb, int n_tt, int &rb, int &tt) {
+    constexpr int SA = 8, SB = 4;
+    const int grp = n_rb * SB;                    // tiles in one group of SB token tiles
+    const int g = L / grp;
+    const int idx = L - g * grp;
+    const int w = min(SB, n_tt - g * SB);         // token tiles in this group (last group may be narrower)
+    const int run = idx / (SA * w);
+    const int rem = idx - run * SA * w;
+    const int hgt = min(SA, n_rb - run * SA);     // row-blocks in this run (last run may be shorter)
+    const int tl = rem / hgt;
+    rb = run * SA + (rem - tl * hgt);
+    tt = g * SB + tl;
+}
+

@@ -1,0 +1,462 @@
+// gemm_wide.hip — prefill GEMM, "wide" body: 128 x 128 output tile per work-group, K streamed once.
+//
+// Same arithmetic as gemm_mfma.hip (exact integer codes on v_mfma_f32_32x32x16_f16, the two f32 scales applied
+// once per super-block; reference: mul_mat_qX_K_q8_K_T, iqk_mul_mat.inc:601-643), different shape of the work:
+//
+//   * work-group = 8 waves = 4 row tiles x 2 column halves on a 128-row x 128-token output tile, full K per
+//     wave (no intra-work-group split-K, no LDS combine, ONE barrier per super-block).  Two waves per SIMD: the
+//     LDS-DMA / ds_read issue of one wave overlaps the MFMA + VALU stream of the other (a 4-wave, one-wave-per-
+//     SIMD variant with 32 x 128 per wave was issue-bound: every LDS-DMA piece blocks the only wave 60-180 cycles).
+//   * K is split across work-groups (KS = 1, 2, 4 ...) when the tile grid alone cannot fill 256 CUs; partial
+//     tiles meet in C with f32 atomic adds onto zeros (the activation-prep kernel zeroes C).  With KS = 2 the
+//     result is deterministic (0 + a + b, and a + b commutes), so KS is capped at 2.
+//   * all loads are issued in inline asm (LDS-DMA for the activation tile / d8 / mins operand, global_load
+//     with an SGPR base for the weights), one super-block ahead, and retired by ONE s_waitcnt vmcnt(0) +
+//     s_barrier per super-block: hipcc's waitcnt pass cannot count LDS-DMA and otherwise drains the prefetch
+//     in the middle of the MFMA phase (cdna_hip_programming.md §5.7).  Per-lane source offsets are loop
+//     invariant (16 VGPRs); the super-block advance is an SGPR add — no VALU address arithmetic in the loop.
+#include "gemm_common.h"
+#include <type_traits>
+#ifndef GEMM_DIAG
+#define GEMM_DIAG 0
+#endif
+
+#define WD_COLS 128
+#define WD_XSTAGE (WD_COLS * XT_ROW_BYTES) // 64 KiB of f16 codes per super-block
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <int TYPE>
+struct wide_w {
+    u32x4 qs[4];
+    u32x4 hd;    // Q4_K: {d, dmin, scales[12]};  Q6_K: 16 int8 scales
+    u32x4 qh[2]; // Q6_K only
+    uint32_t dw; // Q6_K only (f16 bits)
+};
+
+template <int IMM>
+__device__ static inline void gload16(u32x4 &dst, const void *base, uint32_t voff) {
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(base), "n"(IMM) : "memory");
+}
+template <int IMM>
+__device__ static inline void gload2(uint32_t &dst, const void *base, uint32_t voff) {
+    asm volatile("s_nop 4\n\tglobal_load_ushort %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(base), "n"(IMM) : "memory");
+}
+
+// four LDS-DMA pieces (1 KiB each) to consecutive LDS slots from one SGPR base + per-lane offsets
+__device__ static inline void glds4(const void *base, uint32_t lds_dst, uint32_t o0, uint32_t o1, uint32_t o2, uint32_t o3) {
+    uint32_t keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %5\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %5\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(base), "s"(lds_dst)
+                 : "memory", "scc");
+}
+__device__ static inline void glds1x16(const void *base, uint32_t lds_dst, uint32_t o0) {
+    uint32_t keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(o0), "s"(base), "s"(lds_dst)
+                 : "memory");
+}
+__device__ static inline void glds1x4(const void *base, uint32_t lds_dst, uint32_t o0) {
+    uint32_t keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(o0), "s"(base), "s"(lds_dst)
+                 : "memory");
+}
+
+// make a wave-uniform pointer provably so (an "s" operand must be), via two v_readfirstlane
+__device__ static inline const uint8_t *uniform_ptr(const void *p) {
+    const uint64_t v = (uint64_t)(uintptr_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return (const uint8_t *)(uintptr_t)(((uint64_t)hi << 32) | lo);
+}
+
+// LDS fragment read hipcc neither counts nor moves: the K loop below keeps the next K-step's four fragments in
+// flight under the current step's MFMAs and waits with a counted lgkmcnt (left to itself hipcc reuses ONE
+// fragment register and waits lgkmcnt(0) in front of every MFMA — the whole LDS latency, 64 times per super-block)
+template <int IMM>
+__device__ static inline void dsr16(half8_t &dst, uint32_t addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(IMM));
+}
+template <int N>
+__device__ static inline void ds_wait(half8_t &a, half8_t &b) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
+}
+
+__device__ static inline uint32_t lds_addr(const void *p) {
+    return __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint8_t *)(const uint8_t *)p);
+}
+
+#if GEMM_DIAG == 3
+__device__ unsigned long long g_wide_stamps[8 * 64];
+extern "C" int lfamd_debug_wide_stamps(unsigned long long *dst) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_wide_stamps), sizeof(g_wide_stamps));
+}
+#endif
+
+template <int TYPE>
+__global__ __launch_bounds__(512) void gemm_wide_kernel(const uint8_t *__restrict__ A, long m, int nb,
+                                                        const _Float16 *__restrict__ Xh, const float *__restrict__ d8T,
+                                                        const _Float16 *__restrict__ Xm, long n, long n_pad,
+                                                        float *__restrict__ C, long ldc, int n_rb, int n_ct, int ks_n,
+                                                        int nbs) {
+    __shared__ __attribute__((aligned(16))) uint8_t xs[2][WD_XSTAGE];     // activation codes, XOR-swizzled rows
+    __shared__ __attribute__((aligned(16))) float d8s[2][WD_COLS];        // d8 of the 128 tokens
+    __shared__ __attribute__((aligned(16))) uint8_t xms[2][WD_COLS * 32]; // Q4_K mins operand rows
+    constexpr int TILE = TYPE == LFAMD_TYPE_Q4_K ? P4K_TILE : P6K_TILE;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = lane & 31, h = lane >> 5;
+
+    // XCD-aware order: block ids go round-robin over the 8 XCDs; give each XCD a contiguous run of the order
+    // (K-split index slowest, then super-tiles of 8 x 4 tiles, see tile_of)
+    const int n_tiles = n_rb * n_ct, n_wg = n_tiles * ks_n;
+    const int id = blockIdx.x, q8 = n_wg >> 3, r8 = n_wg & 7, xcd = id & 7;
+    const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3);
+    const int ks = L / n_tiles;
+    int rb, ct;
+    tile_of(L - ks * n_tiles, n_rb, n_ct, rb, ct);
+
+    const long n_row_tiles = (m + 31) / 32;
+    const int rw = wave & 3, ch = wave >> 2; // row tile and 64-token column half of this wave
+    const long rt = (long)rb * 4 + rw;
+    const bool active = rt < n_row_tiles;
+    const long n0 = (long)ct * WD_COLS;
+    const long k = (long)nb * 256;
+    const int b0 = ks * nbs, b1 = min(nb, b0 + nbs), nit = b1 - b0; // this work-group's super-blocks
+    if (nit <= 0)
+        return; // uniform over the work-group
+
+    // ---- loop-invariant per-lane offsets
+    // activation pieces: wave-instruction e of this wave copies token rows 32*wave + 2e + h; lane slot p = i of a
+    // row receives logical 16-B chunk p ^ (row & 15).  Pieces 4q..4q+3 share one M0 setting.
+    uint32_t xo[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const int nn = 16 * wave + 2 * e + h;
+        xo[e] = (uint32_t)(nn * 512 + ((i ^ (nn & 15)) * 16));
+    }
+    const uint32_t wo = lane * 16, ho = i * 16 + (TYPE == LFAMD_TYPE_Q4_K ? P4K_HDR : P6K_SC) - 4096;
+    const uint32_t xmo = (uint32_t)((32 * (wave & 3) + (lane >> 1)) * 32 + (lane & 1) * 16);
+    const uint8_t *xbase = (const uint8_t *)Xh + (size_t)n0 * 512;           // + b * n_pad * 512
+    const uint8_t *wbase = A + (size_t)(active ? rt : 0) * nb * TILE;
+    const uint8_t *xmbase = (const uint8_t *)Xm + (size_t)n0 * 32;           // + b * n_pad * 32
+    const uint32_t xs_a[2] = {lds_addr(xs[0]), lds_addr(xs[1])};
+    const uint32_t d8_a[2] = {lds_addr(d8s[0]), lds_addr(d8s[1])};
+    const uint32_t xm_a[2] = {lds_addr(xms[0]), lds_addr(xms[1])};
+
+    auto prefetch = [&](int b, int st, wide_w<TYPE> &w) {
+#if GEMM_DIAG == 2 // development: compute chain only (operands loaded twice)
+        if (b > b0 + 1)
+            return;
+#endif
+        const uint8_t *xb = uniform_ptr(xbase + (size_t)b * n_pad * 512);
+        const uint32_t dst = xs_a[st] + wave * 8192;
+        glds4(xb, dst, xo[0], xo[1], xo[2], xo[3]);
+        glds4(xb, dst + 4096, xo[4], xo[5], xo[6], xo[7]);
+        if (wave >= 6) // d8 of tokens 64*(wave-6) + lane
+            glds1x4(uniform_ptr(d8T + (size_t)b * n_pad + n0), d8_a[st] + (wave - 6) * 256, (uint32_t)((wave - 6) * 256 + lane * 4));
+        if constexpr (TYPE == LFAMD_TYPE_Q4_K) {
+            if (wave < 4)
+                glds1x16(uniform_ptr(xmbase + (size_t)b * n_pad * 32), xm_a[st] + wave * 1024, xmo);
+        }
+        const uint8_t *tile = uniform_ptr(wbase + (size_t)b * TILE);
+        const uint8_t *tile_h = uniform_ptr(tile + 4096), *tile_d = uniform_ptr(tile + P6K_D);
+        gload16<0>(w.qs[0], tile, wo);
+        gload16<1024>(w.qs[1], tile, wo);
+        gload16<2048>(w.qs[2], tile, wo);
+        gload16<3072>(w.qs[3], tile, wo);
+        if constexpr (TYPE == LFAMD_TYPE_Q4_K) {
+            gload16<0>(w.hd, tile_h, ho);
+        } else {
+            gload16<0>(w.qh[0], tile_h, wo);    // P6K_QH = 4096
+            gload16<1024>(w.qh[1], tile_h, wo);
+            gload16<0>(w.hd, tile_h, ho);
+            gload2<0>(w.dw, tile_d, (uint32_t)(i * 2));
+        }
+    };
+    // The same loads, spread over the K-steps of the super-block being computed: an LDS-DMA piece blocks the
+    // issuing wave for 100-200 cycles (measured with s_memtime: a burst of 10 right after the barrier cost every
+    // wave 1000-1800 cycles with both waves of a SIMD stalled together); one piece per K-step stalls one wave
+    // while its SIMD partner keeps the MFMA pipe busy.  Weights (HBM latency) first, activation pieces next, the
+    // small operands last; nothing is issued during the last five K-steps so the data lands before the barrier.
+    auto prefetch_step = [&](int t, int b, int st, wide_w<TYPE> &w) {
+        if (t == 0) {
+            const uint8_t *tile = uniform_ptr(wbase + (size_t)b * TILE);
+            const uint8_t *tile_h = uniform_ptr(tile + 4096), *tile_d = uniform_ptr(tile + P6K_D);
+            gload16<0>(w.qs[0], tile, wo);
+            gload16<1024>(w.qs[1], tile, wo);
+            gload16<2048>(w.qs[2], tile, wo);
+            gload16<3072>(w.qs[3], tile, wo);
+            if constexpr (TYPE == LFAMD_TYPE_Q4_K) {
+                gload16<0>(w.hd, tile_h, ho);
+            } else {
+                gload16<0>(w.qh[0], tile_h, wo);
+                gload16<1024>(w.qh[1], tile_h, wo);
+                gload16<0>(w.hd, tile_h, ho);
+                gload2<0>(w.dw, tile_d, (uint32_t)(i * 2));
+            }
+        } else if (t <= 8) {
+            const int e = t - 1;
+            glds1x16(uniform_ptr(xbase + (size_t)b * n_pad * 512), xs_a[st] + wave * 8192 + e * 1024, xo[e]);
+        } else if (t == 9) {
+            if (wave >= 6)
+                glds1x4(uniform_ptr(d8T + (size_t)b * n_pad + n0), d8_a[st] + (wave - 6) * 256, (uint32_t)((wave - 6) * 256 + lane * 4));
+        } else if (t == 10) {
+            if constexpr (TYPE == LFAMD_TYPE_Q4_K) {
+                if (wave < 4)
+                    glds1x16(uniform_ptr(xmbase + (size_t)b * n_pad * 32), xm_a[st] + wave * 1024, xmo);
+            }
+        }
+    };
+    // retire every load of the stage (this wave's), then meet the other waves: their LDS-DMA has landed too, and
+    // everybody has finished reading the stage that the next prefetch overwrites
+    auto arrive = [&](wide_w<TYPE> &w) {
+        if constexpr (TYPE == LFAMD_TYPE_Q4_K)
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier"
+                         : "+v"(w.qs[0]), "+v"(w.qs[1]), "+v"(w.qs[2]), "+v"(w.qs[3]), "+v"(w.hd)
+                         :
+                         : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier"
+                         : "+v"(w.qs[0]), "+v"(w.qs[1]), "+v"(w.qs[2]), "+v"(w.qs[3]), "+v"(w.hd), "+v"(w.qh[0]),
+                           "+v"(w.qh[1]), "+v"(w.dw)
+                         :
+                         : "memory");
+    };
+
+    float16_t_ acc[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+            acc[nt][r] = 0.0f;
+
+    // byte offset of this lane's fragment chunk inside a token row: chunk (c ^ (i & 15)) with c = 2t + h
+    uint32_t xoff[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+        xoff[u] = xs_a[0] + ch * 32768 + (uint32_t)(i * XT_ROW_BYTES + ((((2 * u + h) & 15) ^ (i & 15)) * 16));
+    const float16_t_ zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const uint32_t magic = opaque_magic();
+
+    auto compute = [&](auto stc, const wide_w<TYPE> &w, int bn, wide_w<TYPE> &wn) {
+        constexpr int st = decltype(stc)::value;
+#if GEMM_DIAG == 1 // development: memory + barrier chain only
+        acc[0][0] += (float)(w.qs[0].x ^ w.qs[1].y ^ w.qs[2].z ^ w.qs[3].w ^ w.hd.x) + d8s[st][lane];
+        return;
+#endif
+        // the four token tiles' fragments of K-step t (all offsets immediates; stage 1 is 64 KiB up: in the address)
+        auto read_frags = [&](half8_t(&f)[2], int t) {
+            const uint32_t a = xoff[t & 7] + (st ? WD_XSTAGE : 0);
+            if ((2 * t) & 16) {
+                dsr16<256>(f[0], a);
+                dsr16<16384 + 256>(f[1], a);
+            } else {
+                dsr16<0>(f[0], a);
+                dsr16<16384>(f[1], a);
+            }
+        };
+        float16_t_ tmp[2];
+        const uint32_t qw[16] = {w.qs[0].x, w.qs[0].y, w.qs[0].z, w.qs[0].w, w.qs[1].x, w.qs[1].y, w.qs[1].z, w.qs[1].w,
+                                 w.qs[2].x, w.qs[2].y, w.qs[2].z, w.qs[2].w, w.qs[3].x, w.qs[3].y, w.qs[3].z, w.qs[3].w};
+        if constexpr (TYPE == LFAMD_TYPE_Q4_K) {
+            const float d = h2f((uint16_t)(w.hd.x & 0xffff)), dmin = h2f((uint16_t)(w.hd.x >> 16));
+            uint32_t sc03, sc47, mn03, mn47;
+            q4k_scales_bytes(w.hd.y, w.hd.z, w.hd.w, sc03, sc47, mn03, mn47);
+            half8_t F[2][2];
+            read_frags(F[0], 0);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const float scf = (float)(((j < 4 ? sc03 : sc47) >> (8 * (j & 3))) & 0xff);
+                const half2_t S = bcast_h2(scf), O = bcast_h2(-1024.0f * scf);
+                const half2_t S16 = bcast_h2(scf * 0.0625f), O16 = bcast_h2(-64.0f * scf);
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    const int t = 2 * j + e;
+                    const half8_t wf = dequant_q4(qw[t], S, O, S16, O16, magic);
+                    if (t + 1 < 16) {
+                        read_frags(F[(t + 1) & 1], t + 1);
+                        ds_wait<2>(F[t & 1][0], F[t & 1][1]);
+                    } else {
+                        ds_wait<0>(F[t & 1][0], F[t & 1][1]);
+                    }
+#pragma unroll
+                    for (int nt = 0; nt < 2; nt++)
+                        tmp[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F[t & 1][nt], wf, t == 0 ? zero16 : tmp[nt], 0, 0, 0);
+                    prefetch_step(t, bn, st ^ 1, wn);
+                }
+            }
+            // mins: one MFMA per token tile, K = 16 = {lo parts | hi parts} of the 8 pair sums
+            frag_u wm;
+            const float mscale = h ? 64.0f : 1.0f;
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                const uint32_t mw = p < 2 ? mn03 : mn47;
+                const float m0 = (float)((mw >> (16 * (p & 1))) & 0xff), m1 = (float)((mw >> (16 * (p & 1) + 8)) & 0xff);
+                half2_t v = {(_Float16)(m0 * mscale), (_Float16)(m1 * mscale)};
+                wm.p[p] = v;
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++) {
+                const half8_t xm = *(const half8_t *)(xms[st] + (ch * 64 + nt * 32 + i) * 32 + h * 16);
+                const float16_t_ tm = __builtin_amdgcn_mfma_f32_32x32x16_f16(xm, wm.v, zero16, 0, 0, 0);
+#pragma unroll
+                for (int r4 = 0; r4 < 4; r4++) {
+                    const float4_t_ d8 = *(const float4_t_ *)(&d8s[st][ch * 64 + nt * 32 + 8 * r4 + 4 * h]);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const int r = 4 * r4 + e;
+                        const float u = fmaf(-dmin, tm[r], d * tmp[nt][r]);
+                        acc[nt][r] = fmaf(u, d8[e], acc[nt][r]);
+                    }
+                }
+            }
+        } else {
+            const uint32_t hw[8] = {w.qh[0].x, w.qh[0].y, w.qh[0].z, w.qh[0].w, w.qh[1].x, w.qh[1].y, w.qh[1].z, w.qh[1].w};
+            const uint32_t scw[4] = {w.hd.x, w.hd.y, w.hd.z, w.hd.w};
+            const float dw = h2f((uint16_t)w.dw);
+            half8_t F[2][2];
+            read_frags(F[0], 0);
+#pragma unroll
+            for (int t = 0; t < 16; t++) {
+                const float scf = (float)(int)(int8_t)((scw[t >> 2] >> (8 * (t & 3))) & 0xff);
+                const half2_t S = bcast_h2(scf);
+                uint32_t H = hw[t >> 1];
+                if (t & 1)
+                    H >>= 2;
+                const half8_t wf = dequant_q6(qw[t], H, S);
+                if (t + 1 < 16) {
+                    read_frags(F[(t + 1) & 1], t + 1);
+                    ds_wait<2>(F[t & 1][0], F[t & 1][1]);
+                } else {
+                    ds_wait<0>(F[t & 1][0], F[t & 1][1]);
+                }
+#pragma unroll
+                for (int nt = 0; nt < 2; nt++)
+                    tmp[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F[t & 1][nt], wf, t == 0 ? zero16 : tmp[nt], 0, 0, 0);
+                prefetch_step(t, bn, st ^ 1, wn);
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; r4++) {
+                    const float4_t_ d8 = *(const float4_t_ *)(&d8s[st][ch * 64 + nt * 32 + 8 * r4 + 4 * h]);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const int r = 4 * r4 + e;
+                        acc[nt][r] = fmaf(dw * tmp[nt][r], d8[e], acc[nt][r]);
+                    }
+                }
+        }
+    };
+
+    // ---- pipeline: super-block it+1 is in flight (registers w[(it+1)&1], LDS stage (it+1)&1) while it computes
+#if GEMM_DIAG == 3 // development: in-kernel time stamps of work-group 0 (s_memtime; never in the product build)
+#define STAMP(slot)                                                                                              \
+    do {                                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                       \
+        if (blockIdx.x == 0 && lane == 0 && stamp_n < 60)                                                        \
+            g_wide_stamps[wave * 64 + stamp_n++] = __builtin_amdgcn_s_memtime();                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                       \
+    } while (0)
+    int stamp_n = 0;
+#else
+#define STAMP(slot)
+#endif
+    wide_w<TYPE> wa, wb;
+    STAMP(0);
+    prefetch(b0, 0, wa);
+    for (int it = 0; it < nit; it += 2) {
+        STAMP(1);
+        arrive(wa);
+        STAMP(2);
+        STAMP(3);
+        compute(std::integral_constant<int, 0>{}, wa, b0 + (it + 1 < nit ? it + 1 : it), wb); // clamped: a redundant reload at the end
+        if (it + 1 < nit) { // uniform
+            STAMP(1);
+            arrive(wb);
+            STAMP(2);
+            STAMP(3);
+            compute(std::integral_constant<int, 1>{}, wb, b0 + (it + 2 < nit ? it + 2 : it + 1), wa);
+        }
+    }
+    STAMP(4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the clamped tail prefetch must not outlive the work-group's LDS
+
+    // ---- store: reg r of token tile nt is token n0 + 32nt + (r&3) + 8(r>>2) + 4h, weight row 32rt + i
+    if (active) {
+        const long row = rt * 32 + i;
+        if (row < m) {
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const long tok = n0 + ch * 64 + nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (tok < n) {
+                        if (ks_n == 1)
+                            C[tok * ldc + row] = acc[nt][r];
+                        else
+                            __builtin_amdgcn_global_atomic_fadd_f32((__attribute__((address_space(1))) float *)(C + tok * ldc + row),
+                                                                    acc[nt][r]);
+                    }
+                }
+        }
+    }
+}
+
+// C = 0 for the K-split accumulation (rows [0,n) x [0,m) of a matrix with leading dimension ldc)
+__global__ void zero_c_kernel(float *__restrict__ C, long ldc, long m, long n) {
+    const long total = m * n;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long j = idx / m;
+        C[j * ldc + (idx - j * m)] = 0.0f;
+    }
+}
+
+// How the wide body splits K: enough work-groups for 256 CUs, at least 2 super-blocks per split.
+static int wide_ksplit(int n_tiles, int nb) {
+    int ks = 1;
+    while (n_tiles * ks < 192 && nb / (ks * 2) >= 2 && ks < 2) // ks <= 2 keeps the sum order-independent
+        ks *= 2;
+    return ks;
+}
+
+extern "C" int lfamd_gemm_wide_ksplit(long m, long k, long n_pad) {
+    const int n_rb = (int)((m + 127) / 128), n_ct = (int)(n_pad / WD_COLS);
+    return wide_ksplit(n_rb * n_ct, (int)(k / 256));
+}
+
+extern "C" hipError_t lfamd_launch_gemm_wide(int Atype, const void *A, long m, long k, const void *Xh, const void *d8T,
+                                             const void *Xm, long n, long n_pad, float *C, long ldc, hipStream_t s) {
+    if (m <= 0 || n <= 0)
+        return hipSuccess;
+    if (n_pad % WD_COLS)
+        return hipErrorInvalidValue;
+    const int nb = (int)(k / 256);
+    const long n_row_tiles = (m + 31) / 32;
+    const int n_rb = (int)((n_row_tiles + 3) / 4), n_ct = (int)(n_pad / WD_COLS);
+    const int ks = wide_ksplit(n_rb * n_ct, nb);
+    const int nbs = (nb + ks - 1) / ks;
+    const int n_wg = n_rb * n_ct * ks;
+    if (ks > 1) {
+        long total = m * n;
+        int blocks = (int)((total + 256 * 8 - 1) / (256 * 8));
+        zero_c_kernel<<<blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks), 256, 0, s>>>(C, ldc, m, n);
+    }
+    if (Atype == LFAMD_TYPE_Q4_K)
+        gemm_wide_kernel<LFAMD_TYPE_Q4_K><<<n_wg, 512, 0, s>>>((const uint8_t *)A, m, nb, (const _Float16 *)Xh, (const float *)d8T,
+                                                                (const _Float16 *)Xm, n, n_pad, C, ldc, n_rb, n_ct, ks, nbs);
+    else if (Atype == LFAMD_TYPE_Q6_K)
+        gemm_wide_kernel<LFAMD_TYPE_Q6_K><<<n_wg, 512, 0, s>>>((const uint8_t *)A, m, nb, (const _Float16 *)Xh, (const float *)d8T,
+                                                                (const _Float16 *)Xm, n, n_pad, C, ldc, n_rb, n_ct, ks, nbs);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}

@@ -184,9 +184,12 @@ __global__ void pack_raw_kernel(const uint8_t *__restrict__ raw, size_t raw_row_
 
 // ---------------------------------------------------------------------------------------------
 // Activation preparation for the MFMA GEMM: llamafile-order Q8_K rows ->
-//   Xh  [n_pad][k]      f16   integer codes q8 (exact in f16), zero rows beyond n
+//   Xh  [nb][n_pad][256] f16  integer codes q8 (exact in f16), zero rows beyond n.  Super-block major: a token
+//                             tile's codes of one super-block are ONE contiguous run (a [n_pad][k] matrix puts the
+//                             tile's 512-byte row pieces a power-of-two stride apart -> they camp on 2 of the 16
+//                             L2 channels and the GEMM's operand stream tops out near 10 TB/s)
 //   d8T [nb][n_pad]     f32   block scales, transposed so a token tile's scales are contiguous
-//   Xm  [n_pad][nb][16] f16   mins operand: for the 8 pair sums S_j = bsums[2j]+bsums[2j+1]
+//   Xm  [nb][n_pad][16] f16   mins operand: for the 8 pair sums S_j = bsums[2j]+bsums[2j+1]
 //                             (|S_j| <= 4096) the split S_j = 64*hi_j + lo_j, lo in [0,63]:
 //                             elements 0..7 = lo_j, 8..15 = hi_j (both exact in f16)
 
@@ -196,7 +199,7 @@ __global__ void prep_q8k_kernel(const uint8_t *__restrict__ B, size_t b_row_byte
     long tok = blk / nb;
     int b = (int)(blk % nb);
     int t = threadIdx.x; // 64 threads: 4 codes each
-    _Float16 *xo = Xh + (size_t)tok * nb * 256 + (size_t)b * 256;
+    _Float16 *xo = Xh + ((size_t)b * n_pad + tok) * 256;
     if (tok < n) {
         const lfamd_block_q8_K *y = (const lfamd_block_q8_K *)(B + tok * b_row_bytes) + b;
         uint32_t q = *(const uint32_t *)((const uint8_t *)y->qs + 4 * t); // 292-byte blocks are 4-aligned
@@ -207,7 +210,7 @@ __global__ void prep_q8k_kernel(const uint8_t *__restrict__ B, size_t b_row_byte
         if (t < 8) {
             int S = (int)y->bsums[2 * t] + (int)y->bsums[2 * t + 1];
             int lo = S & 63, hi = (S - lo) / 64;
-            _Float16 *mo = Xm + ((size_t)tok * nb + b) * 16;
+            _Float16 *mo = Xm + ((size_t)b * n_pad + tok) * 16;
             mo[t] = (_Float16)lo;
             mo[8 + t] = (_Float16)hi;
         }
@@ -217,7 +220,7 @@ __global__ void prep_q8k_kernel(const uint8_t *__restrict__ B, size_t b_row_byte
         if (t == 0)
             d8T[(size_t)b * n_pad + tok] = 0.0f;
         if (t < 16)
-            Xm[((size_t)tok * nb + b) * 16 + t] = (_Float16)0;
+            Xm[((size_t)b * n_pad + tok) * 16 + t] = (_Float16)0;
     }
 }
 
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(64) void prep_f32_kernel(const uint8_t *__restrict_
     long tok = blk / nb;
     int b = (int)(blk % nb);
     int t = threadIdx.x;
-    _Float16 *xo = Xh + (size_t)tok * nb * 256 + (size_t)b * 256;
+    _Float16 *xo = Xh + ((size_t)b * n_pad + tok) * 256;
     typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
     if (tok >= n) {
         half4_t z = {(_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0};
@@ -239,7 +242,7 @@ __global__ __launch_bounds__(64) void prep_f32_kernel(const uint8_t *__restrict_
         if (t == 0)
             d8T[(size_t)b * n_pad + tok] = 0.0f;
         if (t < 16)
-            Xm[((size_t)tok * nb + b) * 16 + t] = (_Float16)0;
+            Xm[((size_t)b * n_pad + tok) * 16 + t] = (_Float16)0;
         return;
     }
     const float4 f = *(const float4 *)((const float *)(X + tok * x_row_bytes) + (size_t)b * 256 + 4 * t);
@@ -286,7 +289,7 @@ __global__ __launch_bounds__(64) void prep_f32_kernel(const uint8_t *__restrict_
     if ((t & 7) == 0) {
         int j = t >> 3;
         int lo = S & 63, hi = (S - lo) / 64;
-        _Float16 *mo = Xm + ((size_t)tok * nb + b) * 16;
+        _Float16 *mo = Xm + ((size_t)b * n_pad + tok) * 16;
         mo[j] = (_Float16)lo;
         mo[8 + j] = (_Float16)hi;
     }

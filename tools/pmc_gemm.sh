@@ -16,7 +16,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in rows:
     k = r["Kernel_Name"]
-    if "gemm_" in k or "prep" in k:
+    if "gemm_" in k or "prep" in k or "zero_c" in k:
         agg[k[:30]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in agg.items():
     print(k, {c: round(sum(v) / len(v), 1) for c, v in d.items()}, "n=", len(next(iter(d.values()))))
