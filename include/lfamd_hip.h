@@ -44,6 +44,8 @@ enum lfamd_status {
                                     tinyBLAS_Q0: Kahan on 2x1/1x2/1x1 edge tiles (tinyblas_cpu.h:797-830) */
 #define LFAMD_FLAG_PRECISE 2u    /* FLAG_precise (--precise): Kahan everywhere in the Q0 kernels */
 #define LFAMD_FLAG_FORCE_GENERIC 4u /* debugging: route through the generic (untuned) kernel */
+#define LFAMD_FLAG_GEMM_NARROW 8u   /* testing: force the 128x64 split-K MFMA body (default: chosen by grid size) */
+#define LFAMD_FLAG_GEMM_WIDE 16u    /* testing: force the 128x128 MFMA body */
 
 int lfamd_abi_version(void);
 const char *lfamd_last_error(void);

@@ -16,6 +16,8 @@ HOST_SO = os.path.join(_HERE, "libllamafile_sgemm.so")
 FLAG_Q0_VREGS32 = 1
 FLAG_PRECISE = 2
 FLAG_FORCE_GENERIC = 4
+FLAG_GEMM_NARROW = 8
+FLAG_GEMM_WIDE = 16
 
 
 class LfamdError(RuntimeError):

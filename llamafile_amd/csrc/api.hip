@@ -262,7 +262,10 @@ int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const v
         // 128 x 64 split-K body (gemm_mfma.hip) for smaller grids.  LFAMD_GEMM_BODY=narrow|wide forces one.
         static const char *body = getenv("LFAMD_GEMM_BODY");
         const long tiles128 = ((m + 127) / 128) * (long)(n_pad / 128);
-        const bool narrow = body ? body[0] == 'n' : tiles128 < 192;
+        const bool narrow = (flags & LFAMD_FLAG_GEMM_NARROW) ? true
+                            : (flags & LFAMD_FLAG_GEMM_WIDE) ? false
+                            : body                           ? body[0] == 'n'
+                                                             : tiles128 < 192;
         if (narrow)
             HIPCHK(lfamd_launch_gemm_kq(Atype, d_A, m, k, Xh, d8T, Xm, n, (long)n_pad, d_C, ldc, s), "gemm_kq");
         else

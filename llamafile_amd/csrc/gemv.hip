@@ -20,6 +20,7 @@
 // weight loads is issued BEFORE the activation staging so HBM latency overlaps it, and the next
 // chunk is always in flight while the current one is consumed.
 #include "lfamd_device.h"
+#include <stdlib.h>
 
 // LDS image of one Q8_K activation block for the K-quant GEMVs.  A lane = (gsel, h) reads its 64 code
 // bytes (two groups g = 2gsel+gi, four K-steps dd each) with four ds_read_b128, its 8 half-sums with
@@ -276,6 +277,25 @@ struct gemv_mats {
     int count;
 };
 
+#ifndef GEMV_DIAG
+#define GEMV_DIAG 0
+#endif
+#if GEMV_DIAG // development: in-kernel s_memtime stamps of two work-groups (never in the product build)
+__device__ unsigned long long g_gemv_stamps[4 * 16 * 16];
+extern "C" int lfamd_debug_gemv_stamps(unsigned long long *dst) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_gemv_stamps), sizeof(g_gemv_stamps));
+}
+#define GSTAMP()                                                                                                 \
+    do {                                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                       \
+        if ((blockIdx.x == 0 || blockIdx.x == 100) && lane == 0 && stamp_n < 16)                                  \
+            g_gemv_stamps[((blockIdx.x ? 1 : 0) * 16 + wave) * 16 + stamp_n++] = __builtin_amdgcn_s_memrealtime(); \
+        __builtin_amdgcn_sched_barrier(0);                                                                       \
+    } while (0)
+#else
+#define GSTAMP()
+#endif
+
 template <typename TR, int NC, int BT, int NW, int GEMV_CH>
 __global__ __launch_bounds__(NW * 64) void gemv_kq_kernel(const gemv_mats mats, int nb, const uint8_t *__restrict__ B,
                                                           size_t b_row_bytes, long col0, int n_ht) {
@@ -283,6 +303,10 @@ __global__ __launch_bounds__(NW * 64) void gemv_kq_kernel(const gemv_mats mats, 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i16 = lane & 15, h = (lane >> 4) & 1, gsel = lane >> 5;
     float *red = (float *)(lds + (size_t)NC * nb * XBLK); // [2][NW][NC][16]
+#if GEMV_DIAG
+    int stamp_n = 0;
+#endif
+    GSTAMP();
 
     const int sb_per_wave = (nb + NW - 1) / NW;
     const int cpt = (sb_per_wave + GEMV_CH - 1) / GEMV_CH; // chunks per tile
@@ -344,7 +368,9 @@ __global__ __launch_bounds__(NW * 64) void gemv_kq_kernel(const gemv_mats mats, 
                     rb[(wave * NC + c) * 16 + lane] = v;
                 acc[c] = 0.0f;
             }
+            GSTAMP();
             __syncthreads();
+            GSTAMP();
             if (threadIdx.x < 16 * NC) {
                 const int c = threadIdx.x >> 4, i = threadIdx.x & 15;
                 float v = 0.0f;
@@ -378,17 +404,24 @@ __global__ __launch_bounds__(NW * 64) void gemv_kq_kernel(const gemv_mats mats, 
         if (mine)
             load_piece(v, (const float *)(B + col0 * b_row_bytes), threadIdx.x);
         issue(bufA, 0);
+        GSTAMP();
         if (mine)
             quantise_piece_q8k(lds + (size_t)(threadIdx.x >> 4) * XBLK, v, threadIdx.x & 15);
+        GSTAMP();
     } else {
         issue(bufA, 0); // in flight during the staging below
         stage_x<BT>(lds, B, b_row_bytes, col0, NC, nb);
     }
     __syncthreads();
+    GSTAMP();
 
+    // (issuing bufB before the staging as well, and re-issuing each buffer right after its consume, measured
+    // 10-25 % SLOWER on every decode shape: the counted waits degrade and the activation loads queue behind more
+    // weight traffic)
     for (int f = 0; f < total; f += 2) {
         issue(bufB, f + 1);
         consume(bufA, f);
+        GSTAMP();
         issue(bufA, f + 2);
         if (f + 1 < total)
             consume(bufB, f + 1);
@@ -603,6 +636,13 @@ static hipError_t launch_kq_pick(const gemv_mats &mats, int n_ht, long k, const 
                                  hipStream_t s) {
     const long nb = k / 256;
     if constexpr (NC == 1) {
+        static const char *v = getenv("LFAMD_GEMV_VARIANT"); // development: wave count x chunk depth
+        if (v && v[0] == 'a')
+            return nb <= 16 ? launch_kq<TR, NC, BT, 8, 2>(mats, n_ht, k, B, brb, col0, s)
+                            : launch_kq<TR, NC, BT, 8, 4>(mats, n_ht, k, B, brb, col0, s);
+        if (v && v[0] == 'b')
+            return nb <= 16 ? launch_kq<TR, NC, BT, 4, 4>(mats, n_ht, k, B, brb, col0, s)
+                            : launch_kq<TR, NC, BT, 4, 4>(mats, n_ht, k, B, brb, col0, s);
         if (nb <= 16)
             return launch_kq<TR, NC, BT, 16, 1>(mats, n_ht, k, B, brb, col0, s);
         return launch_kq<TR, NC, BT, 16, 2>(mats, n_ht, k, B, brb, col0, s);

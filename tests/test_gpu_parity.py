@@ -66,14 +66,34 @@ def test_q8_0_bit_exact(gpu, oracle, variant, precise, shape):
 @pytest.mark.parametrize("t", [T.Q4_K, T.Q6_K], ids=lambda t: T.NAMES[t])
 @pytest.mark.parametrize("shape", [(128, 64, 512), (96, 100, 1024), (33, 9, 256), (256, 512, 2048), (64, 130, 768)],
                          ids=str)
-def test_mfma_gemm_vs_oracle(gpu, oracle, t, shape):
+@pytest.mark.parametrize("body", ["narrow", "wide"])
+def test_mfma_gemm_vs_oracle(gpu, oracle, t, shape, body):
+    """Both MFMA bodies (128x64 split-K, gemm_mfma.hip; 128x128, gemm_wide.hip) on every shape, ragged m / n
+    included; the default picks by grid size, which small test shapes would never send to the wide body."""
+    from llamafile_amd import _hip
     m, n, k = shape
     A, B, bt = make_case(t, m, n, k, seed=300 + t)
     ok, G = oracle.sgemm(t, A, bt, B, m, n, k, nth=4)
     assert ok == 1
-    C = run_gpu(gpu, t, A, B, bt, m, n, k)
+    flag = _hip.FLAG_GEMM_NARROW if body == "narrow" else _hip.FLAG_GEMM_WIDE
+    C = run_gpu(gpu, t, A, B, bt, m, n, k, flags=gpu.host_variant_flags() | flag)
     assert not np.isnan(C).any()
     assert rel_err(C, G) <= GEMM_TOL[t], (T.NAMES[t], shape, rel_err(C, G))
+
+
+@pytest.mark.parametrize("t", [T.Q4_K, T.Q6_K], ids=lambda t: T.NAMES[t])
+def test_mfma_bodies_agree_and_repeat(gpu, t):
+    """Same inputs -> the wide body gives identical bits on every run (no atomics in the default K split), and
+    the two bodies agree to the f32 summation-order tolerance.  Odd super-block count, ragged rows and tokens."""
+    from llamafile_amd import _hip
+    m, n, k = 300, 200, 256 * 5
+    A, B, bt = make_case(t, m, n, k, seed=77)
+    base = gpu.host_variant_flags()
+    w1 = run_gpu(gpu, t, A, B, bt, m, n, k, flags=base | _hip.FLAG_GEMM_WIDE)
+    w2 = run_gpu(gpu, t, A, B, bt, m, n, k, flags=base | _hip.FLAG_GEMM_WIDE)
+    nr = run_gpu(gpu, t, A, B, bt, m, n, k, flags=base | _hip.FLAG_GEMM_NARROW)
+    assert np.array_equal(w1.view(np.uint32), w2.view(np.uint32))
+    assert rel_err(w1, nr) <= 2e-6
 
 
 @pytest.mark.parametrize("t", [T.Q4_0, T.Q5_K, T.IQ4_XS, T.Q2_K], ids=lambda t: T.NAMES[t])
