@@ -436,13 +436,20 @@ __global__ __launch_bounds__(NW * 64) void gemv_kq_kernel(const gemv_mats mats, 
 // Cv = fma(a, b, Cv)   or, on a PRECISE tile, madder (tinyblas_cpu.h:203-209) with the compiler's
 // contraction of sub(mul(a,b),e) into fma(a,b,-e).
 
-#define X80_BLK 36 // LDS: 8 dwords of q8 + f32 d
-#define Q80_DEPTH 16 // quads (1 KiB per wave each) kept in flight per wave
+// LDS image of the Q8_0 activations, per QUAD of four 32-blocks (the unit a weight tile covers): for each of the
+// eight dword positions j the four blocks' dwords side by side (a lane = (row r, position j) takes its four
+// activation dwords with ONE ds_read_b128; the eight rows of a wave read the same 128 bytes: broadcast), then the
+// four block scales as f32 (one more ds_read_b128, uniform).  8 ds_read_b32 per quad became 2 ds_read_b128.
+#define X80_QUAD 144
+#define X80_QD 128
+// quads (1 KiB per wave each) kept in flight per wave: the row's blocks MUST be visited in order by one lane
+// (bit-exact f32 chain), so a matrix offers only m/8 waves (2 per CU at m = 4096) and memory-level parallelism
+// has to come from depth.  n = 1: 32 (a whole k = 4096 row group in flight, 192 ring VGPRs); batches: 16.
 #define Q80_WAVES 2  // waves per work-group (8 rows each) sharing one staged activation image
 
 // MODE: 0 = every output plain fma, 1 = every output Kahan (uniform for n = 1: tinyblas_cpu.h:797-925),
 // 2 = per-output choice from the mnpack geometry (small batches n > 1)
-template <int NC, int BT, int MODE>
+template <int NC, int BT, int MODE, int Q80_DEPTH>
 __global__ __launch_bounds__(Q80_WAVES * 64) void gemv_q80_kernel(const uint8_t *__restrict__ A, long m, long n_total,
                                                                  int nblocks, int nquads, const uint8_t *__restrict__ B,
                                                                  size_t b_row_bytes, long col0, float *__restrict__ C,
@@ -450,6 +457,10 @@ __global__ __launch_bounds__(Q80_WAVES * 64) void gemv_q80_kernel(const uint8_t 
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane >> 3, j = lane & 7;
+#if GEMV_DIAG
+    int stamp_n = 0;
+#endif
+    GSTAMP();
     const long rg = (long)blockIdx.x * Q80_WAVES + wave;
     const long n_rg = (m + 7) / 8;
     const long row = rg * 8 + r;
@@ -472,17 +483,20 @@ __global__ __launch_bounds__(Q80_WAVES * 64) void gemv_q80_kernel(const uint8_t 
         const int pieces = nblocks * 2, nthr = Q80_WAVES * 64;
         for (int c = 0; c < NC; c++) {
             const float *x = (const float *)(B + (col0 + c) * b_row_bytes);
-            for (int p0 = 0; p0 < pieces; p0 += nthr) {
-                const int p = p0 + threadIdx.x;
-                float v[16];
-                if (p < pieces)
-                    load_piece(v, x, p);
+            // two pieces per thread and round: both loads go out together (one memory latency per round, not two)
+            for (int p0 = 0; p0 < pieces; p0 += 2 * nthr) {
+                const int pa = p0 + threadIdx.x, pb = pa + nthr;
+                float va[16], vb[16];
+                if (pa < pieces)
+                    load_piece(va, x, pa);
+                if (pb < pieces)
+                    load_piece(vb, x, pb);
                 if (c == 0 && p0 == 0) {
 #pragma unroll
                     for (int s = 0; s < Q80_DEPTH; s++)
                         issue(s, s);
                 }
-                if (p < pieces) {
+                auto quantise = [&](const float (&v)[16], int p) {
                     float amax = 0.0f;
 #pragma unroll
                     for (int e = 0; e < 16; e++)
@@ -496,11 +510,19 @@ __global__ __launch_bounds__(Q80_WAVES * 64) void gemv_q80_kernel(const uint8_t 
                         int q = (int)roundf(v[e] * id);
                         y[e >> 2] |= (uint32_t)(q & 0xff) << (8 * (e & 3));
                     }
-                    uint8_t *dst = lds + (size_t)(c * nblocks + (p >> 1)) * X80_BLK;
-                    *(uint4 *)(dst + 16 * (p & 1)) = make_uint4(y[0], y[1], y[2], y[3]);
-                    if ((p & 1) == 0)
-                        *(float *)(dst + 32) = h2f(f2h_bits(d)); // the block stores d as f16
-                }
+                    const int l = p >> 1, hf = p & 1;
+                    uint8_t *dst = lds + (size_t)(c * nquads + (l >> 2)) * X80_QUAD + (l & 3) * 4;
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        *(uint32_t *)(dst + (4 * hf + e) * 16) = y[e];
+                    if (hf == 0)
+                        *(float *)(dst + X80_QD) = h2f(f2h_bits(d)); // the block stores d as f16
+                };
+                // (pieces is even and nthr a multiple of 64: the lane pair (2i, 2i+1) of a block is either both in or out)
+                if (pa < pieces)
+                    quantise(va, pa);
+                if (pb < pieces)
+                    quantise(vb, pb);
             }
         }
     } else {
@@ -518,10 +540,12 @@ __global__ __launch_bounds__(Q80_WAVES * 64) void gemv_q80_kernel(const uint8_t 
             } else {
                 v = __builtin_bit_cast(uint32_t, h2f(*(const uint16_t *)y));
             }
-            *(uint32_t *)(lds + (size_t)(c * nblocks + l) * X80_BLK + 4 * w) = v;
+            *(uint32_t *)(lds + (size_t)(c * nquads + (l >> 2)) * X80_QUAD + (l & 3) * 4 + (w < 8 ? w * 16 : X80_QD)) = v;
         }
     }
+    GSTAMP();
     __syncthreads();
+    GSTAMP();
 
     bool kahan[NC];
 #pragma unroll
@@ -533,13 +557,39 @@ __global__ __launch_bounds__(Q80_WAVES * 64) void gemv_q80_kernel(const uint8_t 
     for (int c = 0; c < NC; c++)
         Cv[c] = Ce[c] = 0.0f;
 
-    // one block: a = f32(dA)*f32(dB), b = f32(int dot of bytes 4j..4j+3), then the reference's update
-    auto step = [&](float da, uint32_t qwd, int l) {
+    // One block: a = f32(dA)*f32(dB), b = f32(int dot of bytes 4j..4j+3), then the reference's update.  The update is a
+    // chain of dependent f32 ops (four per block under Kahan) that ONE lane must run in block order; everything else
+    // (scale products, integer dots) is independent of it.  A row offers a single wave no other work, so the loop is
+    // software-pipelined by hand: the products of quad L+1 are prepared (prep) before the chain of quad L runs and
+    // fill its latency bubbles (measured: the fused form spent ~80 cycles per block, 4-5 us per k = 4096 row).
+    struct prepd {
+        float a[4][NC], b[4][NC];
+    };
+    auto prep = [&](int sl, int L, prepd &P) {
+        const uint4 q4 = qa[sl];
+        const uint2 d2 = ds[sl];
+        const uint32_t qw[4] = {q4.x, q4.y, q4.z, q4.w};
+        const float da[4] = {h2f((uint16_t)(d2.x & 0xffff)), h2f((uint16_t)(d2.x >> 16)), h2f((uint16_t)(d2.y & 0xffff)),
+                             h2f((uint16_t)(d2.y >> 16))};
+        const int Lc = L < nquads ? L : nquads - 1; // clamped: the LDS reads are unconditional
 #pragma unroll
         for (int c = 0; c < NC; c++) {
-            const uint8_t *xb = lds + (size_t)(c * nblocks + l) * X80_BLK;
-            const float a = da * *(const float *)(xb + 32);
-            const float bq = (float)sdot4(qwd, *(const uint32_t *)(xb + 4 * j), 0);
+            const uint8_t *xb = lds + (size_t)(c * nquads + Lc) * X80_QUAD;
+            const uint4 xq4 = *(const uint4 *)(xb + j * 16);
+            const float4 xd4 = *(const float4 *)(xb + X80_QD);
+            const uint32_t xq[4] = {xq4.x, xq4.y, xq4.z, xq4.w};
+            const float xd[4] = {xd4.x, xd4.y, xd4.z, xd4.w};
+#pragma unroll
+            for (int dd = 0; dd < 4; dd++) {
+                P.a[dd][c] = da[dd] * xd[dd];
+                P.b[dd][c] = (float)sdot4(qw[dd], xq[dd], 0);
+            }
+        }
+    };
+    auto chain = [&](const prepd &P, int dd) {
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            const float a = P.a[dd][c], bq = P.b[dd][c];
             if constexpr (MODE == 0) {
                 Cv[c] = __builtin_fmaf(a, bq, Cv[c]);
             } else if constexpr (MODE == 1) {
@@ -547,7 +597,7 @@ __global__ __launch_bounds__(Q80_WAVES * 64) void gemv_q80_kernel(const uint8_t 
                 const float t = Cv[c] + y;
                 Ce[c] = (t - Cv[c]) - y;
                 Cv[c] = t;
-            } else { // branch-free select so the loads of later blocks are scheduled ahead of the f32 chain
+            } else { // branch-free select
                 const float plain = __builtin_fmaf(a, bq, Cv[c]);
                 const float y = __builtin_fmaf(a, bq, -Ce[c]);
                 const float t = Cv[c] + y;
@@ -561,28 +611,48 @@ __global__ __launch_bounds__(Q80_WAVES * 64) void gemv_q80_kernel(const uint8_t 
     // Blocks past the row (zero padding of the last quad, zero-filled prefetch slots) must NOT run: a Kahan
     // step with a*b = 0 still folds the pending compensation into the sum.  Full quads run unguarded.
     const int nq_full = nblocks >> 2;
-    for (int L0 = 0; L0 < nquads; L0 += Q80_DEPTH) {
+    prepd P[2];
+    prep(0, 0, P[0]);
+    issue(0, Q80_DEPTH);
+    // rounds of Q80_DEPTH full quads run without a branch in the body (k = 4096 and 14336: every round);
+    // the remainder round carries the guards
+    int L0 = 0;
+    for (; L0 + Q80_DEPTH <= nq_full; L0 += Q80_DEPTH) {
+#pragma unroll
+        for (int s = 0; s < Q80_DEPTH; s++) {
+            const int sn = (s + 1) % Q80_DEPTH;
+            prep(sn, L0 + s + 1, P[(s + 1) & 1]); // slot sn holds quad L+1
+            issue(sn, L0 + s + 1 + Q80_DEPTH);    // and is refilled as soon as its registers are read
+            const prepd &Pc = P[s & 1];
+            chain(Pc, 0);
+            chain(Pc, 1);
+            chain(Pc, 2);
+            chain(Pc, 3);
+        }
+    }
+    if (L0 < nquads) {
 #pragma unroll
         for (int s = 0; s < Q80_DEPTH; s++) {
             const int L = L0 + s;
-            const uint4 q4 = qa[s];
-            const uint2 d2 = ds[s];
-            issue(s, L + Q80_DEPTH); // refill this slot (past the end: zeros, no traffic)
-            const uint32_t qw[4] = {q4.x, q4.y, q4.z, q4.w};
-            const float da[4] = {h2f((uint16_t)(d2.x & 0xffff)), h2f((uint16_t)(d2.x >> 16)), h2f((uint16_t)(d2.y & 0xffff)),
-                                 h2f((uint16_t)(d2.y >> 16))};
+            const int sn = (s + 1) % Q80_DEPTH;
+            prep(sn, L + 1, P[(s + 1) & 1]);
+            const prepd &Pc = P[s & 1];
             if (L < nq_full) {
-#pragma unroll
-                for (int dd = 0; dd < 4; dd++)
-                    step(da[dd], qw[dd], 4 * L + dd);
+                chain(Pc, 0);
+                chain(Pc, 1);
+                chain(Pc, 2);
+                chain(Pc, 3);
             } else if (L == nq_full) {
-#pragma unroll
-                for (int dd = 0; dd < 3; dd++)
-                    if (4 * L + dd < nblocks)
-                        step(da[dd], qw[dd], 4 * L + dd);
+                if (4 * L + 0 < nblocks)
+                    chain(Pc, 0);
+                if (4 * L + 1 < nblocks)
+                    chain(Pc, 1);
+                if (4 * L + 2 < nblocks)
+                    chain(Pc, 2);
             }
         }
     }
+    GSTAMP();
     // hsum(__m256), tinyblas_cpu.h:277-296: ((v0+v4)+(v2+v6)) + ((v1+v5)+(v3+v7))
 #pragma unroll
     for (int c = 0; c < NC; c++) {
@@ -667,13 +737,13 @@ template <int NC, int BT>
 static hipError_t launch_q80(const void *A, long m, long n_total, long k, const void *B, size_t brb, long col0, float *C,
                              long ldc, int vregs32, int precise, hipStream_t s) {
     int nblocks = (int)(k / 32), nquads = (nblocks + 3) / 4;
-    size_t smem = (size_t)NC * nblocks * X80_BLK;
+    size_t smem = (size_t)NC * nquads * X80_QUAD;
     unsigned grid = (unsigned)(((m + 7) / 8 + Q80_WAVES - 1) / Q80_WAVES);
     // n = 1: the whole problem is one column of 2x1 / 1x1 tiles, so the summation mode is uniform
     const int mode = n_total == 1 ? ((vregs32 || precise) ? 1 : 0) : 2;
 #define Q80_GO(MODE)                                                                                                   \
     do {                                                                                                               \
-        auto kernel = gemv_q80_kernel<NC, BT, MODE>;                                                                   \
+        auto kernel = gemv_q80_kernel<NC, BT, MODE, 16>;                                                          \
         if (smem > 64 * 1024) {                                                                                        \
             hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
             if (e != hipSuccess)                                                                                       \
@@ -736,7 +806,7 @@ extern "C" hipError_t lfamd_launch_gemv_multi(int Atype, int count, const void *
         return hipSuccess;
     size_t per_col;
     if (Atype == LFAMD_TYPE_Q8_0)
-        per_col = (size_t)(k / 32) * X80_BLK;
+        per_col = (size_t)((k / 32 + 3) / 4) * X80_QUAD;
     else
         per_col = (size_t)(k / 256) * XBLK;
     int step = max_cols_for(per_col);
