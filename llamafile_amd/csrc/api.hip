@@ -21,6 +21,9 @@ hipError_t lfamd_launch_gemv(int, const void *, long, long, int, const void *, s
                              hipStream_t);
 hipError_t lfamd_launch_gemv_multi(int, int, const void *const *, const long *, long, int, const void *, size_t, long,
                                    float *const *, const long *, int, int, hipStream_t);
+hipError_t lfamd_launch_gemm_q80(const void *, long, long, int, const void *, size_t, long, float *, long, void *, int, int,
+                                 hipStream_t);
+size_t lfamd_gemm_q80_workspace(long, long);
 hipError_t lfamd_launch_gemm_wide(int, const void *, long, long, const void *, const void *, const void *, long, long,
                                   float *, long, hipStream_t);
 hipError_t lfamd_launch_gemm_kq(int, const void *, long, long, const void *, const void *, const void *, long, long,
@@ -196,12 +199,15 @@ static bool use_gemm(int Atype, long n, unsigned flags) {
     return n > 8 && (Atype == LFAMD_TYPE_Q4_K || Atype == LFAMD_TYPE_Q6_K);
 }
 
+// Q8_0 batches: the register-tiled bit-exact kernel (gemm_q80.hip)
+static bool use_gemm_q80(int Atype, long n, unsigned flags) {
+    return !(flags & LFAMD_FLAG_FORCE_GENERIC) && n > 8 && Atype == LFAMD_TYPE_Q8_0;
+}
+
 static bool use_gemv(int Atype, long n, unsigned flags) {
     if (flags & LFAMD_FLAG_FORCE_GENERIC)
         return false;
-    if (Atype == LFAMD_TYPE_Q8_0)
-        return true; // the bit-exact kernel services every n for Q8_0 (column tiles of 8)
-    return n <= 8 && (Atype == LFAMD_TYPE_Q4_K || Atype == LFAMD_TYPE_Q6_K);
+    return n <= 8 && (Atype == LFAMD_TYPE_Q4_K || Atype == LFAMD_TYPE_Q6_K || Atype == LFAMD_TYPE_Q8_0);
 }
 
 static bool gemv_quantise_separately(int Atype, long m) {
@@ -217,6 +223,8 @@ size_t lfamd_mul_mat_workspace(int Atype, long m, long k, long n) {
         size_t n_pad = align_up((size_t)n, 128), nb = (size_t)(k / 256);
         return align_up(n_pad * (size_t)k * 2, 256) + align_up(nb * n_pad * 4, 256) + align_up(n_pad * nb * 32, 256);
     }
+    if (use_gemm_q80(Atype, n, 0))
+        return align_up(lfamd_gemm_q80_workspace(k, n), 256);
     if (use_gemv(Atype, n, 0) || !type_known(Atype) || lfamd_blck_size(Atype) == 1)
         return 0;
     // generic kernels given f32 activations quantise them into the workspace first
@@ -270,6 +278,13 @@ int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const v
             HIPCHK(lfamd_launch_gemm_kq(Atype, d_A, m, k, Xh, d8T, Xm, n, (long)n_pad, d_C, ldc, s), "gemm_kq");
         else
             HIPCHK(lfamd_launch_gemm_wide(Atype, d_A, m, k, Xh, d8T, Xm, n, (long)n_pad, d_C, ldc, s), "gemm_wide");
+        return LFAMD_OK;
+    }
+    if (use_gemm_q80(Atype, n, flags)) {
+        size_t need = lfamd_mul_mat_workspace(Atype, m, k, n);
+        if (ws_bytes < need || !d_ws)
+            return fail(LFAMD_ERR_WORKSPACE, "mul_mat: workspace too small%s", "");
+        HIPCHK(lfamd_launch_gemm_q80(d_A, m, k, Btype, d_B, b_row_bytes, n, d_C, ldc, d_ws, vregs32, precise, s), "gemm_q80");
         return LFAMD_OK;
     }
     if (use_gemv(Atype, n, flags)) {

@@ -39,8 +39,8 @@ def test_small_n_vs_oracle(gpu, oracle, t, shape):
 
 @pytest.mark.parametrize("variant", ["zen4", "avx2"])
 @pytest.mark.parametrize("precise", [0, 1])
-@pytest.mark.parametrize("shape", [(64, 1, 1024), (37, 5, 4096), (128, 8, 768), (9, 2, 32), (5, 7, 96), (100, 24, 256)],
-                         ids=str)
+@pytest.mark.parametrize("shape", [(64, 1, 1024), (37, 5, 4096), (128, 8, 768), (9, 2, 32), (5, 7, 96), (100, 24, 256),
+                                   (70, 45, 224), (33, 100, 544), (257, 33, 512), (31, 9, 32)], ids=str)
 def test_q8_0_bit_exact(gpu, oracle, variant, precise, shape):
     """Q8_0 vecdot bit-exact (north star): every output equals the restated tinyBLAS_Q0_AVX2 bit for
     bit, for both reference builds (32 / 16 vector registers) and --precise."""
