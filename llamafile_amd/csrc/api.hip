@@ -355,8 +355,12 @@ int lfamd_mul_mat_id(int type, const void *d_W, long rows, long cols, int expert
     if (rows < 0 || cols < 0 || cols % lfamd_blck_size(type) || experts <= 0 || tasks <= 0 || thinkers <= 0 ||
         tasks > thinkers || thinkers > experts)
         return fail(LFAMD_ERR_INVALID, "mul_mat_id: bad shape%s", "");
-    if (Btype != lfamd_vec_dot_type(type))
-        return fail(LFAMD_ERR_UNSUPPORTED, "mul_mat_id: activations must be in the weight type's vec_dot format%s", "");
+    // f32 activations (the GGML_OP_MUL_MAT_ID boundary) are served by the decode path, which quantises in-kernel
+    const bool f32_decode = Btype == LFAMD_TYPE_F32 && tokens <= 4 && (type == LFAMD_TYPE_Q4_K || type == LFAMD_TYPE_Q6_K) &&
+                            !(flags & LFAMD_FLAG_FORCE_GENERIC);
+    if (Btype != lfamd_vec_dot_type(type) && !f32_decode)
+        return fail(LFAMD_ERR_UNSUPPORTED,
+                    "mul_mat_id: activations must be in the weight type's vec_dot format (or F32 for <= 4 tokens of K-quants)%s", "");
     if (tokens == 0 || rows == 0)
         return LFAMD_OK;
     size_t need = lfamd_moe_workspace(type, rows, cols, experts, tokens, thinkers);

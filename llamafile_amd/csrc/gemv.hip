@@ -275,6 +275,11 @@ struct gemv_mats {
     long ldc[GEMV_MAX_MATS];
     int ht_end[GEMV_MAX_MATS]; // exclusive prefix of half-tile counts
     int count;
+    // GGML_OP_MUL_MAT_ID at decode (IDS kernels only): matrix j is expert ids[id_idx[j]] of the stack at A[j]
+    const int32_t *ids;
+    long expert_bytes;
+    int id_idx[GEMV_MAX_MATS];
+    int experts;
 };
 
 #ifndef GEMV_DIAG
@@ -296,7 +301,7 @@ extern "C" int lfamd_debug_gemv_stamps(unsigned long long *dst) {
 #define GSTAMP()
 #endif
 
-template <typename TR, int NC, int BT, int NW, int GEMV_CH>
+template <typename TR, int NC, int BT, int NW, int GEMV_CH, bool IDS = false>
 __global__ __launch_bounds__(NW * 64) void gemv_kq_kernel(const gemv_mats mats, int nb, const uint8_t *__restrict__ B,
                                                           size_t b_row_bytes, long col0, int n_ht) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -328,10 +333,17 @@ __global__ __launch_bounds__(NW * 64) void gemv_kq_kernel(const gemv_mats mats, 
             if (jj < mats.count && ht >= mats.ht_end[jj - 1])
                 j = jj;
         const uint8_t *A = mats.A[j];
+        bool have = f < total;
+        if constexpr (IDS) { // expert picked on the device: no routing-table read-back, graph-capturable
+            const int ex = mats.ids[mats.id_idx[j]];
+            const bool ok = ex >= 0 && ex < mats.experts;
+            A += (size_t)(ok ? ex : 0) * mats.expert_bytes;
+            have = have && ok;
+        }
         if (j > 0)
             ht -= mats.ht_end[j - 1];
         const int hh = (int)(ht & 1);
-        const lfamd_rsrc r = make_rsrc(A + (size_t)(ht >> 1) * rt_bytes, f < total ? rt_bytes : 0u);
+        const lfamd_rsrc r = make_rsrc(A + (size_t)(ht >> 1) * rt_bytes, have ? rt_bytes : 0u);
         const int slot = h * 32 + hh * 16 + i16, hrow = hh * 16 + i16;
 #pragma unroll
         for (int s = 0; s < GEMV_CH; s++) {
@@ -386,7 +398,12 @@ __global__ __launch_bounds__(NW * 64) void gemv_kq_kernel(const gemv_mats mats, 
                 if (j > 0)
                     ht -= mats.ht_end[j - 1];
                 const long row = (ht >> 1) * 32 + (ht & 1) * 16 + i;
-                if (row < mats.m[j])
+                bool ok = true;
+                if constexpr (IDS) { // an out-of-range expert id leaves its result row untouched (the host path skips it)
+                    const int ex = mats.ids[mats.id_idx[j]];
+                    ok = ex >= 0 && ex < mats.experts;
+                }
+                if (row < mats.m[j] && ok)
                     mats.C[j][(col0 + c) * mats.ldc[j] + row] = v;
             }
         }
@@ -701,6 +718,29 @@ static hipError_t launch_kq(const gemv_mats &mats, int n_ht, long k, const void 
     return hipGetLastError();
 }
 
+template <typename TR, int BT>
+static hipError_t launch_kq_ids(const gemv_mats &mats, int n_ht, long k, const void *B, size_t brb, hipStream_t s) {
+    const int nb = (int)(k / 256);
+    constexpr int NW = 16;
+    const size_t smem = (size_t)nb * XBLK + 2 * NW * 16 * sizeof(float);
+    const int max_wg = num_cus();
+    const int per_wg = (n_ht + max_wg - 1) / max_wg;
+    const int grid = (n_ht + per_wg - 1) / per_wg;
+    if (nb <= 16) {
+        auto kernel = gemv_kq_kernel<TR, 1, BT, NW, 1, true>;
+        kernel<<<grid, NW * 64, smem, s>>>(mats, nb, (const uint8_t *)B, brb, 0, n_ht);
+    } else {
+        auto kernel = gemv_kq_kernel<TR, 1, BT, NW, 2, true>;
+        if (smem > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            if (e != hipSuccess)
+                return e;
+        }
+        kernel<<<grid, NW * 64, smem, s>>>(mats, nb, (const uint8_t *)B, brb, 0, n_ht);
+    }
+    return hipGetLastError();
+}
+
 template <typename TR, int NC, int BT>
 static hipError_t launch_kq_pick(const gemv_mats &mats, int n_ht, long k, const void *B, size_t brb, long col0,
                                  hipStream_t s) {
@@ -836,6 +876,9 @@ extern "C" hipError_t lfamd_launch_gemv_multi(int Atype, int count, const void *
     gemv_mats mats;
     int n_ht = 0;
     mats.count = 0;
+    mats.ids = nullptr, mats.expert_bytes = 0, mats.experts = 0;
+    for (int i = 0; i < GEMV_MAX_MATS; i++)
+        mats.id_idx[i] = 0;
     for (int j = 0; j < count; j++) {
         if (m[j] <= 0)
             continue;
@@ -869,6 +912,35 @@ extern "C" hipError_t lfamd_launch_gemv_multi(int Atype, int count, const void *
         }
     }
     return e;
+}
+
+// GGML_OP_MUL_MAT_ID for ONE activation row: `count` (<= GEMV_MAX_MATS) outputs C[j] = W[ids[id_idx[j]]] x B, the expert
+// index read on the device.  Q4_K / Q6_K stacks; Btype F32 or Q8_K.
+extern "C" hipError_t lfamd_launch_gemv_ids(int Atype, int count, const void *W, long expert_bytes, int experts,
+                                            const int32_t *ids, const int *id_idx, long m, long k, int Btype, const void *B,
+                                            size_t b_row_bytes, float *const *C, hipStream_t s) {
+    if (count <= 0 || count > GEMV_MAX_MATS || m <= 0 || (Atype != LFAMD_TYPE_Q4_K && Atype != LFAMD_TYPE_Q6_K))
+        return hipErrorInvalidValue;
+    if ((size_t)(k / 256) * XBLK > 150 * 1024)
+        return hipErrorInvalidValue;
+    gemv_mats mats;
+    int n_ht = 0;
+    mats.count = count;
+    mats.ids = ids, mats.expert_bytes = expert_bytes, mats.experts = experts;
+    for (int i = 0; i < GEMV_MAX_MATS; i++) {
+        const int j = i < count ? i : 0;
+        mats.A[i] = (const uint8_t *)W, mats.C[i] = C[j], mats.m[i] = i < count ? m : 0, mats.ldc[i] = m;
+        mats.id_idx[i] = id_idx[j];
+        if (i < count)
+            n_ht += (int)(((m + 31) / 32) * 2);
+        mats.ht_end[i] = n_ht;
+    }
+    const bool f32in = Btype == LFAMD_TYPE_F32;
+    if (Atype == LFAMD_TYPE_Q4_K)
+        return f32in ? launch_kq_ids<q4k_traits, LFAMD_TYPE_F32>(mats, n_ht, k, B, b_row_bytes, s)
+                     : launch_kq_ids<q4k_traits, LFAMD_TYPE_Q8_K>(mats, n_ht, k, B, b_row_bytes, s);
+    return f32in ? launch_kq_ids<q6k_traits, LFAMD_TYPE_F32>(mats, n_ht, k, B, b_row_bytes, s)
+                 : launch_kq_ids<q6k_traits, LFAMD_TYPE_Q8_K>(mats, n_ht, k, B, b_row_bytes, s);
 }
 
 extern "C" hipError_t lfamd_launch_gemv(int Atype, const void *A, long m, long k, int Btype, const void *B,

@@ -18,6 +18,8 @@
 extern "C" int lfamd_mul_mat(int, const void *, long, long, int, const void *, size_t, long, float *, long, void *, size_t,
                              unsigned, void *);
 extern "C" size_t lfamd_mul_mat_workspace(int, long, long, long);
+extern "C" hipError_t lfamd_launch_gemv_ids(int, int, const void *, long, int, const int32_t *, const int *, long, long, int,
+                                            const void *, size_t, float *const *, hipStream_t);
 
 __global__ void moe_gather_kernel(const uint8_t *__restrict__ src, size_t src_stride, size_t row_bytes,
                                   const int32_t *__restrict__ src_idx, uint8_t *__restrict__ dst, long nrows) {
@@ -60,6 +62,34 @@ extern "C" hipError_t lfamd_launch_moe(int type, const void *W, long rows, long 
                                        const int32_t *plan, int thinkers, float *result, void *ws, size_t ws_bytes,
                                        unsigned flags, hipStream_t s) {
     const size_t nr = (size_t)tokens * thinkers;
+    // ---- decode (a few tokens), K-quant experts: no read-back, no gather.  Each (token, thinker) row is a GEMV whose
+    // kernel picks the expert from the device-resident routing table; thinkers that share their activations
+    // (tasks == 1: ffn_gate / ffn_up) are fused into one launch.  Asynchronous and graph-capturable, unlike the
+    // reference's host round trip (ggml-cuda.cu.patch:18528-18531).
+    if (tokens <= 4 && (type == LFAMD_TYPE_Q4_K || type == LFAMD_TYPE_Q6_K) && !(flags & LFAMD_FLAG_FORCE_GENERIC) &&
+        (Btype == LFAMD_TYPE_F32 || Btype == LFAMD_TYPE_Q8_K) && (size_t)(cols / 256) * 368 <= 150 * 1024) {
+        for (long t = 0; t < tokens; t++) {
+            int th = 0;
+            while (th < thinkers) {
+                int cnt = 1;
+                if (tasks == 1)
+                    cnt = thinkers - th < 4 ? thinkers - th : 4;
+                int idx[4];
+                float *Cs[4];
+                for (int q = 0; q < cnt; q++) {
+                    idx[q] = (int)(t * thinkers + th + q);
+                    Cs[q] = result + (size_t)(t * thinkers + th + q) * rows;
+                }
+                const uint8_t *Brow = (const uint8_t *)thought + (size_t)(t * tasks + th % tasks) * b_row_bytes;
+                hipError_t e2 = lfamd_launch_gemv_ids(type, cnt, W, (long)expert_bytes, experts, plan, idx, rows, cols, Btype, Brow,
+                                                      b_row_bytes, Cs, s);
+                if (e2 != hipSuccess)
+                    return e2;
+                th += cnt;
+            }
+        }
+        return hipSuccess;
+    }
     std::vector<int32_t> hplan(nr);
     hipError_t e = hipMemcpyAsync(hplan.data(), plan, nr * 4, hipMemcpyDeviceToHost, s);
     if (e != hipSuccess)

@@ -173,12 +173,15 @@ def llamafile_sgemm(m: int, n: int, k: int, A: PackedWeights, lda: int, B: torch
 
 
 def mul_mat_id(Ws: torch.Tensor, wtype: int, rows: int, cols: int, experts: int, thought: torch.Tensor, Btype: int,
-               tasks: int, tokens: int, plan: torch.Tensor, thinkers: int, flags: int | None = None) -> torch.Tensor:
+               tasks: int, tokens: int, plan: torch.Tensor, thinkers: int, flags: int | None = None,
+               prefill: float | None = None) -> torch.Tensor:
     """GGML_OP_MUL_MAT_ID.  Ws: packed weights of all experts back to back; thought: uint8
     [tokens*tasks, row_bytes]; plan int32 [tokens, thinkers].  Returns f32 [tokens, thinkers, rows]."""
     L = _hip.lib()
     flags = host_variant_flags() if flags is None else flags
     res = torch.empty((tokens, thinkers, rows), dtype=torch.float32, device=thought.device)
+    if prefill is not None:  # tests: rows of out-of-range expert ids must stay untouched
+        res.fill_(prefill)
     need = L.lfamd_mul_mat_id_workspace(wtype, rows, cols, experts, tokens, thinkers)
     ws = torch.empty(max(need, 16), dtype=torch.uint8, device=thought.device)
     rc = L.lfamd_mul_mat_id(wtype, _ptr(Ws), rows, cols, experts, Btype, _ptr(thought), thought.stride(0), tasks, tokens,

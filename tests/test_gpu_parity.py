@@ -187,3 +187,43 @@ def test_experimental_lds3_gemm_variant(gpu, oracle, monkeypatch):
         ok, G = oracle.sgemm(T.Q4_K, A, bt, B, m, n, k)
         C = run_gpu(gpu, T.Q4_K, A, B, bt, m, n, k)
         assert rel_err(C, G) <= 2e-6, (m, n, k)
+
+
+@pytest.mark.parametrize("t", [T.Q4_K, T.Q6_K], ids=lambda t: T.NAMES[t])
+@pytest.mark.parametrize("tokens,tasks", [(1, 1), (1, 2), (3, 1), (2, 2)])
+@pytest.mark.parametrize("f32in", [False, True], ids=["q8k", "f32"])
+def test_mul_mat_id_decode_on_device(gpu, oracle, t, tokens, tasks, f32in):
+    """GGML_OP_MUL_MAT_ID for a few tokens: the expert is picked inside the GEMV kernel from the device-resident plan
+    (no host read-back).  result[token][thinker] = W[plan[token][thinker]] x thought[token][thinker % tasks]
+    (tinyblas_cpu_mixmul.inc:39-50); an out-of-range expert id leaves its result row untouched."""
+    from llamafile_amd import synth
+    rows, cols, experts, thinkers = 96, 512, 5, 2
+    Ws = [synth.random_weights(t, rows, cols, 900 + e) for e in range(experts)]
+    packed = torch.cat([gpu.upload_weights(t, W, rows, cols).data for W in Ws])
+    x = synth.random_activations(tokens * tasks, cols, 77)
+    vdt = T.VEC_DOT[t]
+    xq = synth.quantize_activations(vdt, x)
+    rng = np.random.default_rng(5)
+    plan = rng.integers(0, experts, size=(tokens, thinkers)).astype(np.int32)
+    if tokens > 1:
+        plan[-1, -1] = experts + 3  # invalid: skipped
+    if f32in:
+        thought = torch.from_numpy(x).cuda().view(torch.uint8).view(tokens * tasks, cols * 4)
+        bt = T.F32
+    else:
+        thought = torch.from_numpy(xq).cuda()
+        bt = vdt
+    res = gpu.mul_mat_id(packed, t, rows, cols, experts, thought, bt, tasks, tokens, torch.from_numpy(plan).cuda(), thinkers,
+                         prefill=-7.0)
+    torch.cuda.synchronize()
+    res = res.cpu().numpy()
+    for tok in range(tokens):
+        for th in range(thinkers):
+            ex = int(plan[tok, th])
+            if ex >= experts:
+                assert (res[tok, th] == -7.0).all()
+                continue
+            row = tok * tasks + th % tasks
+            ok, G = oracle.sgemm(t, Ws[ex], vdt, xq[row:row + 1], rows, 1, cols)
+            assert ok == 1
+            assert rel_err(res[tok, th], G[0]) <= DEFAULT_TOL, (tok, th)
