@@ -24,6 +24,8 @@ hipError_t lfamd_launch_gemv_multi(int, int, const void *const *, const long *, 
 hipError_t lfamd_launch_gemm_q80(const void *, long, long, int, const void *, size_t, long, float *, long, void *, int, int,
                                  hipStream_t);
 size_t lfamd_gemm_q80_workspace(long, long);
+hipError_t lfamd_launch_gemm_wide_multi(int, int, const void *const *, const long *, long, const void *, const void *,
+                                        const void *, long, long, float *const *, const long *, hipStream_t);
 hipError_t lfamd_launch_gemm_wide(int, const void *, long, long, const void *, const void *, const void *, long, long,
                                   float *, long, hipStream_t);
 hipError_t lfamd_launch_gemm_kq(int, const void *, long, long, const void *, const void *, const void *, long, long,
@@ -334,6 +336,38 @@ int lfamd_mul_mat_multi(int Atype, int count, const void *const *d_A, const long
                                        (hipStream_t)stream),
                "gemv_multi");
         return LFAMD_OK;
+    }
+    // K-quant batches: ONE activation prep for all the matrices, and one launch of the 128 x 128 body over their
+    // concatenated row blocks when that grid fills the chip (attn_q/k/v: 48 + 8 + 8 row blocks instead of three
+    // launches of which two fill a quarter of the CUs)
+    bool gfuse = count > 1 && count <= 4 && use_gemm(Atype, n, flags) && k > 0 && k % 256 == 0 &&
+                 (Btype == LFAMD_TYPE_F32 || Btype == lfamd_vec_dot_type(Atype)) && b_row_bytes >= lfamd_row_size(Btype, k) &&
+                 !(flags & LFAMD_FLAG_GEMM_NARROW);
+    long rbs = 0;
+    for (int j = 0; j < count && gfuse; j++) {
+        gfuse = m[j] >= 0 && ldc[j] >= m[j];
+        rbs += (m[j] + 127) / 128;
+    }
+    if (gfuse) {
+        hipStream_t s = (hipStream_t)stream;
+        size_t n_pad = align_up((size_t)n, 128), nb = (size_t)(k / 256);
+        gfuse = rbs * (long)(n_pad / 128) >= 192 || (flags & LFAMD_FLAG_GEMM_WIDE);
+        if (gfuse) {
+            size_t need = align_up(n_pad * (size_t)k * 2, 256) + align_up(nb * n_pad * 4, 256) + align_up(n_pad * nb * 32, 256);
+            if (ws_bytes < need || !d_ws)
+                return fail(LFAMD_ERR_WORKSPACE, "mul_mat_multi: workspace too small%s", "");
+            uint8_t *ws = (uint8_t *)d_ws;
+            void *Xh = ws;
+            void *d8T = ws + align_up(n_pad * (size_t)k * 2, 256);
+            void *Xm = (uint8_t *)d8T + align_up(nb * n_pad * 4, 256);
+            if (Btype == LFAMD_TYPE_F32)
+                HIPCHK(lfamd_launch_prep_f32(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, s), "prep_f32");
+            else
+                HIPCHK(lfamd_launch_prep_q8k(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, s), "prep_q8k");
+            HIPCHK(lfamd_launch_gemm_wide_multi(Atype, count, d_A, m, k, Xh, d8T, Xm, n, (long)n_pad, d_C, ldc, s),
+                   "gemm_wide_multi");
+            return LFAMD_OK;
+        }
     }
     for (int j = 0; j < count; j++) {
         int r = lfamd_mul_mat(Atype, d_A[j], m[j], k, Btype, d_B, b_row_bytes, n, d_C[j], ldc[j], d_ws, ws_bytes, flags, stream);

@@ -101,12 +101,22 @@ extern "C" int lfamd_debug_wide_stamps(unsigned long long *dst) {
 }
 #endif
 
+// Up to GEMM_MAX_MATS weight matrices of one type and row length that consume the SAME activations (attn_q/k/v,
+// ffn_gate/up) share one prep and one launch: their 128-row blocks are concatenated (rb_end = exclusive prefix).
+#define GEMM_MAX_MATS 4
+struct gemm_mats {
+    const uint8_t *A[GEMM_MAX_MATS];
+    float *C[GEMM_MAX_MATS];
+    long m[GEMM_MAX_MATS];
+    long ldc[GEMM_MAX_MATS];
+    int rb_end[GEMM_MAX_MATS];
+    int count;
+};
+
 template <int TYPE>
-__global__ __launch_bounds__(512) void gemm_wide_kernel(const uint8_t *__restrict__ A, long m, int nb,
-                                                        const _Float16 *__restrict__ Xh, const float *__restrict__ d8T,
-                                                        const _Float16 *__restrict__ Xm, long n, long n_pad,
-                                                        float *__restrict__ C, long ldc, int n_rb, int n_ct, int ks_n,
-                                                        int nbs) {
+__global__ __launch_bounds__(512) void gemm_wide_kernel(const gemm_mats mats, int nb, const _Float16 *__restrict__ Xh,
+                                                        const float *__restrict__ d8T, const _Float16 *__restrict__ Xm, long n,
+                                                        long n_pad, int n_rb, int n_ct, int ks_n, int nbs) {
     __shared__ __attribute__((aligned(16))) uint8_t xs[2][WD_XSTAGE];     // activation codes, XOR-swizzled rows
     __shared__ __attribute__((aligned(16))) float d8s[2][WD_COLS];        // d8 of the 128 tokens
     __shared__ __attribute__((aligned(16))) uint8_t xms[2][WD_COLS * 32]; // Q4_K mins operand rows
@@ -123,6 +133,16 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const uint8_t *__restric
     int rb, ct;
     tile_of(L - ks * n_tiles, n_rb, n_ct, rb, ct);
 
+    int mj = 0;
+#pragma unroll
+    for (int jj = 1; jj < GEMM_MAX_MATS; jj++)
+        if (jj < mats.count && rb >= mats.rb_end[jj - 1])
+            mj = jj;
+    if (mj > 0)
+        rb -= mats.rb_end[mj - 1];
+    const uint8_t *__restrict__ A = mats.A[mj];
+    float *__restrict__ C = mats.C[mj];
+    const long m = mats.m[mj], ldc = mats.ldc[mj];
     const long n_row_tiles = (m + 31) / 32;
     const int rw = wave & 3, ch = wave >> 2; // row tile and 64-token column half of this wave
     const long rt = (long)rb * 4 + rw;
@@ -433,30 +453,52 @@ extern "C" int lfamd_gemm_wide_ksplit(long m, long k, long n_pad) {
     return wide_ksplit(n_rb * n_ct, (int)(k / 256));
 }
 
-extern "C" hipError_t lfamd_launch_gemm_wide(int Atype, const void *A, long m, long k, const void *Xh, const void *d8T,
-                                             const void *Xm, long n, long n_pad, float *C, long ldc, hipStream_t s) {
-    if (m <= 0 || n <= 0)
+extern "C" hipError_t lfamd_launch_gemm_wide_multi(int Atype, int count, const void *const *A, const long *m, long k,
+                                                   const void *Xh, const void *d8T, const void *Xm, long n, long n_pad,
+                                                   float *const *C, const long *ldc, hipStream_t s) {
+    if (n <= 0 || count <= 0)
         return hipSuccess;
-    if (n_pad % WD_COLS)
+    if (n_pad % WD_COLS || count > GEMM_MAX_MATS)
         return hipErrorInvalidValue;
     const int nb = (int)(k / 256);
-    const long n_row_tiles = (m + 31) / 32;
-    const int n_rb = (int)((n_row_tiles + 3) / 4), n_ct = (int)(n_pad / WD_COLS);
+    gemm_mats mats;
+    int n_rb = 0;
+    mats.count = 0;
+    for (int j = 0; j < count; j++) {
+        if (m[j] <= 0)
+            continue;
+        const int i = mats.count++;
+        mats.A[i] = (const uint8_t *)A[j], mats.C[i] = C[j], mats.m[i] = m[j], mats.ldc[i] = ldc[j];
+        n_rb += (int)((m[j] + 127) / 128);
+        mats.rb_end[i] = n_rb;
+    }
+    if (mats.count == 0)
+        return hipSuccess;
+    for (int i = mats.count; i < GEMM_MAX_MATS; i++)
+        mats.A[i] = mats.A[0], mats.C[i] = mats.C[0], mats.m[i] = 0, mats.ldc[i] = 0, mats.rb_end[i] = n_rb;
+    const int n_ct = (int)(n_pad / WD_COLS);
     const int ks = wide_ksplit(n_rb * n_ct, nb);
     const int nbs = (nb + ks - 1) / ks;
     const int n_wg = n_rb * n_ct * ks;
     if (ks > 1) {
-        long total = m * n;
-        int blocks = (int)((total + 256 * 8 - 1) / (256 * 8));
-        zero_c_kernel<<<blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks), 256, 0, s>>>(C, ldc, m, n);
+        for (int i = 0; i < mats.count; i++) {
+            long total = mats.m[i] * n;
+            int blocks = (int)((total + 256 * 8 - 1) / (256 * 8));
+            zero_c_kernel<<<blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks), 256, 0, s>>>(mats.C[i], mats.ldc[i], mats.m[i], n);
+        }
     }
     if (Atype == LFAMD_TYPE_Q4_K)
-        gemm_wide_kernel<LFAMD_TYPE_Q4_K><<<n_wg, 512, 0, s>>>((const uint8_t *)A, m, nb, (const _Float16 *)Xh, (const float *)d8T,
-                                                                (const _Float16 *)Xm, n, n_pad, C, ldc, n_rb, n_ct, ks, nbs);
+        gemm_wide_kernel<LFAMD_TYPE_Q4_K><<<n_wg, 512, 0, s>>>(mats, nb, (const _Float16 *)Xh, (const float *)d8T,
+                                                                (const _Float16 *)Xm, n, n_pad, n_rb, n_ct, ks, nbs);
     else if (Atype == LFAMD_TYPE_Q6_K)
-        gemm_wide_kernel<LFAMD_TYPE_Q6_K><<<n_wg, 512, 0, s>>>((const uint8_t *)A, m, nb, (const _Float16 *)Xh, (const float *)d8T,
-                                                                (const _Float16 *)Xm, n, n_pad, C, ldc, n_rb, n_ct, ks, nbs);
+        gemm_wide_kernel<LFAMD_TYPE_Q6_K><<<n_wg, 512, 0, s>>>(mats, nb, (const _Float16 *)Xh, (const float *)d8T,
+                                                                (const _Float16 *)Xm, n, n_pad, n_rb, n_ct, ks, nbs);
     else
         return hipErrorInvalidValue;
     return hipGetLastError();
+}
+
+extern "C" hipError_t lfamd_launch_gemm_wide(int Atype, const void *A, long m, long k, const void *Xh, const void *d8T,
+                                             const void *Xm, long n, long n_pad, float *C, long ldc, hipStream_t s) {
+    return lfamd_launch_gemm_wide_multi(Atype, 1, &A, &m, k, Xh, d8T, Xm, n, n_pad, &C, &ldc, s);
 }

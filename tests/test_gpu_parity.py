@@ -156,6 +156,22 @@ def test_mul_mat_multi_equals_separate(gpu, t, n):
         assert np.array_equal(f.cpu().numpy().view(np.uint32), sep.cpu().numpy().view(np.uint32))
 
 
+@pytest.mark.parametrize("t", [T.Q4_K, T.Q6_K], ids=lambda t: T.NAMES[t])
+def test_mul_mat_multi_gemm_fused_launch(gpu, t):
+    """Batches: sibling mat-muls share one activation prep and ONE launch of the 128 x 128 MFMA body over their
+    concatenated row blocks; bit-identical to separate calls of the same body (ragged rows, a 7-row matrix)."""
+    from llamafile_amd import synth, _hip
+    k, n = 768, 150
+    ms = [200, 128, 7, 130]
+    Ws = [gpu.upload_weights(t, synth.random_weights(t, m, k, 160 + i), m, k) for i, m in enumerate(ms)]
+    x = torch.from_numpy(synth.random_activations(n, k, 170)).cuda()
+    flags = gpu.host_variant_flags() | _hip.FLAG_GEMM_WIDE
+    fused = gpu.mul_mat_multi(Ws, x.view(torch.uint8), T.F32, n=n, flags=flags)
+    for W, f in zip(Ws, fused):
+        sep = gpu.mul_mat(W, x.view(torch.uint8), T.F32, n=n, flags=flags)
+        assert np.array_equal(f.cpu().numpy().view(np.uint32), sep.cpu().numpy().view(np.uint32))
+
+
 @pytest.mark.parametrize("ta,tb", [(T.F32, T.F32), (T.F16, T.F16), (T.F16, T.F32), (T.BF16, T.BF16), (T.BF16, T.F32)],
                          ids=lambda t: T.NAMES[t])
 @pytest.mark.parametrize("shape", [(64, 1, 1000), (33, 2, 513), (40, 17, 256)], ids=str)
