@@ -11,6 +11,7 @@
 
 extern "C" {
 hipError_t lfamd_launch_pack_q4k(const void *, size_t, long, long, void *, hipStream_t);
+hipError_t lfamd_launch_pack_q5k(const void *, size_t, long, long, void *, hipStream_t);
 hipError_t lfamd_launch_pack_q6k(const void *, size_t, long, long, void *, hipStream_t);
 hipError_t lfamd_launch_pack_q80(const void *, size_t, long, long, void *, hipStream_t);
 hipError_t lfamd_launch_pack_raw(const void *, size_t, long, size_t, void *, hipStream_t);
@@ -148,6 +149,8 @@ size_t lfamd_packed_size(int type, long rows, long cols) {
     switch (type) {
     case LFAMD_TYPE_Q4_K:
         return (size_t)((rows + 31) / 32) * (size_t)(cols / 256) * P4K_TILE;
+    case LFAMD_TYPE_Q5_K:
+        return (size_t)((rows + 31) / 32) * (size_t)(cols / 256) * P5K_TILE;
     case LFAMD_TYPE_Q6_K:
         return (size_t)((rows + 31) / 32) * (size_t)(cols / 256) * P6K_TILE;
     case LFAMD_TYPE_Q8_0:
@@ -169,6 +172,9 @@ int lfamd_pack_weights(int type, long rows, long cols, const void *d_raw, size_t
     switch (type) {
     case LFAMD_TYPE_Q4_K:
         HIPCHK(lfamd_launch_pack_q4k(d_raw, raw_row_bytes, rows, cols, d_packed, s), "pack_q4k");
+        break;
+    case LFAMD_TYPE_Q5_K:
+        HIPCHK(lfamd_launch_pack_q5k(d_raw, raw_row_bytes, rows, cols, d_packed, s), "pack_q5k");
         break;
     case LFAMD_TYPE_Q6_K:
         HIPCHK(lfamd_launch_pack_q6k(d_raw, raw_row_bytes, rows, cols, d_packed, s), "pack_q6k");
@@ -198,7 +204,7 @@ int lfamd_quantize_rows(int vec_dot_type, const float *d_x, long nrows, long col
 static bool use_gemm(int Atype, long n, unsigned flags) {
     if (flags & LFAMD_FLAG_FORCE_GENERIC)
         return false;
-    return n > 8 && (Atype == LFAMD_TYPE_Q4_K || Atype == LFAMD_TYPE_Q6_K);
+    return n > 8 && (Atype == LFAMD_TYPE_Q4_K || Atype == LFAMD_TYPE_Q5_K || Atype == LFAMD_TYPE_Q6_K);
 }
 
 // Q8_0 batches: the register-tiled bit-exact kernel (gemm_q80.hip)
@@ -209,7 +215,8 @@ static bool use_gemm_q80(int Atype, long n, unsigned flags) {
 static bool use_gemv(int Atype, long n, unsigned flags) {
     if (flags & LFAMD_FLAG_FORCE_GENERIC)
         return false;
-    return n <= 8 && (Atype == LFAMD_TYPE_Q4_K || Atype == LFAMD_TYPE_Q6_K || Atype == LFAMD_TYPE_Q8_0);
+    return n <= 8 && (Atype == LFAMD_TYPE_Q4_K || Atype == LFAMD_TYPE_Q5_K || Atype == LFAMD_TYPE_Q6_K ||
+                      Atype == LFAMD_TYPE_Q8_0);
 }
 
 static bool gemv_quantise_separately(int Atype, long m) {
@@ -303,7 +310,7 @@ int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const v
         HIPCHK(lfamd_launch_gemv(Atype, d_A, m, k, Btype, d_B, b_row_bytes, n, d_C, ldc, vregs32, precise, s), "gemv");
         return LFAMD_OK;
     }
-    if (Atype == LFAMD_TYPE_Q4_K || Atype == LFAMD_TYPE_Q6_K || Atype == LFAMD_TYPE_Q8_0)
+    if (Atype == LFAMD_TYPE_Q4_K || Atype == LFAMD_TYPE_Q5_K || Atype == LFAMD_TYPE_Q6_K || Atype == LFAMD_TYPE_Q8_0)
         return fail(LFAMD_ERR_UNSUPPORTED, "mul_mat: FORCE_GENERIC needs RAW-layout weights; this type is packed%s", "");
     if (!float_a && Btype == LFAMD_TYPE_F32) {
         size_t qrow = lfamd_row_size(vdt, k), need = align_up((size_t)n * qrow, 256);
@@ -323,7 +330,7 @@ int lfamd_mul_mat_multi(int Atype, int count, const void *const *d_A, const long
     if (count <= 0)
         return LFAMD_OK;
     // one fused launch when the GEMV path applies to every matrix; otherwise one mul_mat per matrix
-    bool fuse = count <= 4 && n <= 8 && (Atype == LFAMD_TYPE_Q4_K || Atype == LFAMD_TYPE_Q6_K) &&
+    bool fuse = count <= 4 && n <= 8 && (Atype == LFAMD_TYPE_Q4_K || Atype == LFAMD_TYPE_Q5_K || Atype == LFAMD_TYPE_Q6_K) &&
                 !(flags & LFAMD_FLAG_FORCE_GENERIC) && (Btype == LFAMD_TYPE_F32 || Btype == lfamd_vec_dot_type(Atype)) &&
                 k > 0 && k % 256 == 0 && b_row_bytes >= lfamd_row_size(Btype, k);
     for (int j = 0; j < count && fuse; j++)

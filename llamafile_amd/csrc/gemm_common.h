@@ -39,6 +39,19 @@ __device__ static inline half8_t dequant_q4(uint32_t x, half2_t S, half2_t O, ha
     return f.v;
 }
 
+// Q5_K: the fifth bits of the K-step, already shifted onto their lattice (Hd = H >> dd, see q5hpos), join the
+// nibbles before the same fused multiply-add: sc*q <= 63*31 = 1953 stays exact in f16.
+__device__ static inline half8_t dequant_q5(uint32_t x, uint32_t Hd, half2_t S, half2_t O, half2_t S16, half2_t O16,
+                                            uint32_t magic) {
+    frag_u f;
+    const uint32_t y = x >> 8;
+    f.p[0] = pk_fma(as_half2((Hd & 0x00100010u) | ((x & 0x000F000Fu) | magic)), S, O);
+    f.p[1] = pk_fma(as_half2((Hd & 0x01000100u) | ((x & 0x00F000F0u) | magic)), S16, O16);
+    f.p[2] = pk_fma(as_half2(((Hd >> 8) & 0x00100010u) | ((y & 0x000F000Fu) | magic)), S, O);
+    f.p[3] = pk_fma(as_half2(((Hd << 8) & 0x01000100u) | ((y & 0x00F000F0u) | magic)), S16, O16);
+    return f.v;
+}
+
 __device__ static inline uint32_t opaque_magic() {
     uint32_t magic = 0x64006400u;
     asm volatile("" : "+v"(magic)); // keep it a register value (see dequant_q4)

@@ -55,7 +55,8 @@ __global__ __launch_bounds__(512) void gemm_kq_kernel(const uint8_t *__restrict_
     // per K-group two activation tiles (64 tokens x 256 codes, f16): the global->LDS copy of the next
     // super-block runs under the MFMAs of the current one.  2 x 2 x 32 KiB = 128 KiB.
     __shared__ __attribute__((aligned(16))) uint8_t xt[GEMM_KG][2][TOK_TILE * XT_ROW_BYTES];
-    constexpr int TILE = TYPE == LFAMD_TYPE_Q4_K ? P4K_TILE : P6K_TILE;
+    constexpr int TILE = TYPE == LFAMD_TYPE_Q4_K ? P4K_TILE : TYPE == LFAMD_TYPE_Q5_K ? P5K_TILE : P6K_TILE;
+    constexpr bool MINS = TYPE == LFAMD_TYPE_Q4_K || TYPE == LFAMD_TYPE_Q5_K; // Q4_K family: {d, dmin, 6-bit scales/mins}
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int kg = wave >> 2, rw = wave & 3; // K-group, row-tile inside the work-group
     const int i = lane & 31, h = lane >> 5;
@@ -99,8 +100,10 @@ __global__ __launch_bounds__(512) void gemm_kq_kernel(const uint8_t *__restrict_
 #pragma unroll
         for (int g = 0; g < 4; g++)
             w.qs[g] = *(const uint4 *)(tile + g * 1024 + lane * 16);
-        if constexpr (TYPE == LFAMD_TYPE_Q4_K) {
-            w.hd = *(const uint4 *)(tile + P4K_HDR + i * 16);
+        if constexpr (MINS) {
+            w.hd = *(const uint4 *)(tile + P4K_HDR + i * 16); // P5K_HDR == P4K_HDR
+            if constexpr (TYPE == LFAMD_TYPE_Q5_K)
+                w.qh[0] = *(const uint4 *)(tile + P5K_QH + lane * 16);
         } else {
             w.qh[0] = *(const uint4 *)(tile + P6K_QH + 0 * 1024 + lane * 16);
             w.qh[1] = *(const uint4 *)(tile + P6K_QH + 1 * 1024 + lane * 16);
@@ -118,6 +121,8 @@ __global__ __launch_bounds__(512) void gemm_kq_kernel(const uint8_t *__restrict_
         for (int g = 0; g < 4; g++)
             asm volatile("" : "+v"(w.qs[g].x), "+v"(w.qs[g].y), "+v"(w.qs[g].z), "+v"(w.qs[g].w));
         asm volatile("" : "+v"(w.hd.x), "+v"(w.hd.y), "+v"(w.hd.z), "+v"(w.hd.w));
+        if constexpr (TYPE == LFAMD_TYPE_Q5_K)
+            asm volatile("" : "+v"(w.qh[0].x), "+v"(w.qh[0].y), "+v"(w.qh[0].z), "+v"(w.qh[0].w));
         if constexpr (TYPE == LFAMD_TYPE_Q6_K) {
             asm volatile("" : "+v"(w.qh[0].x), "+v"(w.qh[0].y), "+v"(w.qh[0].z), "+v"(w.qh[0].w));
             asm volatile("" : "+v"(w.qh[1].x), "+v"(w.qh[1].y), "+v"(w.qh[1].z), "+v"(w.qh[1].w));
@@ -127,7 +132,7 @@ __global__ __launch_bounds__(512) void gemm_kq_kernel(const uint8_t *__restrict_
     };
     auto load_scales = [&](int it, sregs &sr) {
         const int b = it * GEMM_KG + kg;
-        if constexpr (TYPE == LFAMD_TYPE_Q4_K) {
+        if constexpr (MINS) {
 #pragma unroll
             for (int nt = 0; nt < 2; nt++)
                 sr.xm[nt] = *(const half8_t *)(Xm + ((size_t)b * n_pad + n0 + nt * 32 + i) * 16 + 8 * h);
@@ -164,8 +169,10 @@ __global__ __launch_bounds__(512) void gemm_kq_kernel(const uint8_t *__restrict_
         float16_t_ tmp[2]; // first K-step accumulates onto the constant 0 (an inline operand, no register init)
         const uint32_t qw[16] = {w.qs[0].x, w.qs[0].y, w.qs[0].z, w.qs[0].w, w.qs[1].x, w.qs[1].y, w.qs[1].z, w.qs[1].w,
                                  w.qs[2].x, w.qs[2].y, w.qs[2].z, w.qs[2].w, w.qs[3].x, w.qs[3].y, w.qs[3].z, w.qs[3].w};
-        if constexpr (TYPE == LFAMD_TYPE_Q4_K) {
+        if constexpr (MINS) {
             const uint4 hd = w.hd;
+            const uint32_t hq5[4] = {w.qh[0].x, w.qh[0].y, w.qh[0].z, w.qh[0].w}; // Q5_K only
+            (void)hq5;
             const float d = h2f((uint16_t)(hd.x & 0xffff)), dmin = h2f((uint16_t)(hd.x >> 16));
             uint32_t sc03, sc47, mn03, mn47;
             q4k_scales_bytes(hd.y, hd.z, hd.w, sc03, sc47, mn03, mn47);
@@ -177,7 +184,11 @@ __global__ __launch_bounds__(512) void gemm_kq_kernel(const uint8_t *__restrict_
 #pragma unroll
                 for (int e = 0; e < 2; e++) {
                     const int t = 2 * j + e;
-                    const half8_t wf = dequant_q4(qw[t], S, O, S16, O16, magic);
+                    half8_t wf;
+                    if constexpr (TYPE == LFAMD_TYPE_Q5_K)
+                        wf = dequant_q5(qw[t], hq5[t >> 2] >> (t & 3), S, O, S16, O16, magic);
+                    else
+                        wf = dequant_q4(qw[t], S, O, S16, O16, magic);
 #pragma unroll
                     for (int nt = 0; nt < 2; nt++) {
                         const half8_t xf = *(const half8_t *)(xb + xoff[t & 7] + nt * 32 * XT_ROW_BYTES + ((2 * t) & 16) * 16);
@@ -535,6 +546,10 @@ extern "C" hipError_t lfamd_launch_gemm_kq(int Atype, const void *A, long m, lon
                                                               n_wg);
     } else if (Atype == LFAMD_TYPE_Q4_K)
         gemm_kq_kernel<LFAMD_TYPE_Q4_K><<<n_wg, 512, 0, s>>>((const uint8_t *)A, m, nb, (const _Float16 *)Xh,
+                                                               (const float *)d8T, (const _Float16 *)Xm, n, n_pad, C, ldc,
+                                                               n_rb, n_wg);
+    else if (Atype == LFAMD_TYPE_Q5_K)
+        gemm_kq_kernel<LFAMD_TYPE_Q5_K><<<n_wg, 512, 0, s>>>((const uint8_t *)A, m, nb, (const _Float16 *)Xh,
                                                                (const float *)d8T, (const _Float16 *)Xm, n, n_pad, C, ldc,
                                                                n_rb, n_wg);
     else if (Atype == LFAMD_TYPE_Q6_K)

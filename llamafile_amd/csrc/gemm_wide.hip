@@ -120,7 +120,8 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const gemm_mats mats, in
     __shared__ __attribute__((aligned(16))) uint8_t xs[2][WD_XSTAGE];     // activation codes, XOR-swizzled rows
     __shared__ __attribute__((aligned(16))) float d8s[2][WD_COLS];        // d8 of the 128 tokens
     __shared__ __attribute__((aligned(16))) uint8_t xms[2][WD_COLS * 32]; // Q4_K mins operand rows
-    constexpr int TILE = TYPE == LFAMD_TYPE_Q4_K ? P4K_TILE : P6K_TILE;
+    constexpr int TILE = TYPE == LFAMD_TYPE_Q4_K ? P4K_TILE : TYPE == LFAMD_TYPE_Q5_K ? P5K_TILE : P6K_TILE;
+    constexpr bool MINS = TYPE == LFAMD_TYPE_Q4_K || TYPE == LFAMD_TYPE_Q5_K; // Q4_K family: {d, dmin, 6-bit scales/mins}
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 31, h = lane >> 5;
 
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const gemm_mats mats, in
         const int nn = 16 * wave + 2 * e + h;
         xo[e] = (uint32_t)(nn * 512 + ((i ^ (nn & 15)) * 16));
     }
-    const uint32_t wo = lane * 16, ho = i * 16 + (TYPE == LFAMD_TYPE_Q4_K ? P4K_HDR : P6K_SC) - 4096;
+    const uint32_t wo = lane * 16, ho = i * 16 + (MINS ? P4K_HDR : P6K_SC) - 4096; // P5K_HDR == P4K_HDR
     const uint32_t xmo = (uint32_t)((32 * (wave & 3) + (lane >> 1)) * 32 + (lane & 1) * 16);
     const uint8_t *xbase = (const uint8_t *)Xh + (size_t)n0 * 512;           // + b * n_pad * 512
     const uint8_t *wbase = A + (size_t)(active ? rt : 0) * nb * TILE;
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const gemm_mats mats, in
         glds4(xb, dst + 4096, xo[4], xo[5], xo[6], xo[7]);
         if (wave >= 6) // d8 of tokens 64*(wave-6) + lane
             glds1x4(uniform_ptr(d8T + (size_t)b * n_pad + n0), d8_a[st] + (wave - 6) * 256, (uint32_t)((wave - 6) * 256 + lane * 4));
-        if constexpr (TYPE == LFAMD_TYPE_Q4_K) {
+        if constexpr (MINS) {
             if (wave < 4)
                 glds1x16(uniform_ptr(xmbase + (size_t)b * n_pad * 32), xm_a[st] + wave * 1024, xmo);
         }
@@ -192,8 +193,10 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const gemm_mats mats, in
         gload16<1024>(w.qs[1], tile, wo);
         gload16<2048>(w.qs[2], tile, wo);
         gload16<3072>(w.qs[3], tile, wo);
-        if constexpr (TYPE == LFAMD_TYPE_Q4_K) {
+        if constexpr (MINS) {
             gload16<0>(w.hd, tile_h, ho);
+            if constexpr (TYPE == LFAMD_TYPE_Q5_K)
+                gload16<512>(w.qh[0], tile_h, wo); // P5K_QH = 4608
         } else {
             gload16<0>(w.qh[0], tile_h, wo);    // P6K_QH = 4096
             gload16<1024>(w.qh[1], tile_h, wo);
@@ -214,8 +217,10 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const gemm_mats mats, in
             gload16<1024>(w.qs[1], tile, wo);
             gload16<2048>(w.qs[2], tile, wo);
             gload16<3072>(w.qs[3], tile, wo);
-            if constexpr (TYPE == LFAMD_TYPE_Q4_K) {
+            if constexpr (MINS) {
                 gload16<0>(w.hd, tile_h, ho);
+                if constexpr (TYPE == LFAMD_TYPE_Q5_K)
+                    gload16<512>(w.qh[0], tile_h, wo);
             } else {
                 gload16<0>(w.qh[0], tile_h, wo);
                 gload16<1024>(w.qh[1], tile_h, wo);
@@ -229,7 +234,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const gemm_mats mats, in
             if (wave >= 6)
                 glds1x4(uniform_ptr(d8T + (size_t)b * n_pad + n0), d8_a[st] + (wave - 6) * 256, (uint32_t)((wave - 6) * 256 + lane * 4));
         } else if (t == 10) {
-            if constexpr (TYPE == LFAMD_TYPE_Q4_K) {
+            if constexpr (MINS) {
                 if (wave < 4)
                     glds1x16(uniform_ptr(xmbase + (size_t)b * n_pad * 32), xm_a[st] + wave * 1024, xmo);
             }
@@ -241,6 +246,11 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const gemm_mats mats, in
         if constexpr (TYPE == LFAMD_TYPE_Q4_K)
             asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier"
                          : "+v"(w.qs[0]), "+v"(w.qs[1]), "+v"(w.qs[2]), "+v"(w.qs[3]), "+v"(w.hd)
+                         :
+                         : "memory");
+        else if constexpr (TYPE == LFAMD_TYPE_Q5_K)
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier"
+                         : "+v"(w.qs[0]), "+v"(w.qs[1]), "+v"(w.qs[2]), "+v"(w.qs[3]), "+v"(w.hd), "+v"(w.qh[0])
                          :
                          : "memory");
         else
@@ -286,7 +296,9 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const gemm_mats mats, in
         float16_t_ tmp[2];
         const uint32_t qw[16] = {w.qs[0].x, w.qs[0].y, w.qs[0].z, w.qs[0].w, w.qs[1].x, w.qs[1].y, w.qs[1].z, w.qs[1].w,
                                  w.qs[2].x, w.qs[2].y, w.qs[2].z, w.qs[2].w, w.qs[3].x, w.qs[3].y, w.qs[3].z, w.qs[3].w};
-        if constexpr (TYPE == LFAMD_TYPE_Q4_K) {
+        if constexpr (MINS) {
+            const uint32_t hq5[4] = {w.qh[0].x, w.qh[0].y, w.qh[0].z, w.qh[0].w}; // Q5_K only
+            (void)hq5;
             const float d = h2f((uint16_t)(w.hd.x & 0xffff)), dmin = h2f((uint16_t)(w.hd.x >> 16));
             uint32_t sc03, sc47, mn03, mn47;
             q4k_scales_bytes(w.hd.y, w.hd.z, w.hd.w, sc03, sc47, mn03, mn47);
@@ -300,7 +312,11 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const gemm_mats mats, in
 #pragma unroll
                 for (int e = 0; e < 2; e++) {
                     const int t = 2 * j + e;
-                    const half8_t wf = dequant_q4(qw[t], S, O, S16, O16, magic);
+                    half8_t wf;
+                    if constexpr (TYPE == LFAMD_TYPE_Q5_K)
+                        wf = dequant_q5(qw[t], hq5[t >> 2] >> (t & 3), S, O, S16, O16, magic);
+                    else
+                        wf = dequant_q4(qw[t], S, O, S16, O16, magic);
                     if (t + 1 < 16) {
                         read_frags(F[(t + 1) & 1], t + 1);
                         ds_wait<2>(F[t & 1][0], F[t & 1][1]);
@@ -489,6 +505,9 @@ extern "C" hipError_t lfamd_launch_gemm_wide_multi(int Atype, int count, const v
     }
     if (Atype == LFAMD_TYPE_Q4_K)
         gemm_wide_kernel<LFAMD_TYPE_Q4_K><<<n_wg, 512, 0, s>>>(mats, nb, (const _Float16 *)Xh, (const float *)d8T,
+                                                                (const _Float16 *)Xm, n, n_pad, n_rb, n_ct, ks, nbs);
+    else if (Atype == LFAMD_TYPE_Q5_K)
+        gemm_wide_kernel<LFAMD_TYPE_Q5_K><<<n_wg, 512, 0, s>>>(mats, nb, (const _Float16 *)Xh, (const float *)d8T,
                                                                 (const _Float16 *)Xm, n, n_pad, n_rb, n_ct, ks, nbs);
     else if (Atype == LFAMD_TYPE_Q6_K)
         gemm_wide_kernel<LFAMD_TYPE_Q6_K><<<n_wg, 512, 0, s>>>(mats, nb, (const _Float16 *)Xh, (const float *)d8T,

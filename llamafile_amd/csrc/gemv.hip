@@ -215,6 +215,56 @@ struct q4k_traits {
     }
 };
 
+// Q5_K: Q4_K with a fifth bit per weight (DequantizerQ5K, iqk_mul_mat.inc:496-511): codes 0..31, same scales / mins.
+struct q5k_traits {
+    static constexpr int TILE = P5K_TILE;
+    struct chunk {
+        uint4 q0[GEMV_CH_MAX], q1[GEMV_CH_MAX], hd[GEMV_CH_MAX];
+        uint2 hq[GEMV_CH_MAX];
+    };
+    __device__ static inline void load(chunk &ch, int s, lfamd_rsrc r, uint32_t off, int gsel, int slot, int hrow) {
+        ch.q0[s] = buf_ld16_nt(r, off + (2 * gsel + 0) * 1024 + slot * 16);
+        ch.q1[s] = buf_ld16_nt(r, off + (2 * gsel + 1) * 1024 + slot * 16);
+        ch.hd[s] = buf_ld16_nt(r, off + P5K_HDR + hrow * 16);
+        ch.hq[s] = buf_ld8(r, off + P5K_QH + slot * 16 + gsel * 8); // fifth bits of groups 2 gsel, 2 gsel + 1
+    }
+    __device__ static inline float dot(const chunk &ch, int s, const uint8_t *xb, int gsel, int h) {
+        const uint4 q0 = ch.q0[s], q1 = ch.q1[s], hd = ch.hd[s];
+        const uint32_t hw[2] = {ch.hq[s].x, ch.hq[s].y};
+        const float d = h2f((uint16_t)(hd.x & 0xffff)), dmin = h2f((uint16_t)(hd.x >> 16));
+        uint32_t sc03, sc47, mn03, mn47;
+        q4k_scales_bytes(hd.y, hd.z, hd.w, sc03, sc47, mn03, mn47);
+        const uint32_t scw = gsel ? sc47 : sc03, mnw = gsel ? mn47 : mn03;
+        const uint32_t qw[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+        const uint4 *yq = (const uint4 *)(xb + 128 * gsel + 64 * h);
+        const uint4 ya = yq[0], yb = yq[1], yc = yq[2], yd = yq[3];
+        const uint32_t yw[16] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w,
+                                 yc.x, yc.y, yc.z, yc.w, yd.x, yd.y, yd.z, yd.w};
+        const uint2 psw = *(const uint2 *)(xb + XBLK_PS + 16 * gsel + 8 * h);
+        const int ps[4] = {(int)(int16_t)(psw.x & 0xffff), (int)(int16_t)(psw.x >> 16), (int)(int16_t)(psw.y & 0xffff),
+                           (int)(int16_t)(psw.y >> 16)};
+        int sumi = 0, summ = 0;
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) { // jj = 2 gi + e
+            int isum = 0;
+#pragma unroll
+            for (int d2 = 0; d2 < 2; d2++) {
+                const int t8 = 2 * jj + d2; // = 4 gi + dd
+                const uint32_t x = qw[t8];
+                const uint32_t Hd = hw[t8 >> 2] >> (t8 & 3);
+                const uint32_t c0 = (x & 0x0F0F0F0F) | (Hd & 0x10101010);
+                const uint32_t c1 = ((x >> 4) & 0x0F0F0F0F) | ((Hd >> 4) & 0x00100010) | ((Hd << 12) & 0x10001000);
+                isum = sdot4(c0, yw[2 * t8], isum);
+                isum = sdot4(c1, yw[2 * t8 + 1], isum);
+            }
+            sumi += (int)((scw >> (8 * jj)) & 0xff) * isum;
+            summ += (int)((mnw >> (8 * jj)) & 0xff) * ps[jj];
+        }
+        const float d8 = *(const float *)(xb + XBLK_D);
+        return fmaf(d * d8, (float)sumi, -(dmin * d8) * (float)summ);
+    }
+};
+
 // Q6_K: sub-blocks are 16 wide (one per K-step), codes are 6 bit, offset -32 handled as
 // sum sc*(dot(code,q8) - 32*sum(q8)) like DequantizerQ6K (iqk_mul_mat.inc:570-599).
 struct q6k_traits {
@@ -769,6 +819,11 @@ static hipError_t launch_q4k(const gemv_mats &mats, int n_ht, long k, const void
 }
 
 template <int NC, int BT>
+static hipError_t launch_q5k(const gemv_mats &mats, int n_ht, long k, const void *B, size_t brb, long col0, hipStream_t s) {
+    return launch_kq_pick<q5k_traits, NC, BT>(mats, n_ht, k, B, brb, col0, s);
+}
+
+template <int NC, int BT>
 static hipError_t launch_q6k(const gemv_mats &mats, int n_ht, long k, const void *B, size_t brb, long col0, hipStream_t s) {
     return launch_kq_pick<q6k_traits, NC, BT>(mats, n_ht, k, B, brb, col0, s);
 }
@@ -871,7 +926,7 @@ extern "C" hipError_t lfamd_launch_gemv_multi(int Atype, int count, const void *
         }
         return e;
     }
-    if (count > GEMV_MAX_MATS || (Atype != LFAMD_TYPE_Q4_K && Atype != LFAMD_TYPE_Q6_K))
+    if (count > GEMV_MAX_MATS || (Atype != LFAMD_TYPE_Q4_K && Atype != LFAMD_TYPE_Q5_K && Atype != LFAMD_TYPE_Q6_K))
         return hipErrorInvalidValue;
     gemv_mats mats;
     int n_ht = 0;
@@ -902,6 +957,12 @@ extern "C" hipError_t lfamd_launch_gemv_multi(int Atype, int count, const void *
                 DISPATCH_NC(launch_q4k, LFAMD_TYPE_F32, nc, mats, n_ht, k, B, b_row_bytes, col0, s)
             } else {
                 DISPATCH_NC(launch_q4k, LFAMD_TYPE_Q8_K, nc, mats, n_ht, k, B, b_row_bytes, col0, s)
+            }
+        } else if (Atype == LFAMD_TYPE_Q5_K) {
+            if (f32in) {
+                DISPATCH_NC(launch_q5k, LFAMD_TYPE_F32, nc, mats, n_ht, k, B, b_row_bytes, col0, s)
+            } else {
+                DISPATCH_NC(launch_q5k, LFAMD_TYPE_Q8_K, nc, mats, n_ht, k, B, b_row_bytes, col0, s)
             }
         } else {
             if (f32in) {

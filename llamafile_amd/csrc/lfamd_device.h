@@ -27,6 +27,9 @@
 
 #define P4K_TILE 4608
 #define P4K_HDR 4096
+#define P5K_TILE 5632 // P4K (qs 4096 + hdr 512) + 1024 B of fifth bits
+#define P5K_HDR 4096
+#define P5K_QH 4608
 #define P6K_TILE 6720
 #define P6K_QH 4096
 #define P6K_SC 6144
@@ -37,6 +40,17 @@
 // nibble slot of element j (0..7) inside a K-step dword: pairs (j0,j1),(j2,j3),.. sit 16 bits apart
 // so that (x & 0x000F000F) | 0x64006400 is the f16 pair (1024+q0, 1024+q1) with no shuffling.
 #define NIBPOS(j) (((j) >> 1) + 4 * ((j)&1))
+
+// Q5_K fifth bits: lane (i, h) owns one dword per group g of four K-steps; the bit of element j of K-step dd sits
+// at 4*Q5HPOS(j) + dd, so (H >> dd) has the K-step's eight bits on a 4-bit lattice where
+//   GEMM: (Hd & 0x00100010) joins pair (j0,j1), (Hd & 0x01000100) pair (j2,j3) [value bits 7:4],
+//         ((Hd >> 8) & 0x00100010) pair (j4,j5), ((Hd << 8) & 0x01000100) pair (j6,j7)
+//   GEMV: (Hd & 0x10101010) joins the bytes (j0,j4,j1,j5) of x & 0x0F0F0F0F, and
+//         ((Hd >> 4) & 0x00100010) | ((Hd << 12) & 0x10001000) the bytes (j2,j6,j3,j7) of (x >> 4) & 0x0F0F0F0F
+__host__ __device__ static inline int q5hpos(int j) {
+    const int p[8] = {1, 5, 2, 6, 3, 7, 0, 4};
+    return p[j];
+}
 
 // bit of the 2-bit high field of element j of K-step (dd&1) inside the qh dword of K-step pair dd>>1
 //   half (j&1)*16, field {2,4,6,0}[j>>1] + (dd&1), two bits each

@@ -53,6 +53,69 @@ __global__ void pack_q4k_kernel(const uint8_t *__restrict__ raw, size_t raw_row_
 }
 
 // ---------------------------------------------------------------------------------------------
+// Q5_K -> P5K: the P4K image of the low nibbles and the header, then one dword of fifth bits per (lane, group).
+// block_q5_K = {d, dmin, scales[12], qh[32], qs[128]}: weight l of sub-block j has its fifth bit at bit j of qh[l].
+
+__global__ void pack_q5k_kernel(const uint8_t *__restrict__ raw, size_t raw_row_bytes, long rows, int nb,
+                                uint8_t *__restrict__ out, long n_tiles) {
+    long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long tile = tid / 1408; // 1024 qs dwords + 128 header dwords + 256 fifth-bit dwords
+    int w = (int)(tid % 1408);
+    if (tile >= n_tiles)
+        return;
+    long rt = tile / nb;
+    int b = (int)(tile % nb);
+    uint32_t *dst = (uint32_t *)(out + tile * P5K_TILE);
+    if (w < 1024) {
+        int g = w >> 8, lane = (w >> 2) & 63, dd = w & 3;
+        int i = lane & 31, h = lane >> 5;
+        long row = rt * 32 + i;
+        uint32_t v = 0;
+        if (row < rows) {
+            const lfamd_block_q5_K *blk = (const lfamd_block_q5_K *)(raw + row * raw_row_bytes) + b;
+            int t = 4 * g + dd;
+            for (int j = 0; j < 8; j++) {
+                int k = 16 * t + 8 * h + j;
+                int c = k >> 6, wi = k & 63;
+                uint8_t byte = blk->qs[32 * c + (wi & 31)];
+                uint32_t nib = wi < 32 ? (byte & 15u) : (uint32_t)(byte >> 4);
+                v |= nib << (4 * NIBPOS(j));
+            }
+        }
+        dst[w] = v;
+    } else if (w < 1152) {
+        int s = w - 1024; // header dword: the block's first 16 bytes {d, dmin, scales[12]}
+        int i = s >> 2, q = s & 3;
+        long row = rt * 32 + i;
+        uint32_t v = 0;
+        if (row < rows) {
+            const uint8_t *blk = raw + row * raw_row_bytes + (size_t)b * sizeof(lfamd_block_q5_K);
+            const uint16_t *p = (const uint16_t *)(blk + 4 * q);
+            v = (uint32_t)p[0] | ((uint32_t)p[1] << 16);
+        }
+        dst[1024 + s] = v;
+    } else {
+        int s = w - 1152; // lane * 4 + g
+        int lane = s >> 2, g = s & 3;
+        int i = lane & 31, h = lane >> 5;
+        long row = rt * 32 + i;
+        uint32_t v = 0;
+        if (row < rows) {
+            const lfamd_block_q5_K *blk = (const lfamd_block_q5_K *)(raw + row * raw_row_bytes) + b;
+            for (int dd = 0; dd < 4; dd++) {
+                int t = 4 * g + dd, sub = t >> 1;
+                for (int j = 0; j < 8; j++) {
+                    int l = 16 * (t & 1) + 8 * h + j;
+                    uint32_t bit = (blk->qh[l] >> sub) & 1u;
+                    v |= bit << (4 * q5hpos(j) + dd);
+                }
+            }
+        }
+        dst[1152 + s] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Q6_K -> P6K
 
 __device__ static inline int q6k_code(const lfamd_block_q6_K *blk, int k) { // 0..63
@@ -307,6 +370,15 @@ hipError_t lfamd_launch_pack_q4k(const void *raw, size_t raw_row_bytes, long row
     long n_tiles = ((rows + 31) / 32) * nb;
     long threads = n_tiles * 1152;
     pack_q4k_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>((const uint8_t *)raw, raw_row_bytes, rows, nb,
+                                                                        (uint8_t *)out, n_tiles);
+    return hipGetLastError();
+}
+
+hipError_t lfamd_launch_pack_q5k(const void *raw, size_t raw_row_bytes, long rows, long cols, void *out, hipStream_t s) {
+    int nb = (int)(cols / 256);
+    long n_tiles = ((rows + 31) / 32) * nb;
+    long threads = n_tiles * 1408;
+    pack_q5k_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>((const uint8_t *)raw, raw_row_bytes, rows, nb,
                                                                         (uint8_t *)out, n_tiles);
     return hipGetLastError();
 }

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 TOL = {T.Q4_1: 1e-5, T.Q5_1: 1e-5}
 DEFAULT_TOL = 2e-6
 # north-star tolerance: logits within 1e-3 relative; Q6_K's MFMA operand rounds sc*(q-32) > 2048
-GEMM_TOL = {T.Q4_K: 2e-6, T.Q6_K: 1e-3}
+GEMM_TOL = {T.Q4_K: 2e-6, T.Q5_K: 2e-6, T.Q6_K: 1e-3}
 
 
 def run_gpu(gpu, t, A, B, bt, m, n, k, flags=None):
@@ -63,7 +63,7 @@ def test_q8_0_bit_exact(gpu, oracle, variant, precise, shape):
     assert not np.isnan(C).any()
 
 
-@pytest.mark.parametrize("t", [T.Q4_K, T.Q6_K], ids=lambda t: T.NAMES[t])
+@pytest.mark.parametrize("t", [T.Q4_K, T.Q5_K, T.Q6_K], ids=lambda t: T.NAMES[t])
 @pytest.mark.parametrize("shape", [(128, 64, 512), (96, 100, 1024), (33, 9, 256), (256, 512, 2048), (64, 130, 768)],
                          ids=str)
 @pytest.mark.parametrize("body", ["narrow", "wide"])
@@ -81,7 +81,7 @@ def test_mfma_gemm_vs_oracle(gpu, oracle, t, shape, body):
     assert rel_err(C, G) <= GEMM_TOL[t], (T.NAMES[t], shape, rel_err(C, G))
 
 
-@pytest.mark.parametrize("t", [T.Q4_K, T.Q6_K], ids=lambda t: T.NAMES[t])
+@pytest.mark.parametrize("t", [T.Q4_K, T.Q5_K, T.Q6_K], ids=lambda t: T.NAMES[t])
 def test_mfma_bodies_agree_and_repeat(gpu, t):
     """Same inputs -> the wide body gives identical bits on every run (no atomics in the default K split), and
     the two bodies agree to the f32 summation-order tolerance.  Odd super-block count, ragged rows and tokens."""
@@ -140,7 +140,7 @@ def test_f32_activations_equal_prequantised(gpu, t, n):
     assert np.array_equal(c_f32.view(np.uint32), c_q.view(np.uint32))
 
 
-@pytest.mark.parametrize("t", [T.Q4_K, T.Q6_K], ids=lambda t: T.NAMES[t])
+@pytest.mark.parametrize("t", [T.Q4_K, T.Q5_K, T.Q6_K], ids=lambda t: T.NAMES[t])
 @pytest.mark.parametrize("n", [1, 4, 20])
 def test_mul_mat_multi_equals_separate(gpu, t, n):
     """Sibling mat-muls fused into one launch (attn_q/k/v, ffn_gate/up) give bit-identical results to
@@ -156,7 +156,7 @@ def test_mul_mat_multi_equals_separate(gpu, t, n):
         assert np.array_equal(f.cpu().numpy().view(np.uint32), sep.cpu().numpy().view(np.uint32))
 
 
-@pytest.mark.parametrize("t", [T.Q4_K, T.Q6_K], ids=lambda t: T.NAMES[t])
+@pytest.mark.parametrize("t", [T.Q4_K, T.Q5_K, T.Q6_K], ids=lambda t: T.NAMES[t])
 def test_mul_mat_multi_gemm_fused_launch(gpu, t):
     """Batches: sibling mat-muls share one activation prep and ONE launch of the 128 x 128 MFMA body over their
     concatenated row blocks; bit-identical to separate calls of the same body (ragged rows, a 7-row matrix)."""
