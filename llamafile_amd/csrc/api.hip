@@ -11,6 +11,8 @@
 
 extern "C" {
 hipError_t lfamd_launch_pack_q4k(const void *, size_t, long, long, void *, hipStream_t);
+hipError_t lfamd_launch_pack_q40(const void *, size_t, long, long, void *, hipStream_t);
+hipError_t lfamd_launch_prep80(int, const void *, size_t, long, long, long, void *, void *, hipStream_t);
 hipError_t lfamd_launch_pack_q5k(const void *, size_t, long, long, void *, hipStream_t);
 hipError_t lfamd_launch_pack_q6k(const void *, size_t, long, long, void *, hipStream_t);
 hipError_t lfamd_launch_pack_q80(const void *, size_t, long, long, void *, hipStream_t);
@@ -149,6 +151,10 @@ size_t lfamd_packed_size(int type, long rows, long cols) {
     switch (type) {
     case LFAMD_TYPE_Q4_K:
         return (size_t)((rows + 31) / 32) * (size_t)(cols / 256) * P4K_TILE;
+    case LFAMD_TYPE_Q4_0:
+        if (cols % 256 == 0) // P40; other row lengths stay RAW (generic kernels)
+            return (size_t)((rows + 31) / 32) * (size_t)(cols / 256) * P4K_TILE;
+        return (size_t)rows * lfamd_row_size(type, cols);
     case LFAMD_TYPE_Q5_K:
         return (size_t)((rows + 31) / 32) * (size_t)(cols / 256) * P5K_TILE;
     case LFAMD_TYPE_Q6_K:
@@ -172,6 +178,13 @@ int lfamd_pack_weights(int type, long rows, long cols, const void *d_raw, size_t
     switch (type) {
     case LFAMD_TYPE_Q4_K:
         HIPCHK(lfamd_launch_pack_q4k(d_raw, raw_row_bytes, rows, cols, d_packed, s), "pack_q4k");
+        break;
+    case LFAMD_TYPE_Q4_0:
+        if (cols % 256 == 0) {
+            HIPCHK(lfamd_launch_pack_q40(d_raw, raw_row_bytes, rows, cols, d_packed, s), "pack_q40");
+        } else {
+            HIPCHK(lfamd_launch_pack_raw(d_raw, raw_row_bytes, rows, lfamd_row_size(type, cols), d_packed, s), "pack_raw");
+        }
         break;
     case LFAMD_TYPE_Q5_K:
         HIPCHK(lfamd_launch_pack_q5k(d_raw, raw_row_bytes, rows, cols, d_packed, s), "pack_q5k");
@@ -201,10 +214,15 @@ int lfamd_quantize_rows(int vec_dot_type, const float *d_x, long nrows, long col
 
 // ---------------------------------------------------------------------------------------------
 
-static bool use_gemm(int Atype, long n, unsigned flags) {
+// Q4_0 rows that are whole 256-weight groups are kept in the P40 layout and served by the tuned kernels
+static bool packed40(int Atype, long k) {
+    return Atype == LFAMD_TYPE_Q4_0 && k % 256 == 0;
+}
+
+static bool use_gemm(int Atype, long n, unsigned flags, long k) {
     if (flags & LFAMD_FLAG_FORCE_GENERIC)
         return false;
-    return n > 8 && (Atype == LFAMD_TYPE_Q4_K || Atype == LFAMD_TYPE_Q5_K || Atype == LFAMD_TYPE_Q6_K);
+    return n > 8 && (Atype == LFAMD_TYPE_Q4_K || Atype == LFAMD_TYPE_Q5_K || Atype == LFAMD_TYPE_Q6_K || packed40(Atype, k));
 }
 
 // Q8_0 batches: the register-tiled bit-exact kernel (gemm_q80.hip)
@@ -212,11 +230,11 @@ static bool use_gemm_q80(int Atype, long n, unsigned flags) {
     return !(flags & LFAMD_FLAG_FORCE_GENERIC) && n > 8 && Atype == LFAMD_TYPE_Q8_0;
 }
 
-static bool use_gemv(int Atype, long n, unsigned flags) {
+static bool use_gemv(int Atype, long n, unsigned flags, long k) {
     if (flags & LFAMD_FLAG_FORCE_GENERIC)
         return false;
     return n <= 8 && (Atype == LFAMD_TYPE_Q4_K || Atype == LFAMD_TYPE_Q5_K || Atype == LFAMD_TYPE_Q6_K ||
-                      Atype == LFAMD_TYPE_Q8_0);
+                      Atype == LFAMD_TYPE_Q8_0 || packed40(Atype, k));
 }
 
 static bool gemv_quantise_separately(int Atype, long m) {
@@ -226,15 +244,15 @@ static bool gemv_quantise_separately(int Atype, long m) {
 }
 
 size_t lfamd_mul_mat_workspace(int Atype, long m, long k, long n) {
-    if (use_gemv(Atype, n, 0) && gemv_quantise_separately(Atype, m))
+    if (use_gemv(Atype, n, 0, k) && gemv_quantise_separately(Atype, m))
         return align_up((size_t)n * lfamd_row_size(lfamd_vec_dot_type(Atype), k), 256);
-    if (use_gemm(Atype, n, 0)) {
+    if (use_gemm(Atype, n, 0, k)) {
         size_t n_pad = align_up((size_t)n, 128), nb = (size_t)(k / 256);
         return align_up(n_pad * (size_t)k * 2, 256) + align_up(nb * n_pad * 4, 256) + align_up(n_pad * nb * 32, 256);
     }
     if (use_gemm_q80(Atype, n, 0))
         return align_up(lfamd_gemm_q80_workspace(k, n), 256);
-    if (use_gemv(Atype, n, 0) || !type_known(Atype) || lfamd_blck_size(Atype) == 1)
+    if (use_gemv(Atype, n, 0, k) || !type_known(Atype) || lfamd_blck_size(Atype) == 1)
         return 0;
     // generic kernels given f32 activations quantise them into the workspace first
     return align_up((size_t)n * lfamd_row_size(lfamd_vec_dot_type(Atype), k), 256);
@@ -262,7 +280,7 @@ int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const v
     hipStream_t s = (hipStream_t)stream;
     const int vregs32 = (flags & LFAMD_FLAG_Q0_VREGS32) ? 1 : 0, precise = (flags & LFAMD_FLAG_PRECISE) ? 1 : 0;
 
-    if (use_gemm(Atype, n, flags)) {
+    if (use_gemm(Atype, n, flags, k)) {
         size_t need = lfamd_mul_mat_workspace(Atype, m, k, n);
         if (ws_bytes < need || !d_ws)
             return fail(LFAMD_ERR_WORKSPACE, "mul_mat: workspace too small%s", "");
@@ -271,6 +289,11 @@ int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const v
         void *Xh = ws;
         void *d8T = ws + align_up(n_pad * (size_t)k * 2, 256);
         void *Xm = (uint8_t *)d8T + align_up(nb * n_pad * 4, 256);
+        if (Atype == LFAMD_TYPE_Q4_0) { // Q8_0-quantised activations, eight scales per 256 (they take the Xm area too)
+            HIPCHK(lfamd_launch_prep80(Btype, d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, s), "prep80");
+            HIPCHK(lfamd_launch_gemm_wide(Atype, d_A, m, k, Xh, d8T, nullptr, n, (long)n_pad, d_C, ldc, s), "gemm_wide");
+            return LFAMD_OK;
+        }
         if (Btype == LFAMD_TYPE_F32)
             HIPCHK(lfamd_launch_prep_f32(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, s), "prep_f32");
         else
@@ -296,7 +319,7 @@ int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const v
         HIPCHK(lfamd_launch_gemm_q80(d_A, m, k, Btype, d_B, b_row_bytes, n, d_C, ldc, d_ws, vregs32, precise, s), "gemm_q80");
         return LFAMD_OK;
     }
-    if (use_gemv(Atype, n, flags)) {
+    if (use_gemv(Atype, n, flags, k)) {
         if (Btype == LFAMD_TYPE_F32 && gemv_quantise_separately(Atype, m)) {
             // very tall matrices (output.weight): thousands of work-groups would each re-quantise the same
             // activation vector; quantise it once into the workspace instead
@@ -310,7 +333,8 @@ int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const v
         HIPCHK(lfamd_launch_gemv(Atype, d_A, m, k, Btype, d_B, b_row_bytes, n, d_C, ldc, vregs32, precise, s), "gemv");
         return LFAMD_OK;
     }
-    if (Atype == LFAMD_TYPE_Q4_K || Atype == LFAMD_TYPE_Q5_K || Atype == LFAMD_TYPE_Q6_K || Atype == LFAMD_TYPE_Q8_0)
+    if (Atype == LFAMD_TYPE_Q4_K || Atype == LFAMD_TYPE_Q5_K || Atype == LFAMD_TYPE_Q6_K || Atype == LFAMD_TYPE_Q8_0 ||
+        packed40(Atype, k))
         return fail(LFAMD_ERR_UNSUPPORTED, "mul_mat: FORCE_GENERIC needs RAW-layout weights; this type is packed%s", "");
     if (!float_a && Btype == LFAMD_TYPE_F32) {
         size_t qrow = lfamd_row_size(vdt, k), need = align_up((size_t)n * qrow, 256);
@@ -330,7 +354,8 @@ int lfamd_mul_mat_multi(int Atype, int count, const void *const *d_A, const long
     if (count <= 0)
         return LFAMD_OK;
     // one fused launch when the GEMV path applies to every matrix; otherwise one mul_mat per matrix
-    bool fuse = count <= 4 && n <= 8 && (Atype == LFAMD_TYPE_Q4_K || Atype == LFAMD_TYPE_Q5_K || Atype == LFAMD_TYPE_Q6_K) &&
+    bool fuse = count <= 4 && n <= 8 &&
+                (Atype == LFAMD_TYPE_Q4_K || Atype == LFAMD_TYPE_Q5_K || Atype == LFAMD_TYPE_Q6_K || packed40(Atype, k)) &&
                 !(flags & LFAMD_FLAG_FORCE_GENERIC) && (Btype == LFAMD_TYPE_F32 || Btype == lfamd_vec_dot_type(Atype)) &&
                 k > 0 && k % 256 == 0 && b_row_bytes >= lfamd_row_size(Btype, k);
     for (int j = 0; j < count && fuse; j++)
@@ -347,7 +372,7 @@ int lfamd_mul_mat_multi(int Atype, int count, const void *const *d_A, const long
     // K-quant batches: ONE activation prep for all the matrices, and one launch of the 128 x 128 body over their
     // concatenated row blocks when that grid fills the chip (attn_q/k/v: 48 + 8 + 8 row blocks instead of three
     // launches of which two fill a quarter of the CUs)
-    bool gfuse = count > 1 && count <= 4 && use_gemm(Atype, n, flags) && k > 0 && k % 256 == 0 &&
+    bool gfuse = count > 1 && count <= 4 && use_gemm(Atype, n, flags, k) && Atype != LFAMD_TYPE_Q4_0 && k > 0 && k % 256 == 0 &&
                  (Btype == LFAMD_TYPE_F32 || Btype == lfamd_vec_dot_type(Atype)) && b_row_bytes >= lfamd_row_size(Btype, k) &&
                  !(flags & LFAMD_FLAG_GEMM_NARROW);
     long rbs = 0;

@@ -52,6 +52,20 @@ __device__ static inline half8_t dequant_q5(uint32_t x, uint32_t Hd, half2_t S, 
     return f.v;
 }
 
+// Q4_0: the code minus 8, no integer scale (the f16 block scale is applied in f32 per 32-block).
+__device__ static inline half8_t dequant_q40(uint32_t x, uint32_t magic) {
+    frag_u f;
+    const uint32_t y = x >> 8;
+    const half2_t m1032 = {(_Float16)-1032.0f, (_Float16)-1032.0f};
+    const half2_t m72 = {(_Float16)-72.0f, (_Float16)-72.0f};
+    const half2_t r16 = {(_Float16)0.0625f, (_Float16)0.0625f};
+    f.p[0] = as_half2((x & 0x000F000Fu) | magic) + m1032;
+    f.p[1] = pk_fma(as_half2((x & 0x00F000F0u) | magic), r16, m72);
+    f.p[2] = as_half2((y & 0x000F000Fu) | magic) + m1032;
+    f.p[3] = pk_fma(as_half2((y & 0x00F000F0u) | magic), r16, m72);
+    return f.v;
+}
+
 __device__ static inline uint32_t opaque_magic() {
     uint32_t magic = 0x64006400u;
     asm volatile("" : "+v"(magic)); // keep it a register value (see dequant_q4)

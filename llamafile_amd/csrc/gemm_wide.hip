@@ -118,9 +118,10 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const gemm_mats mats, in
                                                         const float *__restrict__ d8T, const _Float16 *__restrict__ Xm, long n,
                                                         long n_pad, int n_rb, int n_ct, int ks_n, int nbs) {
     __shared__ __attribute__((aligned(16))) uint8_t xs[2][WD_XSTAGE];     // activation codes, XOR-swizzled rows
-    __shared__ __attribute__((aligned(16))) float d8s[2][WD_COLS];        // d8 of the 128 tokens
+    constexpr bool LEGACY = TYPE == LFAMD_TYPE_Q4_0; // 32-blocks: f16 scale per block, Q8_0 activations (8 d8 per 256)
+    __shared__ __attribute__((aligned(16))) float d8s[2][(LEGACY ? 8 : 1) * WD_COLS]; // d8 of the 128 tokens
     __shared__ __attribute__((aligned(16))) uint8_t xms[2][WD_COLS * 32]; // Q4_K mins operand rows
-    constexpr int TILE = TYPE == LFAMD_TYPE_Q4_K ? P4K_TILE : TYPE == LFAMD_TYPE_Q5_K ? P5K_TILE : P6K_TILE;
+    constexpr int TILE = (TYPE == LFAMD_TYPE_Q4_K || LEGACY) ? P4K_TILE : TYPE == LFAMD_TYPE_Q5_K ? P5K_TILE : P6K_TILE;
     constexpr bool MINS = TYPE == LFAMD_TYPE_Q4_K || TYPE == LFAMD_TYPE_Q5_K; // Q4_K family: {d, dmin, 6-bit scales/mins}
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 31, h = lane >> 5;
@@ -163,8 +164,9 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const gemm_mats mats, in
         const int nn = 16 * wave + 2 * e + h;
         xo[e] = (uint32_t)(nn * 512 + ((i ^ (nn & 15)) * 16));
     }
-    const uint32_t wo = lane * 16, ho = i * 16 + (MINS ? P4K_HDR : P6K_SC) - 4096; // P5K_HDR == P4K_HDR
+    const uint32_t wo = lane * 16, ho = i * 16 + ((MINS || LEGACY) ? P4K_HDR : P6K_SC) - 4096; // P5K_HDR == P4K_HDR
     const uint32_t xmo = (uint32_t)((32 * (wave & 3) + (lane >> 1)) * 32 + (lane & 1) * 16);
+    const uint32_t d8o = (uint32_t)((lane >> 5) * n_pad * 4 + (lane & 31) * 16); // LEGACY d8 rows
     const uint8_t *xbase = (const uint8_t *)Xh + (size_t)n0 * 512;           // + b * n_pad * 512
     const uint8_t *wbase = A + (size_t)(active ? rt : 0) * nb * TILE;
     const uint8_t *xmbase = (const uint8_t *)Xm + (size_t)n0 * 32;           // + b * n_pad * 32
@@ -181,7 +183,10 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const gemm_mats mats, in
         const uint32_t dst = xs_a[st] + wave * 8192;
         glds4(xb, dst, xo[0], xo[1], xo[2], xo[3]);
         glds4(xb, dst + 4096, xo[4], xo[5], xo[6], xo[7]);
-        if (wave >= 6) // d8 of tokens 64*(wave-6) + lane
+        if constexpr (LEGACY) { // 8 rows of 128 f32: waves 4..7 copy two rows each (one 16-byte piece)
+            if (wave >= 4)
+                glds1x16(uniform_ptr(d8T + ((size_t)b * 8 + 2 * (wave - 4)) * n_pad + n0), d8_a[st] + (wave - 4) * 1024, d8o);
+        } else if (wave >= 6) // d8 of tokens 64*(wave-6) + lane
             glds1x4(uniform_ptr(d8T + (size_t)b * n_pad + n0), d8_a[st] + (wave - 6) * 256, (uint32_t)((wave - 6) * 256 + lane * 4));
         if constexpr (MINS) {
             if (wave < 4)
@@ -193,7 +198,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const gemm_mats mats, in
         gload16<1024>(w.qs[1], tile, wo);
         gload16<2048>(w.qs[2], tile, wo);
         gload16<3072>(w.qs[3], tile, wo);
-        if constexpr (MINS) {
+        if constexpr (MINS || LEGACY) {
             gload16<0>(w.hd, tile_h, ho);
             if constexpr (TYPE == LFAMD_TYPE_Q5_K)
                 gload16<512>(w.qh[0], tile_h, wo); // P5K_QH = 4608
@@ -217,7 +222,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const gemm_mats mats, in
             gload16<1024>(w.qs[1], tile, wo);
             gload16<2048>(w.qs[2], tile, wo);
             gload16<3072>(w.qs[3], tile, wo);
-            if constexpr (MINS) {
+            if constexpr (MINS || LEGACY) {
                 gload16<0>(w.hd, tile_h, ho);
                 if constexpr (TYPE == LFAMD_TYPE_Q5_K)
                     gload16<512>(w.qh[0], tile_h, wo);
@@ -231,7 +236,10 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const gemm_mats mats, in
             const int e = t - 1;
             glds1x16(uniform_ptr(xbase + (size_t)b * n_pad * 512), xs_a[st] + wave * 8192 + e * 1024, xo[e]);
         } else if (t == 9) {
-            if (wave >= 6)
+            if constexpr (LEGACY) {
+                if (wave >= 4)
+                    glds1x16(uniform_ptr(d8T + ((size_t)b * 8 + 2 * (wave - 4)) * n_pad + n0), d8_a[st] + (wave - 4) * 1024, d8o);
+            } else if (wave >= 6)
                 glds1x4(uniform_ptr(d8T + (size_t)b * n_pad + n0), d8_a[st] + (wave - 6) * 256, (uint32_t)((wave - 6) * 256 + lane * 4));
         } else if (t == 10) {
             if constexpr (MINS) {
@@ -243,7 +251,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const gemm_mats mats, in
     // retire every load of the stage (this wave's), then meet the other waves: their LDS-DMA has landed too, and
     // everybody has finished reading the stage that the next prefetch overwrites
     auto arrive = [&](wide_w<TYPE> &w) {
-        if constexpr (TYPE == LFAMD_TYPE_Q4_K)
+        if constexpr (TYPE == LFAMD_TYPE_Q4_K || LEGACY)
             asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier"
                          : "+v"(w.qs[0]), "+v"(w.qs[1]), "+v"(w.qs[2]), "+v"(w.qs[3]), "+v"(w.hd)
                          :
@@ -275,6 +283,8 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const gemm_mats mats, in
         xoff[u] = xs_a[0] + ch * 32768 + (uint32_t)(i * XT_ROW_BYTES + ((((2 * u + h) & 15) ^ (i & 15)) * 16));
     const float16_t_ zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const uint32_t magic = opaque_magic();
+    const uint32_t d8_lane = d8_a[0] + (uint32_t)((ch * 64 + 4 * h) * 4);
+    (void)d8_lane;
 
     auto compute = [&](auto stc, const wide_w<TYPE> &w, int bn, wide_w<TYPE> &wn) {
         constexpr int st = decltype(stc)::value;
@@ -353,6 +363,54 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const gemm_mats mats, in
                         acc[nt][r] = fmaf(u, d8[e], acc[nt][r]);
                     }
                 }
+            }
+        } else if constexpr (LEGACY) {
+            const uint32_t hdw[4] = {w.hd.x, w.hd.y, w.hd.z, w.hd.w}; // eight f16 block scales of this lane's row
+            const uint32_t d8base = d8_lane; // LDS address of d8s[0][ch * 64 + 4 * h]
+            half8_t F[2][2];
+            read_frags(F[0], 0);
+#pragma unroll
+            for (int bl = 0; bl < 8; bl++) {
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    const int t = 2 * bl + e;
+                    const half8_t wf = dequant_q40(qw[t], magic);
+                    if (t + 1 < 16) {
+                        read_frags(F[(t + 1) & 1], t + 1);
+                        ds_wait<2>(F[t & 1][0], F[t & 1][1]);
+                    } else {
+                        ds_wait<0>(F[t & 1][0], F[t & 1][1]);
+                    }
+#pragma unroll
+                    for (int nt = 0; nt < 2; nt++)
+                        tmp[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F[t & 1][nt], wf, e == 0 ? zero16 : tmp[nt], 0, 0, 0);
+                    prefetch_step(t, bn, st ^ 1, wn);
+                }
+                // per 32-block: acc += (<q - 8, q8> * d8[token]) * d[row].  The d8 reads are asm: hipcc hoists plain LDS
+                // reads of all eight blocks above the MFMAs and then spills ~500 registers — among them asm-loaded
+                // weight registers whose data has not landed yet (garbage).
+                const float dbl = h2f((uint16_t)((bl & 1) ? (hdw[bl >> 1] >> 16) : (hdw[bl >> 1] & 0xffff)));
+#pragma unroll
+                for (int nt = 0; nt < 2; nt++) {
+                    // one loop-invariant base register, everything else an immediate (computed addresses get hoisted
+                    // out of the K loop by the dozen and spilled)
+                    float4_t_ d8[4];
+                    asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%5+32\n\t"
+                                 "ds_read_b128 %2, %4 offset:%5+64\n\tds_read_b128 %3, %4 offset:%5+96\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(d8[0]), "=&v"(d8[1]), "=&v"(d8[2]), "=&v"(d8[3])
+                                 : "v"(d8base), "n"(st * 8 * WD_COLS * 4 + bl * WD_COLS * 4 + nt * 128));
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; r4++)
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            const int r = 4 * r4 + e;
+                            acc[nt][r] = fmaf(tmp[nt][r] * d8[r4][e], dbl, acc[nt][r]);
+                        }
+                }
+                // pin the scaling HERE: an empty volatile asm on the accumulators is ordered before the next K-step's
+                // asm reads.  Left free, hipcc sinks all eight blocks' scaling below the MFMAs, keeps 8 x (tmp + d8)
+                // live and spills ~500 registers — among them asm-loaded weight registers whose data has not landed.
+                asm volatile("" : "+v"(acc[0]), "+v"(acc[1]));
             }
         } else {
             const uint32_t hw[8] = {w.qh[0].x, w.qh[0].y, w.qh[0].z, w.qh[0].w, w.qh[1].x, w.qh[1].y, w.qh[1].z, w.qh[1].w};
@@ -505,6 +563,9 @@ extern "C" hipError_t lfamd_launch_gemm_wide_multi(int Atype, int count, const v
     }
     if (Atype == LFAMD_TYPE_Q4_K)
         gemm_wide_kernel<LFAMD_TYPE_Q4_K><<<n_wg, 512, 0, s>>>(mats, nb, (const _Float16 *)Xh, (const float *)d8T,
+                                                                (const _Float16 *)Xm, n, n_pad, n_rb, n_ct, ks, nbs);
+    else if (Atype == LFAMD_TYPE_Q4_0)
+        gemm_wide_kernel<LFAMD_TYPE_Q4_0><<<n_wg, 512, 0, s>>>(mats, nb, (const _Float16 *)Xh, (const float *)d8T,
                                                                 (const _Float16 *)Xm, n, n_pad, n_rb, n_ct, ks, nbs);
     else if (Atype == LFAMD_TYPE_Q5_K)
         gemm_wide_kernel<LFAMD_TYPE_Q5_K><<<n_wg, 512, 0, s>>>(mats, nb, (const _Float16 *)Xh, (const float *)d8T,

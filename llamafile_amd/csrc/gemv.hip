@@ -28,8 +28,8 @@
 //   [0,256)    codes: 8-byte groups at position pos = 16 gsel + 8 h + 4 gi + dd
 //   [256,320)  hb  : int16 sum of each 8-byte group, same position order
 //   [320,352)  ps  : int16 sum of K-step pairs (dd = 2e, 2e+1): position 8 gsel + 4 h + 2 gi + e
-//   [352,356)  d   : f32 block scale
-#define XBLK 368
+//   [352,384)  d   : f32 block scale (Q8_K: one; Q8_0-quantised activations for the legacy 32-block types: eight)
+#define XBLK 384
 #define XBLK_HB 256
 #define XBLK_PS 320
 #define XBLK_D 352
@@ -146,12 +146,78 @@ __device__ static inline void stage_f32_as_q8k(uint8_t *lds, const uint8_t *X, s
     }
 }
 
-template <int BT>
+// ---- activations of the legacy 32-block weight types (Q4_0 ...): Q8_0 quantisation (d = amax/127 per 32 values,
+// stored as f16; q = roundf(x/d): upstream quantize_row_q8_0), same code / group-sum / pair-sum image, eight scales.
+__device__ static inline void quantise_piece_q80(uint8_t *dst, const float (&v)[16], int l16) {
+    float amax = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 16; e++)
+        amax = fmaxf(amax, fabsf(v[e]));
+    amax = fmaxf(amax, __shfl_xor(amax, 1, 64)); // lanes 2b, 2b+1 hold the two halves of 32-block b
+    const float d = amax / 127.0f;
+    const float id = d != 0.0f ? 1.0f / d : 0.0f;
+    uint32_t y[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+        const int q = (int)roundf(v[e] * id);
+        y[e >> 2] |= (uint32_t)(q & 0xff) << (8 * (e & 3));
+    }
+    const int hs0 = put_group(dst, 2 * l16 + 0, y[0], y[1]);
+    const int hs1 = put_group(dst, 2 * l16 + 1, y[2], y[3]);
+    const int o0 = __shfl_xor(hs0, 1, 64), o1 = __shfl_xor(hs1, 1, 64);
+    if ((l16 & 1) == 0) {
+        put_pair(dst, 2 * l16 + 0, hs0 + o0);
+        put_pair(dst, 2 * l16 + 1, hs1 + o1);
+        *(float *)(dst + XBLK_D + 4 * (l16 >> 1)) = h2f(f2h_bits(d));
+    }
+}
+
+__device__ static inline void stage_f32_as_q80(uint8_t *lds, const uint8_t *X, size_t x_row_bytes, long col0, int nc,
+                                               int nb) {
+    const int pieces = nb * 16;
+    const int l16 = threadIdx.x & 15;
+    for (int c = 0; c < nc; c++) {
+        const float *x = (const float *)(X + (col0 + c) * x_row_bytes);
+        for (int p = threadIdx.x; p < pieces; p += blockDim.x) {
+            float v[16];
+            load_piece(v, x, p);
+            quantise_piece_q80(lds + (size_t)(c * nb + (p >> 4)) * XBLK, v, l16);
+        }
+    }
+}
+
+// already-quantised Q8_0 rows (34-byte blocks): one 8-byte group per lane, 32 consecutive lanes per 256 codes
+__device__ static inline void stage_q80_blocks(uint8_t *lds, const uint8_t *B, size_t b_row_bytes, long col0, int nc, int nb) {
+    const int groups = nc * nb * 32;
+    for (int gidx = threadIdx.x; gidx < groups; gidx += blockDim.x) {
+        int c = gidx / (nb * 32), r = gidx % (nb * 32);
+        int b = r >> 5, grp = r & 31;
+        const uint8_t *blk = B + (col0 + c) * b_row_bytes + (size_t)(b * 8 + (grp >> 2)) * 34;
+        const uint16_t *src = (const uint16_t *)(blk + 2 + 8 * (grp & 3));
+        const uint32_t y0 = (uint32_t)src[0] | ((uint32_t)src[1] << 16), y1 = (uint32_t)src[2] | ((uint32_t)src[3] << 16);
+        uint8_t *dst = lds + (size_t)(c * nb + b) * XBLK;
+        const int hs = put_group(dst, grp, y0, y1);
+        const int other = __shfl_xor(hs, 2, 64);
+        if ((grp & 2) == 0)
+            put_pair(dst, grp, hs + other);
+        if ((grp & 3) == 0)
+            *(float *)(dst + XBLK_D + 4 * (grp >> 2)) = h2f(*(const uint16_t *)blk);
+    }
+}
+
+template <int BT, int ACT>
 __device__ static inline void stage_x(uint8_t *lds, const uint8_t *B, size_t b_row_bytes, long col0, int nc, int nb) {
-    if constexpr (BT == LFAMD_TYPE_F32)
-        stage_f32_as_q8k(lds, B, b_row_bytes, col0, nc, nb);
-    else
-        stage_q8k(lds, B, b_row_bytes, col0, nc, nb);
+    if constexpr (ACT == LFAMD_TYPE_Q8_K) {
+        if constexpr (BT == LFAMD_TYPE_F32)
+            stage_f32_as_q8k(lds, B, b_row_bytes, col0, nc, nb);
+        else
+            stage_q8k(lds, B, b_row_bytes, col0, nc, nb);
+    } else {
+        if constexpr (BT == LFAMD_TYPE_F32)
+            stage_f32_as_q80(lds, B, b_row_bytes, col0, nc, nb);
+        else
+            stage_q80_blocks(lds, B, b_row_bytes, col0, nc, nb);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -169,6 +235,7 @@ __device__ static inline void stage_x(uint8_t *lds, const uint8_t *B, size_t b_r
 #define GEMV_CH_MAX 4
 
 struct q4k_traits {
+    static constexpr int ACT = LFAMD_TYPE_Q8_K; // activation quantisation the reference uses for this type
     static constexpr int TILE = P4K_TILE;
     struct chunk {
         uint4 q0[GEMV_CH_MAX], q1[GEMV_CH_MAX], hd[GEMV_CH_MAX];
@@ -215,8 +282,56 @@ struct q4k_traits {
     }
 };
 
+// Q4_0 (legacy 32-blocks, activations Q8_0; mul_mat_qX_0_q8_0_T, iqk_mul_mat.inc:998-1349): the P4K nibble image with
+// eight f16 block scales per row as header; w = d*(q - 8).  Per 32-block: d*d8*(<q, q8> - 8*sum(q8)), the sum taken
+// from the staged pair sums like the Q4_K mins.
+struct q40_traits {
+    static constexpr int ACT = LFAMD_TYPE_Q8_0;
+    static constexpr int TILE = P4K_TILE;
+    struct chunk {
+        uint4 q0[GEMV_CH_MAX], q1[GEMV_CH_MAX];
+        uint2 hd[GEMV_CH_MAX];
+    };
+    __device__ static inline void load(chunk &ch, int s, lfamd_rsrc r, uint32_t off, int gsel, int slot, int hrow) {
+        ch.q0[s] = buf_ld16_nt(r, off + (2 * gsel + 0) * 1024 + slot * 16);
+        ch.q1[s] = buf_ld16_nt(r, off + (2 * gsel + 1) * 1024 + slot * 16);
+        ch.hd[s] = buf_ld8(r, off + P4K_HDR + hrow * 16 + gsel * 8); // scales of blocks 4 gsel .. 4 gsel + 3
+    }
+    __device__ static inline float dot(const chunk &ch, int s, const uint8_t *xb, int gsel, int h) {
+        const uint4 q0 = ch.q0[s], q1 = ch.q1[s];
+        const uint2 hd = ch.hd[s];
+        const uint32_t qw[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+        const uint4 *yq = (const uint4 *)(xb + 128 * gsel + 64 * h);
+        const uint4 ya = yq[0], yb = yq[1], yc = yq[2], yd = yq[3];
+        const uint32_t yw[16] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w,
+                                 yc.x, yc.y, yc.z, yc.w, yd.x, yd.y, yd.z, yd.w};
+        const uint2 psw = *(const uint2 *)(xb + XBLK_PS + 16 * gsel + 8 * h);
+        const int ps[4] = {(int)(int16_t)(psw.x & 0xffff), (int)(int16_t)(psw.x >> 16), (int)(int16_t)(psw.y & 0xffff),
+                           (int)(int16_t)(psw.y >> 16)};
+        const float4 d8 = *(const float4 *)(xb + XBLK_D + 16 * gsel);
+        const float d8v[4] = {d8.x, d8.y, d8.z, d8.w};
+        float acc = 0.0f;
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) { // block 4 gsel + jj
+            int isum = 0;
+#pragma unroll
+            for (int d2 = 0; d2 < 2; d2++) {
+                const int t8 = 2 * jj + d2;
+                const uint32_t x = qw[t8];
+                isum = sdot4(x & 0x0F0F0F0F, yw[2 * t8], isum);
+                isum = sdot4((x >> 4) & 0x0F0F0F0F, yw[2 * t8 + 1], isum);
+            }
+            const uint32_t dw = jj < 2 ? hd.x : hd.y;
+            const float d = h2f((uint16_t)((jj & 1) ? (dw >> 16) : (dw & 0xffff)));
+            acc = fmaf(d * d8v[jj], (float)(isum - 8 * ps[jj]), acc);
+        }
+        return acc;
+    }
+};
+
 // Q5_K: Q4_K with a fifth bit per weight (DequantizerQ5K, iqk_mul_mat.inc:496-511): codes 0..31, same scales / mins.
 struct q5k_traits {
+    static constexpr int ACT = LFAMD_TYPE_Q8_K; // activation quantisation the reference uses for this type
     static constexpr int TILE = P5K_TILE;
     struct chunk {
         uint4 q0[GEMV_CH_MAX], q1[GEMV_CH_MAX], hd[GEMV_CH_MAX];
@@ -268,6 +383,7 @@ struct q5k_traits {
 // Q6_K: sub-blocks are 16 wide (one per K-step), codes are 6 bit, offset -32 handled as
 // sum sc*(dot(code,q8) - 32*sum(q8)) like DequantizerQ6K (iqk_mul_mat.inc:570-599).
 struct q6k_traits {
+    static constexpr int ACT = LFAMD_TYPE_Q8_K; // activation quantisation the reference uses for this type
     static constexpr int TILE = P6K_TILE;
     struct chunk {
         uint4 l0[GEMV_CH_MAX], l1[GEMV_CH_MAX], hq[GEMV_CH_MAX];
@@ -472,12 +588,16 @@ __global__ __launch_bounds__(NW * 64) void gemv_kq_kernel(const gemv_mats mats, 
             load_piece(v, (const float *)(B + col0 * b_row_bytes), threadIdx.x);
         issue(bufA, 0);
         GSTAMP();
-        if (mine)
-            quantise_piece_q8k(lds + (size_t)(threadIdx.x >> 4) * XBLK, v, threadIdx.x & 15);
+        if (mine) {
+            if constexpr (TR::ACT == LFAMD_TYPE_Q8_K)
+                quantise_piece_q8k(lds + (size_t)(threadIdx.x >> 4) * XBLK, v, threadIdx.x & 15);
+            else
+                quantise_piece_q80(lds + (size_t)(threadIdx.x >> 4) * XBLK, v, threadIdx.x & 15);
+        }
         GSTAMP();
     } else {
         issue(bufA, 0); // in flight during the staging below
-        stage_x<BT>(lds, B, b_row_bytes, col0, NC, nb);
+        stage_x<BT, TR::ACT>(lds, B, b_row_bytes, col0, NC, nb);
     }
     __syncthreads();
     GSTAMP();
@@ -819,6 +939,11 @@ static hipError_t launch_q4k(const gemv_mats &mats, int n_ht, long k, const void
 }
 
 template <int NC, int BT>
+static hipError_t launch_q40(const gemv_mats &mats, int n_ht, long k, const void *B, size_t brb, long col0, hipStream_t s) {
+    return launch_kq_pick<q40_traits, NC, BT>(mats, n_ht, k, B, brb, col0, s);
+}
+
+template <int NC, int BT>
 static hipError_t launch_q5k(const gemv_mats &mats, int n_ht, long k, const void *B, size_t brb, long col0, hipStream_t s) {
     return launch_kq_pick<q5k_traits, NC, BT>(mats, n_ht, k, B, brb, col0, s);
 }
@@ -926,7 +1051,8 @@ extern "C" hipError_t lfamd_launch_gemv_multi(int Atype, int count, const void *
         }
         return e;
     }
-    if (count > GEMV_MAX_MATS || (Atype != LFAMD_TYPE_Q4_K && Atype != LFAMD_TYPE_Q5_K && Atype != LFAMD_TYPE_Q6_K))
+    if (count > GEMV_MAX_MATS ||
+        (Atype != LFAMD_TYPE_Q4_K && Atype != LFAMD_TYPE_Q5_K && Atype != LFAMD_TYPE_Q6_K && Atype != LFAMD_TYPE_Q4_0))
         return hipErrorInvalidValue;
     gemv_mats mats;
     int n_ht = 0;
@@ -957,6 +1083,12 @@ extern "C" hipError_t lfamd_launch_gemv_multi(int Atype, int count, const void *
                 DISPATCH_NC(launch_q4k, LFAMD_TYPE_F32, nc, mats, n_ht, k, B, b_row_bytes, col0, s)
             } else {
                 DISPATCH_NC(launch_q4k, LFAMD_TYPE_Q8_K, nc, mats, n_ht, k, B, b_row_bytes, col0, s)
+            }
+        } else if (Atype == LFAMD_TYPE_Q4_0) {
+            if (f32in) {
+                DISPATCH_NC(launch_q40, LFAMD_TYPE_F32, nc, mats, n_ht, k, B, b_row_bytes, col0, s)
+            } else {
+                DISPATCH_NC(launch_q40, LFAMD_TYPE_Q8_0, nc, mats, n_ht, k, B, b_row_bytes, col0, s)
             }
         } else if (Atype == LFAMD_TYPE_Q5_K) {
             if (f32in) {

@@ -53,6 +53,51 @@ __global__ void pack_q4k_kernel(const uint8_t *__restrict__ raw, size_t raw_row_
 }
 
 // ---------------------------------------------------------------------------------------------
+// Q4_0 -> P40 (cols % 256 == 0): the P4K nibble image (K-step dword = the 8 codes of k = 16t + 8h + j) and, as
+// header, the eight f16 block scales of the row's 256 weights.  block_q4_0 = {d, qs[16]}: weight l of a block is the
+// low nibble of qs[l] (l < 16) or the high nibble of qs[l - 16]; value d*(q - 8).
+
+__global__ void pack_q40_kernel(const uint8_t *__restrict__ raw, size_t raw_row_bytes, long rows, int nb,
+                                uint8_t *__restrict__ out, long n_tiles) {
+    long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long tile = tid / 1152;
+    int w = (int)(tid % 1152);
+    if (tile >= n_tiles)
+        return;
+    long rt = tile / nb;
+    int b = (int)(tile % nb);
+    uint32_t *dst = (uint32_t *)(out + tile * P4K_TILE);
+    if (w < 1024) {
+        int g = w >> 8, lane = (w >> 2) & 63, dd = w & 3;
+        int i = lane & 31, h = lane >> 5;
+        long row = rt * 32 + i;
+        uint32_t v = 0;
+        if (row < rows) {
+            const lfamd_block_q4_0 *blk = (const lfamd_block_q4_0 *)(raw + row * raw_row_bytes) + (size_t)b * 8;
+            int t = 4 * g + dd;
+            for (int j = 0; j < 8; j++) {
+                int k = 16 * t + 8 * h + j;
+                int bl = k >> 5, l = k & 31;
+                uint8_t byte = blk[bl].qs[l & 15];
+                uint32_t nib = l < 16 ? (byte & 15u) : (uint32_t)(byte >> 4);
+                v |= nib << (4 * NIBPOS(j));
+            }
+        }
+        dst[w] = v;
+    } else {
+        int s = w - 1024; // row i, scale pair q: blocks 2q, 2q+1
+        int i = s >> 2, q = s & 3;
+        long row = rt * 32 + i;
+        uint32_t v = 0;
+        if (row < rows) {
+            const lfamd_block_q4_0 *blk = (const lfamd_block_q4_0 *)(raw + row * raw_row_bytes) + (size_t)b * 8;
+            v = (uint32_t)blk[2 * q].d | ((uint32_t)blk[2 * q + 1].d << 16);
+        }
+        dst[1024 + s] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Q5_K -> P5K: the P4K image of the low nibbles and the header, then one dword of fifth bits per (lane, group).
 // block_q5_K = {d, dmin, scales[12], qh[32], qs[128]}: weight l of sub-block j has its fifth bit at bit j of qh[l].
 
@@ -360,6 +405,51 @@ __global__ __launch_bounds__(64) void prep_f32_kernel(const uint8_t *__restrict_
         d8T[(size_t)b * n_pad + tok] = d;
 }
 
+// Activation preparation for the legacy 32-block weight types (Q4_0 ...): Q8_0 quantisation (upstream
+// quantize_row_q8_0: d = amax/127 stored as f16, q = roundf(x/d)) ->
+//   Xh  [nb][n_pad][256] f16 codes (as above);  d8T [nb*8][n_pad] f32 block scales.  One wave per (super-block, token).
+template <bool F32IN>
+__global__ __launch_bounds__(256) void prep80_kernel(const uint8_t *__restrict__ X, size_t x_row_bytes, long n, long n_pad, int nb,
+                                                    _Float16 *__restrict__ Xh, float *__restrict__ d8T) {
+    typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+    long blk = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (blk >= (long)nb * n_pad)
+        return;
+    int b = (int)(blk / n_pad);
+    long tok = blk - (long)b * n_pad;
+    int t = threadIdx.x & 63; // codes 4t..4t+3 of the super-block: 32-block t >> 3
+    int q[4] = {0, 0, 0, 0};
+    float d = 0.0f;
+    if (tok < n) {
+        if constexpr (F32IN) {
+            const float4 f = *(const float4 *)((const float *)(X + tok * x_row_bytes) + (size_t)b * 256 + 4 * t);
+            const float v[4] = {f.x, f.y, f.z, f.w};
+            float amax = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+            amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+            amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+            amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
+            const float dd = amax / 127.0f;
+            const float id = dd != 0.0f ? 1.0f / dd : 0.0f;
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                q[e] = (int)roundf(v[e] * id);
+            d = h2f(f2h_bits(dd));
+        } else {
+            const uint8_t *y = X + tok * x_row_bytes + (size_t)(b * 8 + (t >> 3)) * 34; // 34-byte blocks: 2-byte aligned
+            const uint16_t *p = (const uint16_t *)(y + 2 + 4 * (t & 7));
+            const uint32_t w = (uint32_t)p[0] | ((uint32_t)p[1] << 16);
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                q[e] = (int)(int8_t)(w >> (8 * e));
+            d = h2f(*(const uint16_t *)y);
+        }
+    }
+    half4_t h4 = {(_Float16)q[0], (_Float16)q[1], (_Float16)q[2], (_Float16)q[3]};
+    *(half4_t *)(Xh + ((size_t)b * n_pad + tok) * 256 + 4 * t) = h4;
+    if ((t & 7) == 0)
+        d8T[((size_t)b * 8 + (t >> 3)) * n_pad + tok] = d;
+}
+
 // ---------------------------------------------------------------------------------------------
 // host-callable launchers (used by api.hip)
 
@@ -370,6 +460,15 @@ hipError_t lfamd_launch_pack_q4k(const void *raw, size_t raw_row_bytes, long row
     long n_tiles = ((rows + 31) / 32) * nb;
     long threads = n_tiles * 1152;
     pack_q4k_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>((const uint8_t *)raw, raw_row_bytes, rows, nb,
+                                                                        (uint8_t *)out, n_tiles);
+    return hipGetLastError();
+}
+
+hipError_t lfamd_launch_pack_q40(const void *raw, size_t raw_row_bytes, long rows, long cols, void *out, hipStream_t s) {
+    int nb = (int)(cols / 256);
+    long n_tiles = ((rows + 31) / 32) * nb;
+    long threads = n_tiles * 1152;
+    pack_q40_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>((const uint8_t *)raw, raw_row_bytes, rows, nb,
                                                                         (uint8_t *)out, n_tiles);
     return hipGetLastError();
 }
@@ -422,6 +521,21 @@ hipError_t lfamd_launch_prep_f32(const void *X, size_t x_row_bytes, long n, long
         return hipSuccess;
     prep_f32_kernel<<<(unsigned)blocks, 64, 0, s>>>((const uint8_t *)X, x_row_bytes, n, n_pad, nb, (_Float16 *)Xh,
                                                      (float *)d8T, (_Float16 *)Xm);
+    return hipGetLastError();
+}
+
+hipError_t lfamd_launch_prep80(int Btype, const void *B, size_t b_row_bytes, long n, long n_pad, long cols, void *Xh, void *d8T,
+                               hipStream_t s) {
+    int nb = (int)(cols / 256);
+    long blocks = n_pad * nb;
+    if (blocks == 0)
+        return hipSuccess;
+    if (Btype == LFAMD_TYPE_F32)
+        prep80_kernel<true><<<(unsigned)((blocks + 3) / 4), 256, 0, s>>>((const uint8_t *)B, b_row_bytes, n, n_pad, nb,
+                                                                        (_Float16 *)Xh, (float *)d8T);
+    else
+        prep80_kernel<false><<<(unsigned)((blocks + 3) / 4), 256, 0, s>>>((const uint8_t *)B, b_row_bytes, n, n_pad, nb,
+                                                                         (_Float16 *)Xh, (float *)d8T);
     return hipGetLastError();
 }
 
