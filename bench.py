@@ -338,11 +338,11 @@ def main():
     # FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM), stored
     # under profiles/ — counters cannot be read from inside this process
     traffic, traffic_src = None, None
-    tfile = os.path.join(ROOT, "profiles", "r01_v2_pmc_traffic.json")
+    tfile = os.path.join(ROOT, "profiles", "r01_v3_pmc_traffic.json")
     if dom_type == T.Q4_K and world == 1 and os.path.exists(tfile):
         try:
             traffic = json.load(open(tfile))["gemv_q4k"]["hbm_bytes_per_launch"]
-            traffic_src = "profiles/r01_v2_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2)"
+            traffic_src = "profiles/r01_v3_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2)"
         except (KeyError, ValueError):
             pass
     kname = "gemv_kq_kernel<q4k_traits, 1, F32, 16, {1,2}>" if dom_type == T.Q4_K else "gemv_q80_kernel<1, F32, mode>"
@@ -360,8 +360,19 @@ def main():
         fl = 2.0 * o.m * o.k * a.prefill
         tf = fl / (gus * 1e-6) / 1e12
         roofline_gemm = {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(tf / MFMA_F16_PEAK_TFLOPS, 4), "kernel": "prep_f32 + gemm_kq_kernel<Q4_K>",
+                         "frac": round(tf / MFMA_F16_PEAK_TFLOPS, 4),
+                         "kernel": "prep_f32 + gemm_kq_kernel<Q4_K> (128x64 split-K body: 128 tiles of 128x128 cannot fill 256 CUs)",
                          "shape": [o.m, o.k, a.prefill], "avg_launch_us": round(gus, 2)}
+        # the same measurement on the largest Q4_K shape of the model (128x128 body, gemm_wide.hip)
+        big = [q for q in runner.layers[0] if q.W.type == T.Q4_K and q.m >= 8192]
+        if big:
+            q = big[0]
+            xin = runner.buf[a.prefill]["x"][(q.spec.input, q.k)]
+            gus = sgemm.time_mul_mat(q.W, xin.view(torch.uint8), T.F32, a.prefill, warmup=3, iters=20)
+            tf = 2.0 * q.m * q.k * a.prefill / (gus * 1e-6) / 1e12
+            roofline_gemm["large_shape"] = {"shape": [q.m, q.k, a.prefill], "avg_launch_us": round(gus, 2),
+                                            "achieved": round(tf, 1), "frac": round(tf / MFMA_F16_PEAK_TFLOPS, 4),
+                                            "kernel": "prep_f32 + gemm_wide_kernel<Q4_K>"}
 
     if rank != 0:
         if dist_on:

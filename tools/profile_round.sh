@@ -5,7 +5,7 @@
 # Summaries are written to gpurun_out/prof/*.json|csv; copy what should be judged into profiles/.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/prof; rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_profiled.json 2> $OUT/stats.err
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_profiled.json 2> $OUT/stats.err
 f=$(find $OUT/stats -name "*kernel_stats.csv" | head -1)
 python3 - "$f" $OUT/kernel_stats_trimmed.csv <<'PY'
 import csv, sys
@@ -20,7 +20,7 @@ with open(sys.argv[2], "w") as o:
 PY
 rm -rf $OUT/stats/*/*kernel_trace.csv
 for ctr in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $ctr --output-format csv -d $OUT/pmc_$ctr -- python3 bench.py --steps 1 --warmup 0 --decode 4 --no-graph --no-cpu-baseline > $OUT/pmc_$ctr.json 2> $OUT/pmc_$ctr.err
+  timeout -k 10 300 rocprofv3 --pmc $ctr --output-format csv -d $OUT/pmc_$ctr -- python3 bench.py --steps 1 --warmup 0 --decode 4 --no-graph --no-cpu-baseline > $OUT/pmc_$ctr.json 2> $OUT/pmc_$ctr.err
 done
 python3 - $OUT <<'PY'
 import csv, glob, json, sys, collections
@@ -34,7 +34,9 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         if "gemv_kq_kernel" in k and "q4k_traits" in k:
             agg["gemv_q4k"].append(float(r["Counter_Value"]))
         elif "gemm_kq_kernel" in k and "Li12E" in k:
-            agg["gemm_q4k"].append(float(r["Counter_Value"]))
+            agg["gemm_q4k_narrow"].append(float(r["Counter_Value"]))
+        elif "gemm_wide_kernel" in k and "Li12E" in k:
+            agg["gemm_q4k_wide"].append(float(r["Counter_Value"]))
     for k, v in agg.items():
         res[k][ctr + "_KB_avg_per_launch"] = sum(v) / len(v)
         res[k]["launches"] = len(v)
