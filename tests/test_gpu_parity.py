@@ -243,3 +243,28 @@ def test_mul_mat_id_decode_on_device(gpu, oracle, t, tokens, tasks, f32in):
             ok, G = oracle.sgemm(t, Ws[ex], vdt, xq[row:row + 1], rows, 1, cols)
             assert ok == 1
             assert rel_err(res[tok, th], G[0]) <= DEFAULT_TOL, (tok, th)
+
+
+@pytest.mark.parametrize("t", [T.Q4_K, T.Q5_K, T.Q6_K, T.Q8_0, T.Q4_0], ids=lambda t: T.NAMES[t])
+def test_tuned_types_random_shapes(gpu, oracle, t):
+    """Seeded sweep over ragged shapes for every type with tuned kernels: rows not a multiple of the row tile, batches
+    on both sides of the GEMV/GEMM switch and of the 128-token tile, odd super-block counts, both MFMA bodies."""
+    from llamafile_amd import _hip
+    rng = np.random.default_rng(1234 + t)
+    for case in range(10):
+        m = int(rng.integers(1, 300))
+        n = int(rng.choice([1, 2, 3, 7, 8, 9, 17, 64, 127, 128, 129, 200]))
+        k = 256 * int(rng.integers(1, 6))
+        A, B, bt = make_case(t, m, n, k, seed=int(rng.integers(1 << 30)))
+        ok, G = oracle.sgemm(t, A, bt, B, m, n, k, nth=3)
+        assert ok == 1
+        bodies = [0]
+        if n > 8 and t in (T.Q4_K, T.Q5_K, T.Q6_K):
+            bodies = [_hip.FLAG_GEMM_NARROW, _hip.FLAG_GEMM_WIDE]
+        for body in bodies:
+            C = run_gpu(gpu, t, A, B, bt, m, n, k, flags=gpu.host_variant_flags() | body)
+            if t == T.Q8_0:
+                assert np.array_equal(C.view(np.uint32), G.view(np.uint32)), (m, n, k)
+            else:
+                tol = GEMM_TOL.get(t, DEFAULT_TOL) if n > 8 else DEFAULT_TOL
+                assert rel_err(C, G) <= tol, (T.NAMES[t], m, n, k, body, rel_err(C, G))
