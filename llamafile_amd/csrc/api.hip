@@ -17,8 +17,10 @@ hipError_t lfamd_launch_pack_q5k(const void *, size_t, long, long, void *, hipSt
 hipError_t lfamd_launch_pack_q6k(const void *, size_t, long, long, void *, hipStream_t);
 hipError_t lfamd_launch_pack_q80(const void *, size_t, long, long, void *, hipStream_t);
 hipError_t lfamd_launch_pack_raw(const void *, size_t, long, size_t, void *, hipStream_t);
-hipError_t lfamd_launch_prep_q8k(const void *, size_t, long, long, long, void *, void *, void *, hipStream_t);
-hipError_t lfamd_launch_prep_f32(const void *, size_t, long, long, long, void *, void *, void *, hipStream_t);
+hipError_t lfamd_launch_prep_q8k(const void *, size_t, long, long, long, void *, void *, void *, int, hipStream_t);
+hipError_t lfamd_launch_prep_f32(const void *, size_t, long, long, long, void *, void *, void *, int, hipStream_t);
+hipError_t lfamd_launch_wprep16(int, const void *, long, long, void *, hipStream_t);
+size_t lfamd_wprep16_bytes(long, long);
 hipError_t lfamd_launch_generic(int, const void *, long, long, int, const void *, size_t, long, float *, long, hipStream_t);
 hipError_t lfamd_launch_gemv(int, const void *, long, long, int, const void *, size_t, long, float *, long, int, int,
                              hipStream_t);
@@ -225,6 +227,16 @@ static bool use_gemm(int Atype, long n, unsigned flags, long k) {
     return n > 8 && (Atype == LFAMD_TYPE_Q4_K || Atype == LFAMD_TYPE_Q5_K || Atype == LFAMD_TYPE_Q6_K || packed40(Atype, k));
 }
 
+// K-quants kept in RAW layout whose batches go through a per-call canonical image + the MFMA body (Q2_K, Q3_K)
+static bool use_gemm_canon(int Atype, long n, unsigned flags) {
+    return !(flags & LFAMD_FLAG_FORCE_GENERIC) && n > 8 && (Atype == LFAMD_TYPE_Q2_K || Atype == LFAMD_TYPE_Q3_K);
+}
+
+static size_t gemm_act_ws(long k, long n) { // Xh + d8T + Xm of the K-quant GEMM
+    size_t n_pad = align_up((size_t)n, 128), nb = (size_t)(k / 256);
+    return align_up(n_pad * (size_t)k * 2, 256) + align_up(nb * n_pad * 4, 256) + align_up(n_pad * nb * 32, 256);
+}
+
 // Q8_0 batches: the register-tiled bit-exact kernel (gemm_q80.hip)
 static bool use_gemm_q80(int Atype, long n, unsigned flags) {
     return !(flags & LFAMD_FLAG_FORCE_GENERIC) && n > 8 && Atype == LFAMD_TYPE_Q8_0;
@@ -252,6 +264,8 @@ size_t lfamd_mul_mat_workspace(int Atype, long m, long k, long n) {
     }
     if (use_gemm_q80(Atype, n, 0))
         return align_up(lfamd_gemm_q80_workspace(k, n), 256);
+    if (use_gemm_canon(Atype, n, 0))
+        return gemm_act_ws(k, n) + align_up(lfamd_wprep16_bytes(m, k), 256);
     if (use_gemv(Atype, n, 0, k) || !type_known(Atype) || lfamd_blck_size(Atype) == 1)
         return 0;
     // generic kernels given f32 activations quantise them into the workspace first
@@ -295,9 +309,9 @@ int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const v
             return LFAMD_OK;
         }
         if (Btype == LFAMD_TYPE_F32)
-            HIPCHK(lfamd_launch_prep_f32(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, s), "prep_f32");
+            HIPCHK(lfamd_launch_prep_f32(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, 0, s), "prep_f32");
         else
-            HIPCHK(lfamd_launch_prep_q8k(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, s), "prep_q8k");
+            HIPCHK(lfamd_launch_prep_q8k(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, 0, s), "prep_q8k");
         // two bodies: 128 x 128 tiles, K streamed once (gemm_wide.hip) when that grid fills the 256 CUs; the
         // 128 x 64 split-K body (gemm_mfma.hip) for smaller grids.  LFAMD_GEMM_BODY=narrow|wide forces one.
         static const char *body = getenv("LFAMD_GEMM_BODY");
@@ -310,6 +324,25 @@ int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const v
             HIPCHK(lfamd_launch_gemm_kq(Atype, d_A, m, k, Xh, d8T, Xm, n, (long)n_pad, d_C, ldc, s), "gemm_kq");
         else
             HIPCHK(lfamd_launch_gemm_wide(Atype, d_A, m, k, Xh, d8T, Xm, n, (long)n_pad, d_C, ldc, s), "gemm_wide");
+        return LFAMD_OK;
+    }
+    if (use_gemm_canon(Atype, n, flags)) {
+        size_t need = lfamd_mul_mat_workspace(Atype, m, k, n);
+        if (ws_bytes < need || !d_ws)
+            return fail(LFAMD_ERR_WORKSPACE, "mul_mat: workspace too small%s", "");
+        size_t n_pad = align_up((size_t)n, 128), nb = (size_t)(k / 256);
+        uint8_t *ws = (uint8_t *)d_ws;
+        void *Xh = ws;
+        void *d8T = ws + align_up(n_pad * (size_t)k * 2, 256);
+        void *Xm = (uint8_t *)d8T + align_up(nb * n_pad * 4, 256);
+        void *img = ws + gemm_act_ws(k, n);
+        HIPCHK(lfamd_launch_wprep16(Atype, d_A, m, k, img, s), "wprep16");
+        const int mins16 = Atype == LFAMD_TYPE_Q2_K;
+        if (Btype == LFAMD_TYPE_F32)
+            HIPCHK(lfamd_launch_prep_f32(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, mins16, s), "prep_f32");
+        else
+            HIPCHK(lfamd_launch_prep_q8k(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, mins16, s), "prep_q8k");
+        HIPCHK(lfamd_launch_gemm_wide(Atype, img, m, k, Xh, d8T, Xm, n, (long)n_pad, d_C, ldc, s), "gemm_wide");
         return LFAMD_OK;
     }
     if (use_gemm_q80(Atype, n, flags)) {
@@ -393,9 +426,9 @@ int lfamd_mul_mat_multi(int Atype, int count, const void *const *d_A, const long
             void *d8T = ws + align_up(n_pad * (size_t)k * 2, 256);
             void *Xm = (uint8_t *)d8T + align_up(nb * n_pad * 4, 256);
             if (Btype == LFAMD_TYPE_F32)
-                HIPCHK(lfamd_launch_prep_f32(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, s), "prep_f32");
+                HIPCHK(lfamd_launch_prep_f32(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, 0, s), "prep_f32");
             else
-                HIPCHK(lfamd_launch_prep_q8k(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, s), "prep_q8k");
+                HIPCHK(lfamd_launch_prep_q8k(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, 0, s), "prep_q8k");
             HIPCHK(lfamd_launch_gemm_wide_multi(Atype, count, d_A, m, k, Xh, d8T, Xm, n, (long)n_pad, d_C, ldc, s),
                    "gemm_wide_multi");
             return LFAMD_OK;

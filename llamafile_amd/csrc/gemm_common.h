@@ -52,6 +52,20 @@ __device__ static inline half8_t dequant_q5(uint32_t x, uint32_t Hd, half2_t S, 
     return f.v;
 }
 
+// codes with an offset (Q3_K: q = code - 4): -(1024 + off) * sc is not an f16 number in general (1028 * 31 needs 13
+// mantissa bits), so the offset is removed first (exact) and the scale applied by a second packed op.
+__device__ static inline half8_t dequant_q4_off(uint32_t x, half2_t S, float off, uint32_t magic) {
+    frag_u f;
+    const uint32_t y = x >> 8;
+    const half2_t o1 = bcast_h2(-(1024.0f + off)), o16 = bcast_h2(-(64.0f + off));
+    const half2_t r16 = {(_Float16)0.0625f, (_Float16)0.0625f};
+    f.p[0] = (as_half2((x & 0x000F000Fu) | magic) + o1) * S;
+    f.p[1] = pk_fma(as_half2((x & 0x00F000F0u) | magic), r16, o16) * S;
+    f.p[2] = (as_half2((y & 0x000F000Fu) | magic) + o1) * S;
+    f.p[3] = pk_fma(as_half2((y & 0x00F000F0u) | magic), r16, o16) * S;
+    return f.v;
+}
+
 // Q4_0: the code minus 8, no integer scale (the f16 block scale is applied in f32 per 32-block).
 __device__ static inline half8_t dequant_q40(uint32_t x, uint32_t magic) {
     frag_u f;

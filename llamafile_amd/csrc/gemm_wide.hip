@@ -39,6 +39,10 @@ __device__ static inline void gload16(u32x4 &dst, const void *base, uint32_t vof
     asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(base), "n"(IMM) : "memory");
 }
 template <int IMM>
+__device__ static inline void gload4(uint32_t &dst, const void *base, uint32_t voff) {
+    asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(base), "n"(IMM) : "memory");
+}
+template <int IMM>
 __device__ static inline void gload2(uint32_t &dst, const void *base, uint32_t voff) {
     asm volatile("s_nop 4\n\tglobal_load_ushort %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(base), "n"(IMM) : "memory");
 }
@@ -119,9 +123,12 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const gemm_mats mats, in
                                                         long n_pad, int n_rb, int n_ct, int ks_n, int nbs) {
     __shared__ __attribute__((aligned(16))) uint8_t xs[2][WD_XSTAGE];     // activation codes, XOR-swizzled rows
     constexpr bool LEGACY = TYPE == LFAMD_TYPE_Q4_0; // 32-blocks: f16 scale per block, Q8_0 activations (8 d8 per 256)
+    // PCK image built per call (generic.hip, wprep16): 16-wide sub-blocks, int8 scale each; Q2_K also 16 mins
+    constexpr bool CANON16 = TYPE == LFAMD_TYPE_Q2_K || TYPE == LFAMD_TYPE_Q3_K;
+    constexpr bool MINS16 = TYPE == LFAMD_TYPE_Q2_K;
     __shared__ __attribute__((aligned(16))) float d8s[2][(LEGACY ? 8 : 1) * WD_COLS]; // d8 of the 128 tokens
     __shared__ __attribute__((aligned(16))) uint8_t xms[2][WD_COLS * 32]; // Q4_K mins operand rows
-    constexpr int TILE = (TYPE == LFAMD_TYPE_Q4_K || LEGACY) ? P4K_TILE : TYPE == LFAMD_TYPE_Q5_K ? P5K_TILE : P6K_TILE;
+    constexpr int TILE = (TYPE == LFAMD_TYPE_Q4_K || LEGACY) ? P4K_TILE : TYPE == LFAMD_TYPE_Q5_K ? P5K_TILE : CANON16 ? PCK_TILE : P6K_TILE;
     constexpr bool MINS = TYPE == LFAMD_TYPE_Q4_K || TYPE == LFAMD_TYPE_Q5_K; // Q4_K family: {d, dmin, 6-bit scales/mins}
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 31, h = lane >> 5;
@@ -164,7 +171,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const gemm_mats mats, in
         const int nn = 16 * wave + 2 * e + h;
         xo[e] = (uint32_t)(nn * 512 + ((i ^ (nn & 15)) * 16));
     }
-    const uint32_t wo = lane * 16, ho = i * 16 + ((MINS || LEGACY) ? P4K_HDR : P6K_SC) - 4096; // P5K_HDR == P4K_HDR
+    const uint32_t wo = lane * 16, ho = i * 16 + ((MINS || LEGACY || CANON16) ? P4K_HDR : P6K_SC) - 4096; // P5K_HDR == PCK_SC == P4K_HDR
     const uint32_t xmo = (uint32_t)((32 * (wave & 3) + (lane >> 1)) * 32 + (lane & 1) * 16);
     const uint32_t d8o = (uint32_t)((lane >> 5) * n_pad * 4 + (lane & 31) * 16); // LEGACY d8 rows
     const uint8_t *xbase = (const uint8_t *)Xh + (size_t)n0 * 512;           // + b * n_pad * 512
@@ -188,7 +195,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const gemm_mats mats, in
                 glds1x16(uniform_ptr(d8T + ((size_t)b * 8 + 2 * (wave - 4)) * n_pad + n0), d8_a[st] + (wave - 4) * 1024, d8o);
         } else if (wave >= 6) // d8 of tokens 64*(wave-6) + lane
             glds1x4(uniform_ptr(d8T + (size_t)b * n_pad + n0), d8_a[st] + (wave - 6) * 256, (uint32_t)((wave - 6) * 256 + lane * 4));
-        if constexpr (MINS) {
+        if constexpr (MINS || MINS16) {
             if (wave < 4)
                 glds1x16(uniform_ptr(xmbase + (size_t)b * n_pad * 32), xm_a[st] + wave * 1024, xmo);
         }
@@ -198,7 +205,12 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const gemm_mats mats, in
         gload16<1024>(w.qs[1], tile, wo);
         gload16<2048>(w.qs[2], tile, wo);
         gload16<3072>(w.qs[3], tile, wo);
-        if constexpr (MINS || LEGACY) {
+        if constexpr (CANON16) {
+            gload16<0>(w.hd, tile_h, ho);            // 16 int8 scales
+            if constexpr (MINS16)
+                gload16<512>(w.qh[0], tile_h, ho);   // 16 uint8 mins (PCK_MN)
+            gload4<1024>(w.dw, tile_h, (uint32_t)(i * 4)); // {d, dmin} (PCK_D)
+        } else if constexpr (MINS || LEGACY) {
             gload16<0>(w.hd, tile_h, ho);
             if constexpr (TYPE == LFAMD_TYPE_Q5_K)
                 gload16<512>(w.qh[0], tile_h, wo); // P5K_QH = 4608
@@ -222,7 +234,12 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const gemm_mats mats, in
             gload16<1024>(w.qs[1], tile, wo);
             gload16<2048>(w.qs[2], tile, wo);
             gload16<3072>(w.qs[3], tile, wo);
-            if constexpr (MINS || LEGACY) {
+            if constexpr (CANON16) {
+                gload16<0>(w.hd, tile_h, ho);            // 16 int8 scales
+                if constexpr (MINS16)
+                    gload16<512>(w.qh[0], tile_h, ho);   // 16 uint8 mins (PCK_MN)
+                gload4<1024>(w.dw, tile_h, (uint32_t)(i * 4)); // {d, dmin} (PCK_D)
+            } else if constexpr (MINS || LEGACY) {
                 gload16<0>(w.hd, tile_h, ho);
                 if constexpr (TYPE == LFAMD_TYPE_Q5_K)
                     gload16<512>(w.qh[0], tile_h, wo);
@@ -242,7 +259,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const gemm_mats mats, in
             } else if (wave >= 6)
                 glds1x4(uniform_ptr(d8T + (size_t)b * n_pad + n0), d8_a[st] + (wave - 6) * 256, (uint32_t)((wave - 6) * 256 + lane * 4));
         } else if (t == 10) {
-            if constexpr (MINS) {
+            if constexpr (MINS || MINS16) {
                 if (wave < 4)
                     glds1x16(uniform_ptr(xmbase + (size_t)b * n_pad * 32), xm_a[st] + wave * 1024, xmo);
             }
@@ -254,6 +271,11 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const gemm_mats mats, in
         if constexpr (TYPE == LFAMD_TYPE_Q4_K || LEGACY)
             asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier"
                          : "+v"(w.qs[0]), "+v"(w.qs[1]), "+v"(w.qs[2]), "+v"(w.qs[3]), "+v"(w.hd)
+                         :
+                         : "memory");
+        else if constexpr (CANON16)
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier"
+                         : "+v"(w.qs[0]), "+v"(w.qs[1]), "+v"(w.qs[2]), "+v"(w.qs[3]), "+v"(w.hd), "+v"(w.qh[0]), "+v"(w.dw)
                          :
                          : "memory");
         else if constexpr (TYPE == LFAMD_TYPE_Q5_K)
@@ -360,6 +382,63 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const gemm_mats mats, in
                     for (int e = 0; e < 4; e++) {
                         const int r = 4 * r4 + e;
                         const float u = fmaf(-dmin, tm[r], d * tmp[nt][r]);
+                        acc[nt][r] = fmaf(u, d8[e], acc[nt][r]);
+                    }
+                }
+            }
+        } else if constexpr (CANON16) {
+            // w = d * sc_t * q - dmin * mn_t per 16-wide sub-block t (one K-step); operand sc_t * (code - OFF), exact in f16
+            constexpr float OFF = TYPE == LFAMD_TYPE_Q3_K ? 4.0f : 0.0f;
+            const uint32_t scw[4] = {w.hd.x, w.hd.y, w.hd.z, w.hd.w};
+            const float d = h2f((uint16_t)(w.dw & 0xffff)), dmin = h2f((uint16_t)(w.dw >> 16));
+            half8_t F[2][2];
+            read_frags(F[0], 0);
+#pragma unroll
+            for (int t = 0; t < 16; t++) {
+                const float scf = (float)(int)(int8_t)((scw[t >> 2] >> (8 * (t & 3))) & 0xff);
+                const half2_t S = bcast_h2(scf);
+                half8_t wf;
+                if constexpr (OFF != 0.0f) {
+                    wf = dequant_q4_off(qw[t], S, OFF, magic);
+                } else {
+                    const half2_t O = bcast_h2(-1024.0f * scf), S16 = bcast_h2(scf * 0.0625f), O16 = bcast_h2(-64.0f * scf);
+                    wf = dequant_q4(qw[t], S, O, S16, O16, magic);
+                }
+                if (t + 1 < 16) {
+                    read_frags(F[(t + 1) & 1], t + 1);
+                    ds_wait<2>(F[t & 1][0], F[t & 1][1]);
+                } else {
+                    ds_wait<0>(F[t & 1][0], F[t & 1][1]);
+                }
+#pragma unroll
+                for (int nt = 0; nt < 2; nt++)
+                    tmp[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F[t & 1][nt], wf, t == 0 ? zero16 : tmp[nt], 0, 0, 0);
+                prefetch_step(t, bn, st ^ 1, wn);
+            }
+            frag_u wm; // Q2_K: the 16 mins of this lane's row, half h = K entries 8h .. 8h+7 (matching the bsums operand)
+            if constexpr (MINS16) {
+                const uint32_t mw0 = h ? w.qh[0].z : w.qh[0].x, mw1 = h ? w.qh[0].w : w.qh[0].y;
+#pragma unroll
+                for (int p = 0; p < 4; p++) {
+                    const uint32_t mw = p < 2 ? mw0 : mw1;
+                    half2_t v = {(_Float16)(float)((mw >> (16 * (p & 1))) & 0xff), (_Float16)(float)((mw >> (16 * (p & 1) + 8)) & 0xff)};
+                    wm.p[p] = v;
+                }
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++) {
+                float16_t_ tm = zero16;
+                if constexpr (MINS16) {
+                    const half8_t xm = *(const half8_t *)(xms[st] + (ch * 64 + nt * 32 + i) * 32 + h * 16);
+                    tm = __builtin_amdgcn_mfma_f32_32x32x16_f16(xm, wm.v, zero16, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r4 = 0; r4 < 4; r4++) {
+                    const float4_t_ d8 = *(const float4_t_ *)(&d8s[st][ch * 64 + nt * 32 + 8 * r4 + 4 * h]);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const int r = 4 * r4 + e;
+                        const float u = MINS16 ? fmaf(-dmin, tm[r], d * tmp[nt][r]) : d * tmp[nt][r];
                         acc[nt][r] = fmaf(u, d8[e], acc[nt][r]);
                     }
                 }
@@ -563,6 +642,12 @@ extern "C" hipError_t lfamd_launch_gemm_wide_multi(int Atype, int count, const v
     }
     if (Atype == LFAMD_TYPE_Q4_K)
         gemm_wide_kernel<LFAMD_TYPE_Q4_K><<<n_wg, 512, 0, s>>>(mats, nb, (const _Float16 *)Xh, (const float *)d8T,
+                                                                (const _Float16 *)Xm, n, n_pad, n_rb, n_ct, ks, nbs);
+    else if (Atype == LFAMD_TYPE_Q2_K)
+        gemm_wide_kernel<LFAMD_TYPE_Q2_K><<<n_wg, 512, 0, s>>>(mats, nb, (const _Float16 *)Xh, (const float *)d8T,
+                                                                (const _Float16 *)Xm, n, n_pad, n_rb, n_ct, ks, nbs);
+    else if (Atype == LFAMD_TYPE_Q3_K)
+        gemm_wide_kernel<LFAMD_TYPE_Q3_K><<<n_wg, 512, 0, s>>>(mats, nb, (const _Float16 *)Xh, (const float *)d8T,
                                                                 (const _Float16 *)Xm, n, n_pad, n_rb, n_ct, ks, nbs);
     else if (Atype == LFAMD_TYPE_Q4_0)
         gemm_wide_kernel<LFAMD_TYPE_Q4_0><<<n_wg, 512, 0, s>>>(mats, nb, (const _Float16 *)Xh, (const float *)d8T,

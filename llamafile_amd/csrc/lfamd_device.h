@@ -30,6 +30,12 @@
 #define P5K_TILE 5632 // P4K (qs 4096 + hdr 512) + 1024 B of fifth bits
 #define P5K_HDR 4096
 #define P5K_QH 4608
+// PCK: canonical per-call image the GEMM builds in its workspace for K-quants without a resident packed layout
+// (Q2_K, Q3_K): P4K-form nibble image of (q - qmin), then per row 16 int8 sub-block scales, 16 uint8 mins, {d, dmin}
+#define PCK_TILE 5248
+#define PCK_SC 4096
+#define PCK_MN 4608
+#define PCK_D 5120
 #define P6K_TILE 6720
 #define P6K_QH 4096
 #define P6K_SC 6144

@@ -301,8 +301,9 @@ __global__ void pack_raw_kernel(const uint8_t *__restrict__ raw, size_t raw_row_
 //                             (|S_j| <= 4096) the split S_j = 64*hi_j + lo_j, lo in [0,63]:
 //                             elements 0..7 = lo_j, 8..15 = hi_j (both exact in f16)
 
+// mins16: Xm holds the 16 bsums themselves (exact in f16, |sum| <= 2032) for the types with 16-wide sub-blocks (Q2_K)
 __global__ void prep_q8k_kernel(const uint8_t *__restrict__ B, size_t b_row_bytes, long n, long n_pad, int nb,
-                                _Float16 *__restrict__ Xh, float *__restrict__ d8T, _Float16 *__restrict__ Xm) {
+                                _Float16 *__restrict__ Xh, float *__restrict__ d8T, _Float16 *__restrict__ Xm, int mins16) {
     long blk = blockIdx.x; // (token, super-block)
     long tok = blk / nb;
     int b = (int)(blk % nb);
@@ -315,7 +316,10 @@ __global__ void prep_q8k_kernel(const uint8_t *__restrict__ B, size_t b_row_byte
             xo[4 * t + e] = (_Float16)(int)(int8_t)(q >> (8 * e));
         if (t == 0)
             d8T[(size_t)b * n_pad + tok] = y->d;
-        if (t < 8) {
+        if (mins16) {
+            if (t < 16)
+                Xm[((size_t)b * n_pad + tok) * 16 + t] = (_Float16)(int)y->bsums[t];
+        } else if (t < 8) {
             int S = (int)y->bsums[2 * t] + (int)y->bsums[2 * t + 1];
             int lo = S & 63, hi = (S - lo) / 64;
             _Float16 *mo = Xm + ((size_t)b * n_pad + tok) * 16;
@@ -337,7 +341,7 @@ __global__ void prep_q8k_kernel(const uint8_t *__restrict__ B, size_t b_row_byte
 // the Q8_K blocks.  One wave per (token, super-block), 4 values per lane.
 __global__ __launch_bounds__(64) void prep_f32_kernel(const uint8_t *__restrict__ X, size_t x_row_bytes, long n, long n_pad,
                                                       int nb, _Float16 *__restrict__ Xh, float *__restrict__ d8T,
-                                                      _Float16 *__restrict__ Xm) {
+                                                      _Float16 *__restrict__ Xm, int mins16) {
     long blk = blockIdx.x;
     long tok = blk / nb;
     int b = (int)(blk % nb);
@@ -393,8 +397,10 @@ __global__ __launch_bounds__(64) void prep_f32_kernel(const uint8_t *__restrict_
     int S = q[0] + q[1] + q[2] + q[3]; // pair sum j = t/8 covers codes 32j..32j+31 = lanes 8j..8j+7
     S += __shfl_xor(S, 1, 64);
     S += __shfl_xor(S, 2, 64);
+    if (mins16 && (t & 3) == 0) // bsums[t/4]: codes 16(t/4) .. +15
+        Xm[((size_t)b * n_pad + tok) * 16 + (t >> 2)] = (_Float16)S;
     S += __shfl_xor(S, 4, 64);
-    if ((t & 7) == 0) {
+    if (!mins16 && (t & 7) == 0) {
         int j = t >> 3;
         int lo = S & 63, hi = (S - lo) / 64;
         _Float16 *mo = Xm + ((size_t)b * n_pad + tok) * 16;
@@ -514,13 +520,13 @@ hipError_t lfamd_launch_pack_raw(const void *raw, size_t raw_row_bytes, long row
 }
 
 hipError_t lfamd_launch_prep_f32(const void *X, size_t x_row_bytes, long n, long n_pad, long cols, void *Xh, void *d8T,
-                                 void *Xm, hipStream_t s) {
+                                 void *Xm, int mins16, hipStream_t s) {
     int nb = (int)(cols / 256);
     long blocks = n_pad * nb;
     if (blocks == 0)
         return hipSuccess;
     prep_f32_kernel<<<(unsigned)blocks, 64, 0, s>>>((const uint8_t *)X, x_row_bytes, n, n_pad, nb, (_Float16 *)Xh,
-                                                     (float *)d8T, (_Float16 *)Xm);
+                                                     (float *)d8T, (_Float16 *)Xm, mins16);
     return hipGetLastError();
 }
 
@@ -540,13 +546,13 @@ hipError_t lfamd_launch_prep80(int Btype, const void *B, size_t b_row_bytes, lon
 }
 
 hipError_t lfamd_launch_prep_q8k(const void *B, size_t b_row_bytes, long n, long n_pad, long cols, void *Xh, void *d8T,
-                                 void *Xm, hipStream_t s) {
+                                 void *Xm, int mins16, hipStream_t s) {
     int nb = (int)(cols / 256);
     long blocks = n_pad * nb;
     if (blocks == 0)
         return hipSuccess;
     prep_q8k_kernel<<<(unsigned)blocks, 64, 0, s>>>((const uint8_t *)B, b_row_bytes, n, n_pad, nb, (_Float16 *)Xh,
-                                                     (float *)d8T, (_Float16 *)Xm);
+                                                     (float *)d8T, (_Float16 *)Xm, mins16);
     return hipGetLastError();
 }
 }

@@ -96,6 +96,28 @@ def test_mfma_bodies_agree_and_repeat(gpu, t):
     assert rel_err(w1, nr) <= 2e-6
 
 
+@pytest.mark.parametrize("t", [T.Q2_K, T.Q3_K], ids=lambda t: T.NAMES[t])
+@pytest.mark.parametrize("shape", [(128, 64, 512), (96, 100, 1024), (33, 9, 256), (200, 300, 1280), (64, 130, 768)], ids=str)
+@pytest.mark.parametrize("f32in", [False, True], ids=["q8k", "f32"])
+def test_canonical_image_gemm_vs_oracle(gpu, oracle, t, shape, f32in):
+    """Q2_K / Q3_K batches: RAW weights are canonicalised per call (wprep16 -> PCK image) and run on the 128x128 MFMA
+    body; integer parts exact (sc*q <= 128), Q2_K mins through one MFMA on the 16 bsums."""
+    from llamafile_amd import synth
+    m, n, k = shape
+    A = synth.random_weights(t, m, k, 500 + t)
+    x = synth.random_activations(n, k, 501)
+    B = synth.quantize_activations(T.Q8_K, x)
+    ok, G = oracle.sgemm(t, A, T.Q8_K, B, m, n, k, nth=2)
+    assert ok == 1
+    W = gpu.upload_weights(t, A, m, k)
+    if f32in:
+        C = gpu.mul_mat(W, torch.from_numpy(x).cuda().view(torch.uint8).view(n, k * 4), T.F32)
+    else:
+        C = gpu.mul_mat(W, torch.from_numpy(B).cuda(), T.Q8_K)
+    torch.cuda.synchronize()
+    assert rel_err(C.cpu().numpy(), G) <= DEFAULT_TOL
+
+
 @pytest.mark.parametrize("t", [T.Q4_0, T.Q5_K, T.IQ4_XS, T.Q2_K], ids=lambda t: T.NAMES[t])
 def test_generic_large_n(gpu, oracle, t):
     m, n, k = 64, 40, 512
