@@ -12,7 +12,9 @@
 extern "C" {
 hipError_t lfamd_launch_pack_q4k(const void *, size_t, long, long, void *, hipStream_t);
 hipError_t lfamd_launch_pack_q40(const void *, size_t, long, long, void *, hipStream_t);
-hipError_t lfamd_launch_prep80(int, const void *, size_t, long, long, long, void *, void *, hipStream_t);
+hipError_t lfamd_launch_prep80(int, const void *, size_t, long, long, long, void *, void *, void *, hipStream_t);
+hipError_t lfamd_launch_wprep32(int, const void *, long, long, void *, hipStream_t);
+size_t lfamd_wprep32_bytes(long, long);
 hipError_t lfamd_launch_pack_q5k(const void *, size_t, long, long, void *, hipStream_t);
 hipError_t lfamd_launch_pack_q6k(const void *, size_t, long, long, void *, hipStream_t);
 hipError_t lfamd_launch_pack_q80(const void *, size_t, long, long, void *, hipStream_t);
@@ -237,6 +239,12 @@ static size_t gemm_act_ws(long k, long n) { // Xh + d8T + Xm of the K-quant GEMM
     return align_up(n_pad * (size_t)k * 2, 256) + align_up(nb * n_pad * 4, 256) + align_up(n_pad * nb * 32, 256);
 }
 
+// legacy 32-block types kept in RAW layout (Q4_1, Q5_0, Q5_1; rows of whole 256-weight groups): per-call PCL image
+static bool use_gemm_canon32(int Atype, long n, unsigned flags, long k) {
+    return !(flags & LFAMD_FLAG_FORCE_GENERIC) && n > 8 && k % 256 == 0 &&
+           (Atype == LFAMD_TYPE_Q4_1 || Atype == LFAMD_TYPE_Q5_0 || Atype == LFAMD_TYPE_Q5_1);
+}
+
 // Q8_0 batches: the register-tiled bit-exact kernel (gemm_q80.hip)
 static bool use_gemm_q80(int Atype, long n, unsigned flags) {
     return !(flags & LFAMD_FLAG_FORCE_GENERIC) && n > 8 && Atype == LFAMD_TYPE_Q8_0;
@@ -266,6 +274,10 @@ size_t lfamd_mul_mat_workspace(int Atype, long m, long k, long n) {
         return align_up(lfamd_gemm_q80_workspace(k, n), 256);
     if (use_gemm_canon(Atype, n, 0))
         return gemm_act_ws(k, n) + align_up(lfamd_wprep16_bytes(m, k), 256);
+    if (use_gemm_canon32(Atype, n, 0, k)) { // Xh, d8T [nb*8][n_pad], sT [nb*8][n_pad], image
+        size_t n_pad = align_up((size_t)n, 128), nb = (size_t)(k / 256);
+        return align_up(n_pad * (size_t)k * 2, 256) + 2 * align_up(nb * 8 * n_pad * 4, 256) + align_up(lfamd_wprep32_bytes(m, k), 256);
+    }
     if (use_gemv(Atype, n, 0, k) || !type_known(Atype) || lfamd_blck_size(Atype) == 1)
         return 0;
     // generic kernels given f32 activations quantise them into the workspace first
@@ -304,7 +316,7 @@ int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const v
         void *d8T = ws + align_up(n_pad * (size_t)k * 2, 256);
         void *Xm = (uint8_t *)d8T + align_up(nb * n_pad * 4, 256);
         if (Atype == LFAMD_TYPE_Q4_0) { // Q8_0-quantised activations, eight scales per 256 (they take the Xm area too)
-            HIPCHK(lfamd_launch_prep80(Btype, d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, s), "prep80");
+            HIPCHK(lfamd_launch_prep80(Btype, d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, nullptr, s), "prep80");
             HIPCHK(lfamd_launch_gemm_wide(Atype, d_A, m, k, Xh, d8T, nullptr, n, (long)n_pad, d_C, ldc, s), "gemm_wide");
             return LFAMD_OK;
         }
@@ -324,6 +336,22 @@ int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const v
             HIPCHK(lfamd_launch_gemm_kq(Atype, d_A, m, k, Xh, d8T, Xm, n, (long)n_pad, d_C, ldc, s), "gemm_kq");
         else
             HIPCHK(lfamd_launch_gemm_wide(Atype, d_A, m, k, Xh, d8T, Xm, n, (long)n_pad, d_C, ldc, s), "gemm_wide");
+        return LFAMD_OK;
+    }
+    if (use_gemm_canon32(Atype, n, flags, k)) {
+        size_t need = lfamd_mul_mat_workspace(Atype, m, k, n);
+        if (ws_bytes < need || !d_ws)
+            return fail(LFAMD_ERR_WORKSPACE, "mul_mat: workspace too small%s", "");
+        size_t n_pad = align_up((size_t)n, 128), nb = (size_t)(k / 256);
+        uint8_t *ws = (uint8_t *)d_ws;
+        void *Xh = ws;
+        void *d8T = ws + align_up(n_pad * (size_t)k * 2, 256);
+        void *sT = (uint8_t *)d8T + align_up(nb * 8 * n_pad * 4, 256);
+        void *img = (uint8_t *)sT + align_up(nb * 8 * n_pad * 4, 256);
+        const bool q81 = vdt == LFAMD_TYPE_Q8_1;
+        HIPCHK(lfamd_launch_wprep32(Atype, d_A, m, k, img, s), "wprep32");
+        HIPCHK(lfamd_launch_prep80(Btype, d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, q81 ? sT : nullptr, s), "prep80");
+        HIPCHK(lfamd_launch_gemm_wide(Atype, img, m, k, Xh, d8T, q81 ? sT : nullptr, n, (long)n_pad, d_C, ldc, s), "gemm_wide");
         return LFAMD_OK;
     }
     if (use_gemm_canon(Atype, n, flags)) {

@@ -80,6 +80,28 @@ __device__ static inline half8_t dequant_q40(uint32_t x, uint32_t magic) {
     return f.v;
 }
 
+// legacy 32-block types on a per-call image: code (4 or 5 bits, fifth bits Hd on the P5K lattice) minus `off`, no scale
+template <bool H5>
+__device__ static inline half8_t dequant_legacy(uint32_t x, uint32_t Hd, float off, uint32_t magic) {
+    frag_u f;
+    const uint32_t y = x >> 8;
+    const half2_t o1 = bcast_h2(-(1024.0f + off)), o16 = bcast_h2(-(64.0f + off));
+    const half2_t r16 = {(_Float16)0.0625f, (_Float16)0.0625f};
+    uint32_t c0 = (x & 0x000F000Fu) | magic, c1 = (x & 0x00F000F0u) | magic, c2 = (y & 0x000F000Fu) | magic,
+             c3 = (y & 0x00F000F0u) | magic;
+    if constexpr (H5) {
+        c0 |= Hd & 0x00100010u;
+        c1 |= Hd & 0x01000100u;
+        c2 |= (Hd >> 8) & 0x00100010u;
+        c3 |= (Hd << 8) & 0x01000100u;
+    }
+    f.p[0] = as_half2(c0) + o1;
+    f.p[1] = pk_fma(as_half2(c1), r16, o16);
+    f.p[2] = as_half2(c2) + o1;
+    f.p[3] = pk_fma(as_half2(c3), r16, o16);
+    return f.v;
+}
+
 __device__ static inline uint32_t opaque_magic() {
     uint32_t magic = 0x64006400u;
     asm volatile("" : "+v"(magic)); // keep it a register value (see dequant_q4)

@@ -122,13 +122,18 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const gemm_mats mats, in
                                                         const float *__restrict__ d8T, const _Float16 *__restrict__ Xm, long n,
                                                         long n_pad, int n_rb, int n_ct, int ks_n, int nbs) {
     __shared__ __attribute__((aligned(16))) uint8_t xs[2][WD_XSTAGE];     // activation codes, XOR-swizzled rows
-    constexpr bool LEGACY = TYPE == LFAMD_TYPE_Q4_0; // 32-blocks: f16 scale per block, Q8_0 activations (8 d8 per 256)
+    // 32-blocks: f16 scale per block, Q8_0 / Q8_1 activations (8 d8 per 256).  Q4_0 is resident in P40; Q4_1 / Q5_0 / Q5_1
+    // come as a per-call PCL image (generic.hip, wprep32): L5 = fifth bits, L1 = w = d*q + m with the s = d8*sum(q8) term
+    constexpr bool LEGACY = TYPE == LFAMD_TYPE_Q4_0 || TYPE == LFAMD_TYPE_Q4_1 || TYPE == LFAMD_TYPE_Q5_0 || TYPE == LFAMD_TYPE_Q5_1;
+    constexpr bool L5 = TYPE == LFAMD_TYPE_Q5_0 || TYPE == LFAMD_TYPE_Q5_1;
+    constexpr bool L1 = TYPE == LFAMD_TYPE_Q4_1 || TYPE == LFAMD_TYPE_Q5_1;
+    constexpr float LOFF = TYPE == LFAMD_TYPE_Q4_0 ? 8.0f : TYPE == LFAMD_TYPE_Q5_0 ? 16.0f : 0.0f;
     // PCK image built per call (generic.hip, wprep16): 16-wide sub-blocks, int8 scale each; Q2_K also 16 mins
     constexpr bool CANON16 = TYPE == LFAMD_TYPE_Q2_K || TYPE == LFAMD_TYPE_Q3_K;
     constexpr bool MINS16 = TYPE == LFAMD_TYPE_Q2_K;
     __shared__ __attribute__((aligned(16))) float d8s[2][(LEGACY ? 8 : 1) * WD_COLS]; // d8 of the 128 tokens
-    __shared__ __attribute__((aligned(16))) uint8_t xms[2][WD_COLS * 32]; // Q4_K mins operand rows
-    constexpr int TILE = (TYPE == LFAMD_TYPE_Q4_K || LEGACY) ? P4K_TILE : TYPE == LFAMD_TYPE_Q5_K ? P5K_TILE : CANON16 ? PCK_TILE : P6K_TILE;
+    __shared__ __attribute__((aligned(16))) uint8_t xms[2][WD_COLS * 32]; // Q4_K mins operand rows; L1: the 8 x 128 f32 s values
+    constexpr int TILE = (TYPE == LFAMD_TYPE_Q4_K || TYPE == LFAMD_TYPE_Q4_0) ? P4K_TILE : LEGACY ? PCL_TILE : TYPE == LFAMD_TYPE_Q5_K ? P5K_TILE : CANON16 ? PCK_TILE : P6K_TILE;
     constexpr bool MINS = TYPE == LFAMD_TYPE_Q4_K || TYPE == LFAMD_TYPE_Q5_K; // Q4_K family: {d, dmin, 6-bit scales/mins}
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 31, h = lane >> 5;
@@ -199,6 +204,10 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const gemm_mats mats, in
             if (wave < 4)
                 glds1x16(uniform_ptr(xmbase + (size_t)b * n_pad * 32), xm_a[st] + wave * 1024, xmo);
         }
+        if constexpr (L1) { // Xm carries sT [nb*8][n_pad] f32 here
+            if (wave < 4)
+                glds1x16(uniform_ptr((const float *)Xm + ((size_t)b * 8 + 2 * wave) * n_pad + n0), xm_a[st] + wave * 1024, d8o);
+        }
         const uint8_t *tile = uniform_ptr(wbase + (size_t)b * TILE);
         const uint8_t *tile_h = uniform_ptr(tile + 4096), *tile_d = uniform_ptr(tile + P6K_D);
         gload16<0>(w.qs[0], tile, wo);
@@ -213,7 +222,11 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const gemm_mats mats, in
         } else if constexpr (MINS || LEGACY) {
             gload16<0>(w.hd, tile_h, ho);
             if constexpr (TYPE == LFAMD_TYPE_Q5_K)
-                gload16<512>(w.qh[0], tile_h, wo); // P5K_QH = 4608
+                gload16<512>(w.qh[0], tile_h, wo);
+            if constexpr (L1)
+                gload16<512>(w.qh[1], tile_h, ho);  // eight f16 m (PCL_M)
+            if constexpr (L5)
+                gload16<1024>(w.qh[0], tile_h, wo); // fifth bits (PCL_QH) // P5K_QH = 4608
         } else {
             gload16<0>(w.qh[0], tile_h, wo);    // P6K_QH = 4096
             gload16<1024>(w.qh[1], tile_h, wo);
@@ -243,6 +256,10 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const gemm_mats mats, in
                 gload16<0>(w.hd, tile_h, ho);
                 if constexpr (TYPE == LFAMD_TYPE_Q5_K)
                     gload16<512>(w.qh[0], tile_h, wo);
+                if constexpr (L1)
+                    gload16<512>(w.qh[1], tile_h, ho);  // eight f16 m (PCL_M)
+                if constexpr (L5)
+                    gload16<1024>(w.qh[0], tile_h, wo); // fifth bits (PCL_QH)
             } else {
                 gload16<0>(w.qh[0], tile_h, wo);
                 gload16<1024>(w.qh[1], tile_h, wo);
@@ -263,12 +280,21 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const gemm_mats mats, in
                 if (wave < 4)
                     glds1x16(uniform_ptr(xmbase + (size_t)b * n_pad * 32), xm_a[st] + wave * 1024, xmo);
             }
+            if constexpr (L1) {
+                if (wave < 4)
+                    glds1x16(uniform_ptr((const float *)Xm + ((size_t)b * 8 + 2 * wave) * n_pad + n0), xm_a[st] + wave * 1024, d8o);
+            }
         }
     };
     // retire every load of the stage (this wave's), then meet the other waves: their LDS-DMA has landed too, and
     // everybody has finished reading the stage that the next prefetch overwrites
     auto arrive = [&](wide_w<TYPE> &w) {
-        if constexpr (TYPE == LFAMD_TYPE_Q4_K || LEGACY)
+        if constexpr (L1 || L5)
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier"
+                         : "+v"(w.qs[0]), "+v"(w.qs[1]), "+v"(w.qs[2]), "+v"(w.qs[3]), "+v"(w.hd), "+v"(w.qh[0]), "+v"(w.qh[1])
+                         :
+                         : "memory");
+        else if constexpr (TYPE == LFAMD_TYPE_Q4_K || LEGACY)
             asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier"
                          : "+v"(w.qs[0]), "+v"(w.qs[1]), "+v"(w.qs[2]), "+v"(w.qs[3]), "+v"(w.hd)
                          :
@@ -445,6 +471,12 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const gemm_mats mats, in
             }
         } else if constexpr (LEGACY) {
             const uint32_t hdw[4] = {w.hd.x, w.hd.y, w.hd.z, w.hd.w}; // eight f16 block scales of this lane's row
+            const uint32_t mdw[4] = {w.qh[1].x, w.qh[1].y, w.qh[1].z, w.qh[1].w}; // L1: eight f16 m
+            const uint32_t hq5[4] = {w.qh[0].x, w.qh[0].y, w.qh[0].z, w.qh[0].w}; // L5: fifth bits
+            (void)mdw;
+            (void)hq5;
+            const uint32_t s8base = xm_a[0] + (uint32_t)((ch * 64 + 4 * h) * 4);
+            (void)s8base;
             const uint32_t d8base = d8_lane; // LDS address of d8s[0][ch * 64 + 4 * h]
             half8_t F[2][2];
             read_frags(F[0], 0);
@@ -453,7 +485,11 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const gemm_mats mats, in
 #pragma unroll
                 for (int e = 0; e < 2; e++) {
                     const int t = 2 * bl + e;
-                    const half8_t wf = dequant_q40(qw[t], magic);
+                    half8_t wf;
+                    if constexpr (TYPE == LFAMD_TYPE_Q4_0)
+                        wf = dequant_q40(qw[t], magic);
+                    else
+                        wf = dequant_legacy<L5>(qw[t], L5 ? (hq5[t >> 2] >> (t & 3)) : 0u, LOFF, magic);
                     if (t + 1 < 16) {
                         read_frags(F[(t + 1) & 1], t + 1);
                         ds_wait<2>(F[t & 1][0], F[t & 1][1]);
@@ -485,6 +521,21 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const gemm_mats mats, in
                             const int r = 4 * r4 + e;
                             acc[nt][r] = fmaf(tmp[nt][r] * d8[r4][e], dbl, acc[nt][r]);
                         }
+                    if constexpr (L1) { // + m[row] * s[token]   (iqk_mul_mat.inc:1110-1127, MinusType1)
+                        float4_t_ s8[4];
+                        asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%5+32\n\t"
+                                     "ds_read_b128 %2, %4 offset:%5+64\n\tds_read_b128 %3, %4 offset:%5+96\n\ts_waitcnt lgkmcnt(0)"
+                                     : "=&v"(s8[0]), "=&v"(s8[1]), "=&v"(s8[2]), "=&v"(s8[3])
+                                     : "v"(s8base), "n"(st * 8 * WD_COLS * 4 + bl * WD_COLS * 4 + nt * 128));
+                        const float mbl = h2f((uint16_t)((bl & 1) ? (mdw[bl >> 1] >> 16) : (mdw[bl >> 1] & 0xffff)));
+#pragma unroll
+                        for (int r4 = 0; r4 < 4; r4++)
+#pragma unroll
+                            for (int e = 0; e < 4; e++) {
+                                const int r = 4 * r4 + e;
+                                acc[nt][r] = fmaf(mbl, s8[r4][e], acc[nt][r]);
+                            }
+                    }
                 }
                 // pin the scaling HERE: an empty volatile asm on the accumulators is ordered before the next K-step's
                 // asm reads.  Left free, hipcc sinks all eight blocks' scaling below the MFMAs, keeps 8 x (tmp + d8)
@@ -648,6 +699,15 @@ extern "C" hipError_t lfamd_launch_gemm_wide_multi(int Atype, int count, const v
                                                                 (const _Float16 *)Xm, n, n_pad, n_rb, n_ct, ks, nbs);
     else if (Atype == LFAMD_TYPE_Q3_K)
         gemm_wide_kernel<LFAMD_TYPE_Q3_K><<<n_wg, 512, 0, s>>>(mats, nb, (const _Float16 *)Xh, (const float *)d8T,
+                                                                (const _Float16 *)Xm, n, n_pad, n_rb, n_ct, ks, nbs);
+    else if (Atype == LFAMD_TYPE_Q4_1)
+        gemm_wide_kernel<LFAMD_TYPE_Q4_1><<<n_wg, 512, 0, s>>>(mats, nb, (const _Float16 *)Xh, (const float *)d8T,
+                                                                (const _Float16 *)Xm, n, n_pad, n_rb, n_ct, ks, nbs);
+    else if (Atype == LFAMD_TYPE_Q5_0)
+        gemm_wide_kernel<LFAMD_TYPE_Q5_0><<<n_wg, 512, 0, s>>>(mats, nb, (const _Float16 *)Xh, (const float *)d8T,
+                                                                (const _Float16 *)Xm, n, n_pad, n_rb, n_ct, ks, nbs);
+    else if (Atype == LFAMD_TYPE_Q5_1)
+        gemm_wide_kernel<LFAMD_TYPE_Q5_1><<<n_wg, 512, 0, s>>>(mats, nb, (const _Float16 *)Xh, (const float *)d8T,
                                                                 (const _Float16 *)Xm, n, n_pad, n_rb, n_ct, ks, nbs);
     else if (Atype == LFAMD_TYPE_Q4_0)
         gemm_wide_kernel<LFAMD_TYPE_Q4_0><<<n_wg, 512, 0, s>>>(mats, nb, (const _Float16 *)Xh, (const float *)d8T,

@@ -358,6 +358,88 @@ __global__ void wprep16_kernel(const uint8_t *__restrict__ raw, size_t raw_row_b
     }
 }
 
+// Legacy 32-block types (Q4_1, Q5_0, Q5_1) -> PCL tiles.  Weight l of a block: low nibble of qs[l] (l < 16) or high
+// nibble of qs[l - 16], fifth bit = bit l of qh (iqk_mul_mat.inc:1241-1283).
+template <int TYPE>
+__global__ void wprep32_kernel(const uint8_t *__restrict__ raw, size_t raw_row_bytes, long rows, int nb, uint8_t *__restrict__ out,
+                               long n_tiles) {
+    constexpr bool HAS_M = TYPE == LFAMD_TYPE_Q4_1 || TYPE == LFAMD_TYPE_Q5_1;
+    constexpr bool HAS_H = TYPE == LFAMD_TYPE_Q5_0 || TYPE == LFAMD_TYPE_Q5_1;
+    constexpr int BS = TYPE == LFAMD_TYPE_Q4_1 ? 20 : TYPE == LFAMD_TYPE_Q5_0 ? 22 : 24;
+    constexpr int QH_OFF = HAS_M ? 4 : 2, QS_OFF = QH_OFF + (HAS_H ? 4 : 0);
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long tile = tid / 1536; // 1024 code dwords + 128 d + 128 m + 256 fifth-bit dwords
+    const int w = (int)(tid % 1536);
+    if (tile >= n_tiles)
+        return;
+    const long rt = tile / nb;
+    const int b = (int)(tile % nb);
+    uint32_t *dst = (uint32_t *)(out + tile * PCL_TILE);
+    uint32_t v = 0;
+    if (w < 1024) {
+        const int g = w >> 8, lane = (w >> 2) & 63, dd = w & 3;
+        const int i = lane & 31, h = lane >> 5;
+        const long row = rt * 32 + i;
+        if (row < rows) {
+            const uint8_t *blk0 = raw + row * raw_row_bytes + (size_t)b * 8 * BS;
+            const int t = 4 * g + dd;
+            for (int j = 0; j < 8; j++) {
+                const int k = 16 * t + 8 * h + j, bl = k >> 5, l = k & 31;
+                const uint8_t byte = blk0[bl * BS + QS_OFF + (l & 15)];
+                v |= (uint32_t)(l < 16 ? (byte & 15) : (byte >> 4)) << (4 * NIBPOS(j));
+            }
+        }
+    } else if (w < 1280) {
+        const int s4 = w - 1024, is_m = s4 >= 128;
+        const int i = (s4 & 127) >> 2, q = s4 & 3;
+        const long row = rt * 32 + i;
+        if (row < rows && (!is_m || HAS_M)) {
+            const uint8_t *blk0 = raw + row * raw_row_bytes + (size_t)b * 8 * BS;
+            const uint16_t lo = *(const uint16_t *)(blk0 + (2 * q) * BS + (is_m ? 2 : 0));
+            const uint16_t hi = *(const uint16_t *)(blk0 + (2 * q + 1) * BS + (is_m ? 2 : 0));
+            v = (uint32_t)lo | ((uint32_t)hi << 16);
+        }
+    } else {
+        const int s = w - 1280, lane = s >> 2, g = s & 3;
+        const int i = lane & 31, h = lane >> 5;
+        const long row = rt * 32 + i;
+        if (row < rows && HAS_H) {
+            const uint8_t *blk0 = raw + row * raw_row_bytes + (size_t)b * 8 * BS;
+            for (int dd = 0; dd < 4; dd++) {
+                const int t = 4 * g + dd;
+                for (int j = 0; j < 8; j++) {
+                    const int k = 16 * t + 8 * h + j, bl = k >> 5, l = k & 31;
+                    const uint8_t *qh = blk0 + bl * BS + QH_OFF;
+                    const uint32_t bit = (qh[l >> 3] >> (l & 7)) & 1u;
+                    v |= bit << (4 * q5hpos(j) + dd);
+                }
+            }
+        }
+    }
+    dst[w] = v;
+}
+
+extern "C" size_t lfamd_wprep32_bytes(long rows, long cols) {
+    return (size_t)((rows + 31) / 32) * (size_t)(cols / 256) * PCL_TILE;
+}
+
+extern "C" hipError_t lfamd_launch_wprep32(int type, const void *raw, long rows, long cols, void *out, hipStream_t s) {
+    const int nb = (int)(cols / 256);
+    const long n_tiles = ((rows + 31) / 32) * nb;
+    const long threads = n_tiles * 1536;
+    const size_t rrb = lfamd_row_size(type, cols);
+    const unsigned grid = (unsigned)((threads + 255) / 256);
+    if (type == LFAMD_TYPE_Q4_1)
+        wprep32_kernel<LFAMD_TYPE_Q4_1><<<grid, 256, 0, s>>>((const uint8_t *)raw, rrb, rows, nb, (uint8_t *)out, n_tiles);
+    else if (type == LFAMD_TYPE_Q5_0)
+        wprep32_kernel<LFAMD_TYPE_Q5_0><<<grid, 256, 0, s>>>((const uint8_t *)raw, rrb, rows, nb, (uint8_t *)out, n_tiles);
+    else if (type == LFAMD_TYPE_Q5_1)
+        wprep32_kernel<LFAMD_TYPE_Q5_1><<<grid, 256, 0, s>>>((const uint8_t *)raw, rrb, rows, nb, (uint8_t *)out, n_tiles);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
 extern "C" size_t lfamd_wprep16_bytes(long rows, long cols) {
     return (size_t)((rows + 31) / 32) * (size_t)(cols / 256) * PCK_TILE;
 }

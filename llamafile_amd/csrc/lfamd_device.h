@@ -36,6 +36,12 @@
 #define PCK_SC 4096
 #define PCK_MN 4608
 #define PCK_D 5120
+// PCL: per-call image for the legacy 32-block types without a resident packed layout (Q4_1, Q5_0, Q5_1): nibble image,
+// eight f16 d and eight f16 m per row, fifth bits on the P5K lattice
+#define PCL_TILE 6144
+#define PCL_D 4096
+#define PCL_M 4608
+#define PCL_QH 5120
 #define P6K_TILE 6720
 #define P6K_QH 4096
 #define P6K_SC 6144

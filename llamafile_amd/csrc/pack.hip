@@ -414,9 +414,10 @@ __global__ __launch_bounds__(64) void prep_f32_kernel(const uint8_t *__restrict_
 // Activation preparation for the legacy 32-block weight types (Q4_0 ...): Q8_0 quantisation (upstream
 // quantize_row_q8_0: d = amax/127 stored as f16, q = roundf(x/d)) ->
 //   Xh  [nb][n_pad][256] f16 codes (as above);  d8T [nb*8][n_pad] f32 block scales.  One wave per (super-block, token).
-template <bool F32IN>
+// Q81: Q8_1 activations (Q4_1 / Q5_1 weights): additionally sT [nb*8][n_pad] = the block's s = f16(d * sum(q)).
+template <bool F32IN, bool Q81>
 __global__ __launch_bounds__(256) void prep80_kernel(const uint8_t *__restrict__ X, size_t x_row_bytes, long n, long n_pad, int nb,
-                                                    _Float16 *__restrict__ Xh, float *__restrict__ d8T) {
+                                                    _Float16 *__restrict__ Xh, float *__restrict__ d8T, float *__restrict__ sT) {
     typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
     long blk = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (blk >= (long)nb * n_pad)
@@ -425,7 +426,7 @@ __global__ __launch_bounds__(256) void prep80_kernel(const uint8_t *__restrict__
     long tok = blk - (long)b * n_pad;
     int t = threadIdx.x & 63; // codes 4t..4t+3 of the super-block: 32-block t >> 3
     int q[4] = {0, 0, 0, 0};
-    float d = 0.0f;
+    float d = 0.0f, sv = 0.0f;
     if (tok < n) {
         if constexpr (F32IN) {
             const float4 f = *(const float4 *)((const float *)(X + tok * x_row_bytes) + (size_t)b * 256 + 4 * t);
@@ -440,9 +441,19 @@ __global__ __launch_bounds__(256) void prep80_kernel(const uint8_t *__restrict__
             for (int e = 0; e < 4; e++)
                 q[e] = (int)roundf(v[e] * id);
             d = h2f(f2h_bits(dd));
+            if constexpr (Q81) { // upstream quantize_row_q8_1: s = f16(sum * d), d not yet rounded
+                int sum = q[0] + q[1] + q[2] + q[3];
+                sum += __shfl_xor(sum, 1, 64);
+                sum += __shfl_xor(sum, 2, 64);
+                sum += __shfl_xor(sum, 4, 64);
+                sv = h2f(f2h_bits((float)sum * dd));
+            }
         } else {
-            const uint8_t *y = X + tok * x_row_bytes + (size_t)(b * 8 + (t >> 3)) * 34; // 34-byte blocks: 2-byte aligned
-            const uint16_t *p = (const uint16_t *)(y + 2 + 4 * (t & 7));
+            constexpr int BSZ = Q81 ? 36 : 34, QOFF = Q81 ? 4 : 2;
+            const uint8_t *y = X + tok * x_row_bytes + (size_t)(b * 8 + (t >> 3)) * BSZ; // 2-byte aligned blocks
+            const uint16_t *p = (const uint16_t *)(y + QOFF + 4 * (t & 7));
+            if constexpr (Q81)
+                sv = h2f(*(const uint16_t *)(y + 2));
             const uint32_t w = (uint32_t)p[0] | ((uint32_t)p[1] << 16);
 #pragma unroll
             for (int e = 0; e < 4; e++)
@@ -452,8 +463,11 @@ __global__ __launch_bounds__(256) void prep80_kernel(const uint8_t *__restrict__
     }
     half4_t h4 = {(_Float16)q[0], (_Float16)q[1], (_Float16)q[2], (_Float16)q[3]};
     *(half4_t *)(Xh + ((size_t)b * n_pad + tok) * 256 + 4 * t) = h4;
-    if ((t & 7) == 0)
+    if ((t & 7) == 0) {
         d8T[((size_t)b * 8 + (t >> 3)) * n_pad + tok] = d;
+        if constexpr (Q81)
+            sT[((size_t)b * 8 + (t >> 3)) * n_pad + tok] = sv;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -531,17 +545,24 @@ hipError_t lfamd_launch_prep_f32(const void *X, size_t x_row_bytes, long n, long
 }
 
 hipError_t lfamd_launch_prep80(int Btype, const void *B, size_t b_row_bytes, long n, long n_pad, long cols, void *Xh, void *d8T,
-                               hipStream_t s) {
+                               void *sT, hipStream_t s) {
     int nb = (int)(cols / 256);
     long blocks = n_pad * nb;
     if (blocks == 0)
         return hipSuccess;
-    if (Btype == LFAMD_TYPE_F32)
-        prep80_kernel<true><<<(unsigned)((blocks + 3) / 4), 256, 0, s>>>((const uint8_t *)B, b_row_bytes, n, n_pad, nb,
-                                                                        (_Float16 *)Xh, (float *)d8T);
-    else
-        prep80_kernel<false><<<(unsigned)((blocks + 3) / 4), 256, 0, s>>>((const uint8_t *)B, b_row_bytes, n, n_pad, nb,
-                                                                         (_Float16 *)Xh, (float *)d8T);
+    const unsigned grid = (unsigned)((blocks + 3) / 4);
+    const uint8_t *X = (const uint8_t *)B;
+    if (sT) { // Q8_1 activations
+        if (Btype == LFAMD_TYPE_F32)
+            prep80_kernel<true, true><<<grid, 256, 0, s>>>(X, b_row_bytes, n, n_pad, nb, (_Float16 *)Xh, (float *)d8T, (float *)sT);
+        else
+            prep80_kernel<false, true><<<grid, 256, 0, s>>>(X, b_row_bytes, n, n_pad, nb, (_Float16 *)Xh, (float *)d8T, (float *)sT);
+    } else {
+        if (Btype == LFAMD_TYPE_F32)
+            prep80_kernel<true, false><<<grid, 256, 0, s>>>(X, b_row_bytes, n, n_pad, nb, (_Float16 *)Xh, (float *)d8T, nullptr);
+        else
+            prep80_kernel<false, false><<<grid, 256, 0, s>>>(X, b_row_bytes, n, n_pad, nb, (_Float16 *)Xh, (float *)d8T, nullptr);
+    }
     return hipGetLastError();
 }
 

@@ -290,3 +290,26 @@ def test_tuned_types_random_shapes(gpu, oracle, t):
             else:
                 tol = GEMM_TOL.get(t, DEFAULT_TOL) if n > 8 else DEFAULT_TOL
                 assert rel_err(C, G) <= tol, (T.NAMES[t], m, n, k, body, rel_err(C, G))
+
+
+@pytest.mark.parametrize("t", [T.Q4_0, T.Q4_1, T.Q5_0, T.Q5_1], ids=lambda t: T.NAMES[t])
+@pytest.mark.parametrize("shape", [(128, 64, 512), (96, 100, 1024), (33, 9, 256), (200, 300, 1280), (64, 130, 768)], ids=str)
+@pytest.mark.parametrize("f32in", [False, True], ids=["q8", "f32"])
+def test_legacy_types_gemm_vs_oracle(gpu, oracle, t, shape, f32in):
+    """Legacy 32-block types, batches: exact integer codes on the MFMA body, f32 block scales per 32 weights (Q4_0 from
+    its resident P40 layout, the others from a per-call image); Q4_1 / Q5_1 add m * s with Q8_1 activations."""
+    from llamafile_amd import synth
+    m, n, k = shape
+    A = synth.random_weights(t, m, k, 600 + t)
+    x = synth.random_activations(n, k, 601)
+    vdt = T.VEC_DOT[t]
+    B = synth.quantize_activations(vdt, x)
+    ok, G = oracle.sgemm(t, A, vdt, B, m, n, k, nth=2)
+    assert ok == 1
+    W = gpu.upload_weights(t, A, m, k)
+    if f32in:
+        C = gpu.mul_mat(W, torch.from_numpy(x).cuda().view(torch.uint8).view(n, k * 4), T.F32)
+    else:
+        C = gpu.mul_mat(W, torch.from_numpy(B).cuda(), vdt)
+    torch.cuda.synchronize()
+    assert rel_err(C.cpu().numpy(), G) <= TOL.get(t, DEFAULT_TOL)
