@@ -15,6 +15,8 @@ hipError_t lfamd_launch_pack_q40(const void *, size_t, long, long, void *, hipSt
 hipError_t lfamd_launch_prep80(int, const void *, size_t, long, long, long, void *, void *, void *, hipStream_t);
 hipError_t lfamd_launch_wprep32(int, const void *, long, long, void *, hipStream_t);
 size_t lfamd_wprep32_bytes(long, long);
+hipError_t lfamd_launch_wprep8(int, const void *, long, long, void *, hipStream_t);
+size_t lfamd_wprep8_bytes(long, long);
 hipError_t lfamd_launch_pack_q5k(const void *, size_t, long, long, void *, hipStream_t);
 hipError_t lfamd_launch_pack_q6k(const void *, size_t, long, long, void *, hipStream_t);
 hipError_t lfamd_launch_pack_q80(const void *, size_t, long, long, void *, hipStream_t);
@@ -231,7 +233,8 @@ static bool use_gemm(int Atype, long n, unsigned flags, long k) {
 
 // K-quants kept in RAW layout whose batches go through a per-call canonical image + the MFMA body (Q2_K, Q3_K)
 static bool use_gemm_canon(int Atype, long n, unsigned flags) {
-    return !(flags & LFAMD_FLAG_FORCE_GENERIC) && n > 8 && (Atype == LFAMD_TYPE_Q2_K || Atype == LFAMD_TYPE_Q3_K);
+    return !(flags & LFAMD_FLAG_FORCE_GENERIC) && n > 8 &&
+           (Atype == LFAMD_TYPE_Q2_K || Atype == LFAMD_TYPE_Q3_K || Atype == LFAMD_TYPE_IQ4_XS);
 }
 
 static size_t gemm_act_ws(long k, long n) { // Xh + d8T + Xm of the K-quant GEMM
@@ -273,7 +276,7 @@ size_t lfamd_mul_mat_workspace(int Atype, long m, long k, long n) {
     if (use_gemm_q80(Atype, n, 0))
         return align_up(lfamd_gemm_q80_workspace(k, n), 256);
     if (use_gemm_canon(Atype, n, 0))
-        return gemm_act_ws(k, n) + align_up(lfamd_wprep16_bytes(m, k), 256);
+        return gemm_act_ws(k, n) + align_up(Atype == LFAMD_TYPE_IQ4_XS ? lfamd_wprep8_bytes(m, k) : lfamd_wprep16_bytes(m, k), 256);
     if (use_gemm_canon32(Atype, n, 0, k)) { // Xh, d8T [nb*8][n_pad], sT [nb*8][n_pad], image
         size_t n_pad = align_up((size_t)n, 128), nb = (size_t)(k / 256);
         return align_up(n_pad * (size_t)k * 2, 256) + 2 * align_up(nb * 8 * n_pad * 4, 256) + align_up(lfamd_wprep32_bytes(m, k), 256);
@@ -364,7 +367,10 @@ int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const v
         void *d8T = ws + align_up(n_pad * (size_t)k * 2, 256);
         void *Xm = (uint8_t *)d8T + align_up(nb * n_pad * 4, 256);
         void *img = ws + gemm_act_ws(k, n);
-        HIPCHK(lfamd_launch_wprep16(Atype, d_A, m, k, img, s), "wprep16");
+        if (Atype == LFAMD_TYPE_IQ4_XS)
+            HIPCHK(lfamd_launch_wprep8(Atype, d_A, m, k, img, s), "wprep8");
+        else
+            HIPCHK(lfamd_launch_wprep16(Atype, d_A, m, k, img, s), "wprep16");
         const int mins16 = Atype == LFAMD_TYPE_Q2_K;
         if (Btype == LFAMD_TYPE_F32)
             HIPCHK(lfamd_launch_prep_f32(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, mins16, s), "prep_f32");

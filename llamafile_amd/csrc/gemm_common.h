@@ -102,6 +102,18 @@ __device__ static inline half8_t dequant_legacy(uint32_t x, uint32_t Hd, float o
     return f.v;
 }
 
+// IQ4_XS byte image: two dwords = the K-step's eight values + 128; v_perm builds the f16 pairs 1024 + u directly
+// (bytes [u0, 0x64, u1, 0x64]), then sc * value = (1024 + u) * sc - 1152 * sc (1152 * sc = 9 * sc * 2^7 is exact in f16;
+// |sc * value| reaches 4064, so products above 2048 round like Q6_K's).
+__device__ static inline half8_t dequant_bytes(uint32_t d0, uint32_t d1, half2_t S, half2_t O) {
+    frag_u f;
+    f.p[0] = pk_fma(as_half2(__builtin_amdgcn_perm(0x64646464u, d0, 0x04010400u)), S, O);
+    f.p[1] = pk_fma(as_half2(__builtin_amdgcn_perm(0x64646464u, d0, 0x04030402u)), S, O);
+    f.p[2] = pk_fma(as_half2(__builtin_amdgcn_perm(0x64646464u, d1, 0x04010400u)), S, O);
+    f.p[3] = pk_fma(as_half2(__builtin_amdgcn_perm(0x64646464u, d1, 0x04030402u)), S, O);
+    return f.v;
+}
+
 __device__ static inline uint32_t opaque_magic() {
     uint32_t magic = 0x64006400u;
     asm volatile("" : "+v"(magic)); // keep it a register value (see dequant_q4)

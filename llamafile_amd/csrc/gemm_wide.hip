@@ -32,6 +32,7 @@ struct wide_w {
     u32x4 hd;    // Q4_K: {d, dmin, scales[12]};  Q6_K: 16 int8 scales
     u32x4 qh[2]; // Q6_K only
     uint32_t dw; // Q6_K only (f16 bits)
+    u32x4 q8[4]; // IQ4_XS byte image: K-steps 8..15 (qs[] holds 0..7)
 };
 
 template <int IMM>
@@ -131,9 +132,10 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const gemm_mats mats, in
     // PCK image built per call (generic.hip, wprep16): 16-wide sub-blocks, int8 scale each; Q2_K also 16 mins
     constexpr bool CANON16 = TYPE == LFAMD_TYPE_Q2_K || TYPE == LFAMD_TYPE_Q3_K;
     constexpr bool MINS16 = TYPE == LFAMD_TYPE_Q2_K;
+    constexpr bool BYTES8 = TYPE == LFAMD_TYPE_IQ4_XS; // PC8 byte image built per call (generic.hip, wprep8)
     __shared__ __attribute__((aligned(16))) float d8s[2][(LEGACY ? 8 : 1) * WD_COLS]; // d8 of the 128 tokens
     __shared__ __attribute__((aligned(16))) uint8_t xms[2][WD_COLS * 32]; // Q4_K mins operand rows; L1: the 8 x 128 f32 s values
-    constexpr int TILE = (TYPE == LFAMD_TYPE_Q4_K || TYPE == LFAMD_TYPE_Q4_0) ? P4K_TILE : LEGACY ? PCL_TILE : TYPE == LFAMD_TYPE_Q5_K ? P5K_TILE : CANON16 ? PCK_TILE : P6K_TILE;
+    constexpr int TILE = (TYPE == LFAMD_TYPE_Q4_K || TYPE == LFAMD_TYPE_Q4_0) ? P4K_TILE : LEGACY ? PCL_TILE : TYPE == LFAMD_TYPE_Q5_K ? P5K_TILE : CANON16 ? PCK_TILE : BYTES8 ? PC8_TILE : P6K_TILE;
     constexpr bool MINS = TYPE == LFAMD_TYPE_Q4_K || TYPE == LFAMD_TYPE_Q5_K; // Q4_K family: {d, dmin, 6-bit scales/mins}
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 31, h = lane >> 5;
@@ -214,7 +216,13 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const gemm_mats mats, in
         gload16<1024>(w.qs[1], tile, wo);
         gload16<2048>(w.qs[2], tile, wo);
         gload16<3072>(w.qs[3], tile, wo);
-        if constexpr (CANON16) {
+        if constexpr (BYTES8) {
+            gload16<0>(w.q8[0], tile_h, wo);
+            gload16<1024>(w.q8[1], tile_h, wo);
+            gload16<2048>(w.q8[2], tile_h, wo);
+            gload16<3072>(w.q8[3], tile_h, wo);
+            gload16<0>(w.hd, uniform_ptr(tile + PC8_HDR), (uint32_t)(i * 16));
+        } else if constexpr (CANON16) {
             gload16<0>(w.hd, tile_h, ho);            // 16 int8 scales
             if constexpr (MINS16)
                 gload16<512>(w.qh[0], tile_h, ho);   // 16 uint8 mins (PCK_MN)
@@ -247,7 +255,13 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const gemm_mats mats, in
             gload16<1024>(w.qs[1], tile, wo);
             gload16<2048>(w.qs[2], tile, wo);
             gload16<3072>(w.qs[3], tile, wo);
-            if constexpr (CANON16) {
+            if constexpr (BYTES8) {
+                gload16<0>(w.q8[0], tile_h, wo);
+                gload16<1024>(w.q8[1], tile_h, wo);
+                gload16<2048>(w.q8[2], tile_h, wo);
+                gload16<3072>(w.q8[3], tile_h, wo);
+                gload16<0>(w.hd, uniform_ptr(tile + PC8_HDR), (uint32_t)(i * 16));
+            } else if constexpr (CANON16) {
                 gload16<0>(w.hd, tile_h, ho);            // 16 int8 scales
                 if constexpr (MINS16)
                     gload16<512>(w.qh[0], tile_h, ho);   // 16 uint8 mins (PCK_MN)
@@ -297,6 +311,12 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const gemm_mats mats, in
         else if constexpr (TYPE == LFAMD_TYPE_Q4_K || LEGACY)
             asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier"
                          : "+v"(w.qs[0]), "+v"(w.qs[1]), "+v"(w.qs[2]), "+v"(w.qs[3]), "+v"(w.hd)
+                         :
+                         : "memory");
+        else if constexpr (BYTES8)
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier"
+                         : "+v"(w.qs[0]), "+v"(w.qs[1]), "+v"(w.qs[2]), "+v"(w.qs[3]), "+v"(w.hd), "+v"(w.q8[0]), "+v"(w.q8[1]),
+                           "+v"(w.q8[2]), "+v"(w.q8[3])
                          :
                          : "memory");
         else if constexpr (CANON16)
@@ -412,6 +432,46 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const gemm_mats mats, in
                     }
                 }
             }
+        } else if constexpr (BYTES8) {
+            // IQ4_XS: w = d * sc_j * kvalues[code], eight 32-wide sub-blocks; the byte image holds kvalues[code] + 128
+            const uint32_t bw[32] = {w.qs[0].x, w.qs[0].y, w.qs[0].z, w.qs[0].w, w.qs[1].x, w.qs[1].y, w.qs[1].z, w.qs[1].w,
+                                     w.qs[2].x, w.qs[2].y, w.qs[2].z, w.qs[2].w, w.qs[3].x, w.qs[3].y, w.qs[3].z, w.qs[3].w,
+                                     w.q8[0].x, w.q8[0].y, w.q8[0].z, w.q8[0].w, w.q8[1].x, w.q8[1].y, w.q8[1].z, w.q8[1].w,
+                                     w.q8[2].x, w.q8[2].y, w.q8[2].z, w.q8[2].w, w.q8[3].x, w.q8[3].y, w.q8[3].z, w.q8[3].w};
+            const float d = h2f((uint16_t)(w.hd.z & 0xffff));
+            half8_t F[2][2];
+            read_frags(F[0], 0);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const float scf = (float)(int)(int8_t)(((j < 4 ? w.hd.x : w.hd.y) >> (8 * (j & 3))) & 0xff);
+                const half2_t S = bcast_h2(scf), O = bcast_h2(-1152.0f * scf);
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    const int t = 2 * j + e;
+                    const half8_t wf = dequant_bytes(bw[2 * t], bw[2 * t + 1], S, O);
+                    if (t + 1 < 16) {
+                        read_frags(F[(t + 1) & 1], t + 1);
+                        ds_wait<2>(F[t & 1][0], F[t & 1][1]);
+                    } else {
+                        ds_wait<0>(F[t & 1][0], F[t & 1][1]);
+                    }
+#pragma unroll
+                    for (int nt = 0; nt < 2; nt++)
+                        tmp[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F[t & 1][nt], wf, t == 0 ? zero16 : tmp[nt], 0, 0, 0);
+                    prefetch_step(t, bn, st ^ 1, wn);
+                }
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; r4++) {
+                    const float4_t_ d8 = *(const float4_t_ *)(&d8s[st][ch * 64 + nt * 32 + 8 * r4 + 4 * h]);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const int r = 4 * r4 + e;
+                        acc[nt][r] = fmaf(d * tmp[nt][r], d8[e], acc[nt][r]);
+                    }
+                }
         } else if constexpr (CANON16) {
             // w = d * sc_t * q - dmin * mn_t per 16-wide sub-block t (one K-step); operand sc_t * (code - OFF), exact in f16
             constexpr float OFF = TYPE == LFAMD_TYPE_Q3_K ? 4.0f : 0.0f;
@@ -700,6 +760,9 @@ extern "C" hipError_t lfamd_launch_gemm_wide_multi(int Atype, int count, const v
     else if (Atype == LFAMD_TYPE_Q3_K)
         gemm_wide_kernel<LFAMD_TYPE_Q3_K><<<n_wg, 512, 0, s>>>(mats, nb, (const _Float16 *)Xh, (const float *)d8T,
                                                                 (const _Float16 *)Xm, n, n_pad, n_rb, n_ct, ks, nbs);
+    else if (Atype == LFAMD_TYPE_IQ4_XS)
+        gemm_wide_kernel<LFAMD_TYPE_IQ4_XS><<<n_wg, 512, 0, s>>>(mats, nb, (const _Float16 *)Xh, (const float *)d8T,
+                                                                  (const _Float16 *)Xm, n, n_pad, n_rb, n_ct, ks, nbs);
     else if (Atype == LFAMD_TYPE_Q4_1)
         gemm_wide_kernel<LFAMD_TYPE_Q4_1><<<n_wg, 512, 0, s>>>(mats, nb, (const _Float16 *)Xh, (const float *)d8T,
                                                                 (const _Float16 *)Xm, n, n_pad, n_rb, n_ct, ks, nbs);

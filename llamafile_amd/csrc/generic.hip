@@ -440,6 +440,66 @@ extern "C" hipError_t lfamd_launch_wprep32(int type, const void *raw, long rows,
     return hipGetLastError();
 }
 
+// IQ4_XS -> PC8 tiles (kvalues_iq4nl applied here, so the GEMM sees plain integers)
+__global__ void wprep8_iq4xs_kernel(const uint8_t *__restrict__ raw, size_t raw_row_bytes, long rows, int nb, uint8_t *__restrict__ out,
+                                    long n_tiles) {
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long tile = tid / 2176; // 2048 code dwords + 128 header dwords
+    const int w = (int)(tid % 2176);
+    if (tile >= n_tiles)
+        return;
+    const long rt = tile / nb;
+    const int b = (int)(tile % nb);
+    uint32_t *dst = (uint32_t *)(out + tile * PC8_TILE);
+    uint32_t v = 0;
+    if (w < 2048) {
+        const int g2 = w >> 8, lane = (w >> 2) & 63, e = w & 3;
+        const int i = lane & 31, h = lane >> 5;
+        const long row = rt * 32 + i;
+        if (row < rows) {
+            const lfamd_block_iq4_xs *blk = (const lfamd_block_iq4_xs *)(raw + row * raw_row_bytes) + b;
+            const int t = 2 * g2 + (e >> 1);
+            for (int jj = 0; jj < 4; jj++) {
+                const int k = 16 * t + 8 * h + 4 * (e & 1) + jj, ib = k >> 5, l = k & 31;
+                const uint8_t byte = blk->qs[16 * ib + (l & 15)];
+                const int val = kvalues_iq4nl_dev[l < 16 ? (byte & 15) : (byte >> 4)];
+                v |= (uint32_t)((val + 128) & 0xff) << (8 * jj);
+            }
+        }
+    } else {
+        const int s = w - 2048, i = s >> 2, q = s & 3;
+        const long row = rt * 32 + i;
+        if (row < rows && q < 3) {
+            const lfamd_block_iq4_xs *blk = (const lfamd_block_iq4_xs *)(raw + row * raw_row_bytes) + b;
+            if (q < 2) {
+                for (int e = 0; e < 4; e++) {
+                    const int ib = 4 * q + e;
+                    const int ls = ((blk->scales_l[ib / 2] >> (4 * (ib % 2))) & 0xf) | (((blk->scales_h >> (2 * ib)) & 3) << 4);
+                    v |= (uint32_t)((ls - 32) & 0xff) << (8 * e);
+                }
+            } else {
+                v = blk->d;
+            }
+        }
+    }
+    dst[w] = v;
+}
+
+extern "C" size_t lfamd_wprep8_bytes(long rows, long cols) {
+    return (size_t)((rows + 31) / 32) * (size_t)(cols / 256) * PC8_TILE;
+}
+
+extern "C" hipError_t lfamd_launch_wprep8(int type, const void *raw, long rows, long cols, void *out, hipStream_t s) {
+    if (type != LFAMD_TYPE_IQ4_XS)
+        return hipErrorInvalidValue;
+    const int nb = (int)(cols / 256);
+    const long n_tiles = ((rows + 31) / 32) * nb;
+    const long threads = n_tiles * 2176;
+    wprep8_iq4xs_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>((const uint8_t *)raw, lfamd_row_size(type, cols), rows, nb,
+                                                                        (uint8_t *)out, n_tiles);
+    return hipGetLastError();
+}
+
 extern "C" size_t lfamd_wprep16_bytes(long rows, long cols) {
     return (size_t)((rows + 31) / 32) * (size_t)(cols / 256) * PCK_TILE;
 }

@@ -42,6 +42,10 @@
 #define PCL_D 4096
 #define PCL_M 4608
 #define PCL_QH 5120
+// PC8: per-call byte image for IQ4_XS (non-linear 4-bit codebook): value + 128 as one byte per weight, K-steps 2g', 2g'+1
+// of lane (i, h) in the 16 bytes at g' * 1024 + lane * 16; then per row {8 int8 sub-block scales, f16 d, pad}
+#define PC8_TILE 8704
+#define PC8_HDR 8192
 #define P6K_TILE 6720
 #define P6K_QH 4096
 #define P6K_SC 6144

@@ -96,7 +96,7 @@ def test_mfma_bodies_agree_and_repeat(gpu, t):
     assert rel_err(w1, nr) <= 2e-6
 
 
-@pytest.mark.parametrize("t", [T.Q2_K, T.Q3_K], ids=lambda t: T.NAMES[t])
+@pytest.mark.parametrize("t", [T.Q2_K, T.Q3_K, T.IQ4_XS], ids=lambda t: T.NAMES[t])
 @pytest.mark.parametrize("shape", [(128, 64, 512), (96, 100, 1024), (33, 9, 256), (200, 300, 1280), (64, 130, 768)], ids=str)
 @pytest.mark.parametrize("f32in", [False, True], ids=["q8k", "f32"])
 def test_canonical_image_gemm_vs_oracle(gpu, oracle, t, shape, f32in):
@@ -115,7 +115,8 @@ def test_canonical_image_gemm_vs_oracle(gpu, oracle, t, shape, f32in):
     else:
         C = gpu.mul_mat(W, torch.from_numpy(B).cuda(), T.Q8_K)
     torch.cuda.synchronize()
-    assert rel_err(C.cpu().numpy(), G) <= DEFAULT_TOL
+    # IQ4_XS: |sc * kvalue| reaches 4064, products above 2048 round to even in f16 (like Q6_K): north-star tolerance
+    assert rel_err(C.cpu().numpy(), G) <= (1e-3 if t == T.IQ4_XS else DEFAULT_TOL)
 
 
 @pytest.mark.parametrize("t", [T.Q4_0, T.Q5_K, T.IQ4_XS, T.Q2_K], ids=lambda t: T.NAMES[t])
@@ -125,7 +126,7 @@ def test_generic_large_n(gpu, oracle, t):
     ok, G = oracle.sgemm(t, A, bt, B, m, n, k)
     assert ok == 1
     C = run_gpu(gpu, t, A, B, bt, m, n, k)
-    assert rel_err(C, G) <= DEFAULT_TOL
+    assert rel_err(C, G) <= (1e-3 if t == T.IQ4_XS else DEFAULT_TOL)
 
 
 @pytest.mark.parametrize("vdt", [T.Q8_0, T.Q8_1, T.Q8_K], ids=lambda t: T.NAMES[t])
