@@ -422,9 +422,11 @@ int lfamd_mul_mat_multi(int Atype, int count, const void *const *d_A, const long
         return LFAMD_OK;
     // one fused launch when the GEMV path applies to every matrix; otherwise one mul_mat per matrix
     bool fuse = count <= 4 && n <= 8 &&
-                (Atype == LFAMD_TYPE_Q4_K || Atype == LFAMD_TYPE_Q5_K || Atype == LFAMD_TYPE_Q6_K || packed40(Atype, k)) &&
+                (Atype == LFAMD_TYPE_Q4_K || Atype == LFAMD_TYPE_Q5_K || Atype == LFAMD_TYPE_Q6_K || Atype == LFAMD_TYPE_Q8_0 ||
+                 packed40(Atype, k)) &&
                 !(flags & LFAMD_FLAG_FORCE_GENERIC) && (Btype == LFAMD_TYPE_F32 || Btype == lfamd_vec_dot_type(Atype)) &&
-                k > 0 && k % 256 == 0 && b_row_bytes >= lfamd_row_size(Btype, k);
+                k > 0 && k % lfamd_blck_size(Atype) == 0 && (Atype == LFAMD_TYPE_Q8_0 || k % 256 == 0) &&
+                b_row_bytes >= lfamd_row_size(Btype, k);
     for (int j = 0; j < count && fuse; j++)
         fuse = m[j] >= 0 && ldc[j] >= m[j];
     if (fuse) {

@@ -636,11 +636,22 @@ __global__ __launch_bounds__(NW * 64) void gemv_kq_kernel(const gemv_mats mats, 
 
 // MODE: 0 = every output plain fma, 1 = every output Kahan (uniform for n = 1: tinyblas_cpu.h:797-925),
 // 2 = per-output choice from the mnpack geometry (small batches n > 1)
+// sibling matrices that share the activations (attn_q/k/v, ffn_gate/up) run as ONE launch over their concatenated
+// 8-row groups: a 1024-row matrix alone is 128 waves, each a serial k-long chain — three such launches cost three times
+// the chain latency, one launch costs it once.  The mnpack geometry (Kahan choice) stays per matrix.
+struct q80_mats {
+    const uint8_t *A[GEMV_MAX_MATS];
+    float *C[GEMV_MAX_MATS];
+    long m[GEMV_MAX_MATS];
+    long ldc[GEMV_MAX_MATS];
+    long rg_end[GEMV_MAX_MATS]; // exclusive prefix of row-group counts
+    int count;
+};
+
 template <int NC, int BT, int MODE, int Q80_DEPTH>
-__global__ __launch_bounds__(Q80_WAVES * 64) void gemv_q80_kernel(const uint8_t *__restrict__ A, long m, long n_total,
-                                                                 int nblocks, int nquads, const uint8_t *__restrict__ B,
-                                                                 size_t b_row_bytes, long col0, float *__restrict__ C,
-                                                                 long ldc, int vregs32, int precise) {
+__global__ __launch_bounds__(Q80_WAVES * 64) void gemv_q80_kernel(const q80_mats mats, long n_total, int nblocks, int nquads,
+                                                                 const uint8_t *__restrict__ B, size_t b_row_bytes, long col0,
+                                                                 int vregs32, int precise) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane >> 3, j = lane & 7;
@@ -648,7 +659,17 @@ __global__ __launch_bounds__(Q80_WAVES * 64) void gemv_q80_kernel(const uint8_t 
     int stamp_n = 0;
 #endif
     GSTAMP();
-    const long rg = (long)blockIdx.x * Q80_WAVES + wave;
+    long rg = (long)blockIdx.x * Q80_WAVES + wave;
+    int mj = 0;
+#pragma unroll
+    for (int jj = 1; jj < GEMV_MAX_MATS; jj++)
+        if (jj < mats.count && rg >= mats.rg_end[jj - 1])
+            mj = jj;
+    if (mj > 0)
+        rg -= mats.rg_end[mj - 1];
+    const uint8_t *__restrict__ A = mats.A[mj];
+    float *__restrict__ C = mats.C[mj];
+    const long m = mats.m[mj], ldc = mats.ldc[mj];
     const long n_rg = (m + 7) / 8;
     const long row = rg * 8 + r;
     // bounds-checked, unconditional weight loads (zeros past the row group / for an idle wave): keeps
@@ -954,23 +975,24 @@ static hipError_t launch_q6k(const gemv_mats &mats, int n_ht, long k, const void
 }
 
 template <int NC, int BT>
-static hipError_t launch_q80(const void *A, long m, long n_total, long k, const void *B, size_t brb, long col0, float *C,
-                             long ldc, int vregs32, int precise, hipStream_t s) {
+static hipError_t launch_q80(const q80_mats &mats, long n_total, long k, const void *B, size_t brb, long col0, int vregs32,
+                             int precise, hipStream_t s) {
     int nblocks = (int)(k / 32), nquads = (nblocks + 3) / 4;
     size_t smem = (size_t)NC * nquads * X80_QUAD;
-    unsigned grid = (unsigned)(((m + 7) / 8 + Q80_WAVES - 1) / Q80_WAVES);
+    const long rgs = mats.rg_end[GEMV_MAX_MATS - 1];
+    unsigned grid = (unsigned)((rgs + Q80_WAVES - 1) / Q80_WAVES);
     // n = 1: the whole problem is one column of 2x1 / 1x1 tiles, so the summation mode is uniform
     const int mode = n_total == 1 ? ((vregs32 || precise) ? 1 : 0) : 2;
 #define Q80_GO(MODE)                                                                                                   \
     do {                                                                                                               \
-        auto kernel = gemv_q80_kernel<NC, BT, MODE, 16>;                                                          \
+        auto kernel = gemv_q80_kernel<NC, BT, MODE, 16>;                                                               \
         if (smem > 64 * 1024) {                                                                                        \
             hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
             if (e != hipSuccess)                                                                                       \
                 return e;                                                                                              \
         }                                                                                                              \
-        kernel<<<grid, Q80_WAVES * 64, smem, s>>>((const uint8_t *)A, m, n_total, nblocks, nquads, (const uint8_t *)B, brb, \
-                                                  col0, C, ldc, vregs32, precise);                                     \
+        kernel<<<grid, Q80_WAVES * 64, smem, s>>>(mats, n_total, nblocks, nquads, (const uint8_t *)B, brb, col0, vregs32, \
+                                                  precise);                                                            \
     } while (0)
     if (mode == 0)
         Q80_GO(0);
@@ -1035,17 +1057,29 @@ extern "C" hipError_t lfamd_launch_gemv_multi(int Atype, int count, const void *
     const bool f32in = Btype == LFAMD_TYPE_F32;
     hipError_t e = hipSuccess;
     if (Atype == LFAMD_TYPE_Q8_0) {
-        for (int j = 0; j < count && e == hipSuccess; j++) {
-            if (m[j] <= 0)
+        for (int j0 = 0; j0 < count && e == hipSuccess; j0 += GEMV_MAX_MATS) { // groups of up to four matrices per launch
+            q80_mats qm;
+            long rgs = 0;
+            qm.count = 0;
+            for (int j = j0; j < count && j < j0 + GEMV_MAX_MATS; j++) {
+                if (m[j] <= 0)
+                    continue;
+                const int i = qm.count++;
+                qm.A[i] = (const uint8_t *)A[j], qm.C[i] = C[j], qm.m[i] = m[j], qm.ldc[i] = ldc[j];
+                rgs += (m[j] + 7) / 8;
+                rgs = (rgs + Q80_WAVES - 1) / Q80_WAVES * Q80_WAVES; // a work-group never straddles two matrices
+                qm.rg_end[i] = rgs;
+            }
+            if (qm.count == 0)
                 continue;
+            for (int i = qm.count; i < GEMV_MAX_MATS; i++)
+                qm.A[i] = qm.A[0], qm.C[i] = qm.C[0], qm.m[i] = 0, qm.ldc[i] = 0, qm.rg_end[i] = rgs;
             for (long col0 = 0; col0 < n && e == hipSuccess; col0 += step) {
                 int nc = (int)((n - col0) < step ? (n - col0) : step);
                 if (f32in) {
-                    DISPATCH_NC(launch_q80, LFAMD_TYPE_F32, nc, A[j], m[j], n, k, B, b_row_bytes, col0, C[j], ldc[j], vregs32,
-                                precise, s)
+                    DISPATCH_NC(launch_q80, LFAMD_TYPE_F32, nc, qm, n, k, B, b_row_bytes, col0, vregs32, precise, s)
                 } else {
-                    DISPATCH_NC(launch_q80, LFAMD_TYPE_Q8_0, nc, A[j], m[j], n, k, B, b_row_bytes, col0, C[j], ldc[j],
-                                vregs32, precise, s)
+                    DISPATCH_NC(launch_q80, LFAMD_TYPE_Q8_0, nc, qm, n, k, B, b_row_bytes, col0, vregs32, precise, s)
                 }
             }
         }

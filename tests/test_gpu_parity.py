@@ -163,7 +163,7 @@ def test_f32_activations_equal_prequantised(gpu, t, n):
     assert np.array_equal(c_f32.view(np.uint32), c_q.view(np.uint32))
 
 
-@pytest.mark.parametrize("t", [T.Q4_K, T.Q5_K, T.Q6_K], ids=lambda t: T.NAMES[t])
+@pytest.mark.parametrize("t", [T.Q4_K, T.Q5_K, T.Q6_K, T.Q8_0, T.Q4_0], ids=lambda t: T.NAMES[t])
 @pytest.mark.parametrize("n", [1, 4, 20])
 def test_mul_mat_multi_equals_separate(gpu, t, n):
     """Sibling mat-muls fused into one launch (attn_q/k/v, ffn_gate/up) give bit-identical results to
