@@ -256,27 +256,52 @@ def main():
 
     # hipGraph capture of a whole pass (kernels + RCCL collectives).  If capturing the collectives is not
     # possible on this stack, fall back to eager launches rather than fail.
-    use_graph = not a.no_graph
+    # (gloo rehearsals cannot capture their host-side collectives, and a failed capture leaves gloo unusable: eager)
+    use_graph = not a.no_graph and not (dist_on and os.environ.get("LFAMD_DIST_BACKEND", "nccl") != "nccl")
     graphs = {}
+    dead = []  # failed capture objects are kept alive: destroying a half-captured graph can crash the runtime
     if use_graph:
+        cap_stream = torch.cuda.Stream(device=dev)
+
+        def capture(n):
+            # manual begin/end on a side stream (not torch.cuda.graph: its __exit__ raises from capture_end() BEFORE it
+            # restores the current stream, which leaves every later launch on an invalidated capture stream)
+            g = torch.cuda.CUDAGraph()
+            cap_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(cap_stream):
+                g.capture_begin(capture_error_mode="thread_local")
+                try:
+                    runner.run_pass(n)
+                except BaseException:
+                    dead.append(g)
+                    try:
+                        g.capture_end()
+                    except Exception:  # noqa: BLE001
+                        pass
+                    raise
+                g.capture_end()
+            torch.cuda.current_stream().wait_stream(cap_stream)
+            return g
+
         try:
             for n in (a.prefill, 1):
                 runner.run_pass(n)  # warm (also sets any kernel attributes before capture)
                 barrier()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    runner.run_pass(n)
-                graphs[n] = g
+                graphs[n] = capture(n)
             barrier()
             for n in (a.prefill, 1):
                 graphs[n].replay()
             barrier()
         except Exception as e:  # noqa: BLE001
             if rank == 0:
-                print(f"bench.py: graph capture unavailable ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+                print(f"bench.py: graph capture unavailable ({type(e).__name__}: {str(e)[:200]}); running eagerly", file=sys.stderr)
+            dead.extend(graphs.values())
             graphs = {}
             use_graph = False
-            torch.cuda.synchronize()
+            try:
+                torch.cuda.synchronize()
+            except Exception:  # noqa: BLE001
+                pass
 
     def one_pass(n):
         if use_graph:

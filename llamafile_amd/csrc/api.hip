@@ -174,6 +174,7 @@ size_t lfamd_packed_size(int type, long rows, long cols) {
 
 int lfamd_pack_weights(int type, long rows, long cols, const void *d_raw, size_t raw_row_bytes, void *d_packed,
                        void *stream) {
+    (void)hipGetLastError(); // a stale error of an earlier call (e.g. an invalidated stream capture) must not fail this one
     if (!type_known(type))
         return fail(LFAMD_ERR_UNSUPPORTED, "pack_weights: unsupported ggml type%s", "");
     if (rows < 0 || cols < 0 || cols % lfamd_blck_size(type) || raw_row_bytes < lfamd_row_size(type, cols))
@@ -209,6 +210,7 @@ int lfamd_pack_weights(int type, long rows, long cols, const void *d_raw, size_t
 
 int lfamd_quantize_rows(int vec_dot_type, const float *d_x, long nrows, long cols, size_t x_row_bytes, void *d_y,
                         size_t y_row_bytes, void *stream) {
+    (void)hipGetLastError(); // a stale error of an earlier call (e.g. an invalidated stream capture) must not fail this one
     if (vec_dot_type != LFAMD_TYPE_Q8_0 && vec_dot_type != LFAMD_TYPE_Q8_1 && vec_dot_type != LFAMD_TYPE_Q8_K)
         return fail(LFAMD_ERR_UNSUPPORTED, "quantize_rows: unsupported activation type%s", "");
     if (cols % lfamd_blck_size(vec_dot_type) || y_row_bytes < lfamd_row_size(vec_dot_type, cols))
@@ -289,6 +291,7 @@ size_t lfamd_mul_mat_workspace(int Atype, long m, long k, long n) {
 
 int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const void *d_B, size_t b_row_bytes, long n,
                   float *d_C, long ldc, void *d_ws, size_t ws_bytes, unsigned flags, void *stream) {
+    (void)hipGetLastError(); // a stale error of an earlier call (e.g. an invalidated stream capture) must not fail this one
     if (!type_known(Atype))
         return fail(LFAMD_ERR_UNSUPPORTED, "mul_mat: unsupported weight type%s", "");
     if (m < 0 || n < 0 || k < 0 || ldc < m || k % lfamd_blck_size(Atype))
@@ -418,6 +421,7 @@ int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const v
 int lfamd_mul_mat_multi(int Atype, int count, const void *const *d_A, const long *m, long k, int Btype, const void *d_B,
                         size_t b_row_bytes, long n, float *const *d_C, const long *ldc, void *d_ws, size_t ws_bytes,
                         unsigned flags, void *stream) {
+    (void)hipGetLastError(); // a stale error of an earlier call (e.g. an invalidated stream capture) must not fail this one
     if (count <= 0)
         return LFAMD_OK;
     // one fused launch when the GEMV path applies to every matrix; otherwise one mul_mat per matrix
@@ -485,6 +489,7 @@ size_t lfamd_mul_mat_id_workspace(int type, long rows, long cols, int experts, l
 int lfamd_mul_mat_id(int type, const void *d_W, long rows, long cols, int experts, int Btype, const void *d_thought,
                      size_t b_row_bytes, int tasks, long tokens, const int32_t *d_plan, int thinkers, float *d_result,
                      void *d_ws, size_t ws_bytes, unsigned flags, void *stream) {
+    (void)hipGetLastError(); // a stale error of an earlier call (e.g. an invalidated stream capture) must not fail this one
     if (!type_known(type))
         return fail(LFAMD_ERR_UNSUPPORTED, "mul_mat_id: unsupported weight type%s", "");
     if (rows < 0 || cols < 0 || cols % lfamd_blck_size(type) || experts <= 0 || tasks <= 0 || thinkers <= 0 ||
