@@ -110,11 +110,13 @@ int lfamd_mul_mat_multi(int Atype, int count, const void *const *d_A_packed, con
  *   d_thought : activation rows in vec_dot format, index (token*tasks + task), stride b_row_bytes
  *   d_plan    : int32 [tokens][thinkers]
  *   d_result  : f32 [tokens][thinkers][rows]
- * Decode (tokens <= 4, Q4_K / Q6_K experts): the GEMV kernels read the expert index from d_plan themselves — no
- * host read-back (the reference syncs, ggml-cuda.cu.patch:18528-18531), asynchronous, graph-capturable — and
- * Btype may also be F32 (quantised in-kernel); thinkers sharing their activations (tasks == 1) are one launch.
- * Rows whose expert id is out of range are left untouched.  Larger batches gather rows per expert on the host's
- * instruction (routing table read back) and run one mat-mul per expert. */
+ * Decode (tokens <= 4, Q4_K / Q6_K experts): the GEMV kernels read the expert index from d_plan themselves; thinkers
+ * sharing their activations (tasks == 1) are one launch.  Batches of Q4_K / Q5_K / Q6_K experts (up to 60 Ki rows): a
+ * one-work-group routing kernel groups the rows by expert on the device and ONE launch of the 128x128 MFMA body covers
+ * (expert, row block, token tile).  Both are asynchronous and graph-capturable — no host read-back (the reference
+ * synchronises, ggml-cuda.cu.patch:18528-18531) — and accept Btype F32 (quantised on the device).  Rows whose expert id
+ * is out of range are left untouched.  Other expert types gather rows per expert after a routing read-back and run one
+ * mat-mul per expert. */
 size_t lfamd_mul_mat_id_workspace(int type, long rows, long cols, int experts, long tokens, int thinkers);
 int lfamd_mul_mat_id(int type, const void *d_W_packed, long rows, long cols, int experts, int Btype,
                      const void *d_thought, size_t b_row_bytes, int tasks, long tokens,

@@ -21,8 +21,8 @@ hipError_t lfamd_launch_pack_q5k(const void *, size_t, long, long, void *, hipSt
 hipError_t lfamd_launch_pack_q6k(const void *, size_t, long, long, void *, hipStream_t);
 hipError_t lfamd_launch_pack_q80(const void *, size_t, long, long, void *, hipStream_t);
 hipError_t lfamd_launch_pack_raw(const void *, size_t, long, size_t, void *, hipStream_t);
-hipError_t lfamd_launch_prep_q8k(const void *, size_t, long, long, long, void *, void *, void *, int, hipStream_t);
-hipError_t lfamd_launch_prep_f32(const void *, size_t, long, long, long, void *, void *, void *, int, hipStream_t);
+hipError_t lfamd_launch_prep_q8k(const void *, size_t, long, long, long, void *, void *, void *, int, const int32_t *, hipStream_t);
+hipError_t lfamd_launch_prep_f32(const void *, size_t, long, long, long, void *, void *, void *, int, const int32_t *, hipStream_t);
 hipError_t lfamd_launch_wprep16(int, const void *, long, long, void *, hipStream_t);
 size_t lfamd_wprep16_bytes(long, long);
 hipError_t lfamd_launch_generic(int, const void *, long, long, int, const void *, size_t, long, float *, long, hipStream_t);
@@ -327,9 +327,9 @@ int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const v
             return LFAMD_OK;
         }
         if (Btype == LFAMD_TYPE_F32)
-            HIPCHK(lfamd_launch_prep_f32(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, 0, s), "prep_f32");
+            HIPCHK(lfamd_launch_prep_f32(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, 0, nullptr, s), "prep_f32");
         else
-            HIPCHK(lfamd_launch_prep_q8k(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, 0, s), "prep_q8k");
+            HIPCHK(lfamd_launch_prep_q8k(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, 0, nullptr, s), "prep_q8k");
         // two bodies: 128 x 128 tiles, K streamed once (gemm_wide.hip) when that grid fills the 256 CUs; the
         // 128 x 64 split-K body (gemm_mfma.hip) for smaller grids.  LFAMD_GEMM_BODY=narrow|wide forces one.
         static const char *body = getenv("LFAMD_GEMM_BODY");
@@ -376,9 +376,9 @@ int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const v
             HIPCHK(lfamd_launch_wprep16(Atype, d_A, m, k, img, s), "wprep16");
         const int mins16 = Atype == LFAMD_TYPE_Q2_K;
         if (Btype == LFAMD_TYPE_F32)
-            HIPCHK(lfamd_launch_prep_f32(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, mins16, s), "prep_f32");
+            HIPCHK(lfamd_launch_prep_f32(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, mins16, nullptr, s), "prep_f32");
         else
-            HIPCHK(lfamd_launch_prep_q8k(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, mins16, s), "prep_q8k");
+            HIPCHK(lfamd_launch_prep_q8k(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, mins16, nullptr, s), "prep_q8k");
         HIPCHK(lfamd_launch_gemm_wide(Atype, img, m, k, Xh, d8T, Xm, n, (long)n_pad, d_C, ldc, s), "gemm_wide");
         return LFAMD_OK;
     }
@@ -466,9 +466,9 @@ int lfamd_mul_mat_multi(int Atype, int count, const void *const *d_A, const long
             void *d8T = ws + align_up(n_pad * (size_t)k * 2, 256);
             void *Xm = (uint8_t *)d8T + align_up(nb * n_pad * 4, 256);
             if (Btype == LFAMD_TYPE_F32)
-                HIPCHK(lfamd_launch_prep_f32(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, 0, s), "prep_f32");
+                HIPCHK(lfamd_launch_prep_f32(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, 0, nullptr, s), "prep_f32");
             else
-                HIPCHK(lfamd_launch_prep_q8k(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, 0, s), "prep_q8k");
+                HIPCHK(lfamd_launch_prep_q8k(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, 0, nullptr, s), "prep_q8k");
             HIPCHK(lfamd_launch_gemm_wide_multi(Atype, count, d_A, m, k, Xh, d8T, Xm, n, (long)n_pad, d_C, ldc, s),
                    "gemm_wide_multi");
             return LFAMD_OK;
@@ -496,11 +496,13 @@ int lfamd_mul_mat_id(int type, const void *d_W, long rows, long cols, int expert
         tasks > thinkers || thinkers > experts)
         return fail(LFAMD_ERR_INVALID, "mul_mat_id: bad shape%s", "");
     // f32 activations (the GGML_OP_MUL_MAT_ID boundary) are served by the decode path, which quantises in-kernel
-    const bool f32_decode = Btype == LFAMD_TYPE_F32 && tokens <= 4 && (type == LFAMD_TYPE_Q4_K || type == LFAMD_TYPE_Q6_K) &&
-                            !(flags & LFAMD_FLAG_FORCE_GENERIC);
+    const bool f32_decode = Btype == LFAMD_TYPE_F32 && !(flags & LFAMD_FLAG_FORCE_GENERIC) &&
+                            ((tokens <= 4 && (type == LFAMD_TYPE_Q4_K || type == LFAMD_TYPE_Q6_K)) ||
+                             (tokens > 4 && cols % 256 == 0 && experts < 255 && tokens * thinkers <= 60 * 1024 &&
+                              (type == LFAMD_TYPE_Q4_K || type == LFAMD_TYPE_Q5_K || type == LFAMD_TYPE_Q6_K)));
     if (Btype != lfamd_vec_dot_type(type) && !f32_decode)
         return fail(LFAMD_ERR_UNSUPPORTED,
-                    "mul_mat_id: activations must be in the weight type's vec_dot format (or F32 for <= 4 tokens of K-quants)%s", "");
+                    "mul_mat_id: activations must be in the weight type's vec_dot format (F32 only for Q4_K / Q5_K / Q6_K experts)%s", "");
     if (tokens == 0 || rows == 0)
         return LFAMD_OK;
     size_t need = lfamd_moe_workspace(type, rows, cols, experts, tokens, thinkers);

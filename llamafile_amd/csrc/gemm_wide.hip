@@ -116,9 +116,15 @@ struct gemm_mats {
     long ldc[GEMM_MAX_MATS];
     int rb_end[GEMM_MAX_MATS];
     int count;
+    // GGML_OP_MUL_MAT_ID batches (MOE kernels only): A[0] = the expert stack, C[0] = result rows; token slots are grouped
+    // by expert on the device (moe.hip, moe_route_kernel): expert e owns slots [poff[e], poff[e] + cnt[e]), slot -> result
+    // row through slot_row.  The grid covers the worst case; work-groups beyond an expert's count exit at once.
+    const int *moe_cnt, *moe_poff, *moe_slot_row;
+    long expert_bytes;
+    int moe_ct_max;
 };
 
-template <int TYPE>
+template <int TYPE, bool MOE = false>
 __global__ __launch_bounds__(512) void gemm_wide_kernel(const gemm_mats mats, int nb, const _Float16 *__restrict__ Xh,
                                                         const float *__restrict__ d8T, const _Float16 *__restrict__ Xm, long n,
                                                         long n_pad, int n_rb, int n_ct, int ks_n, int nbs) {
@@ -140,31 +146,53 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const gemm_mats mats, in
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 31, h = lane >> 5;
 
-    // XCD-aware order: block ids go round-robin over the 8 XCDs; give each XCD a contiguous run of the order
-    // (K-split index slowest, then super-tiles of 8 x 4 tiles, see tile_of)
-    const int n_tiles = n_rb * n_ct, n_wg = n_tiles * ks_n;
-    const int id = blockIdx.x, q8 = n_wg >> 3, r8 = n_wg & 7, xcd = id & 7;
-    const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3);
-    const int ks = L / n_tiles;
-    int rb, ct;
-    tile_of(L - ks * n_tiles, n_rb, n_ct, rb, ct);
-
-    int mj = 0;
+    int ks, rb, ct, moe_left = 0;
+    const uint8_t *__restrict__ A;
+    float *__restrict__ C;
+    long m, ldc, n0;
+    if constexpr (MOE) {
+        // (expert, row block, token tile of that expert); the routing kernel ran earlier on this stream
+        // block id = (token tile, expert, row block), row blocks fastest: consecutive ids go round-robin over the XCDs,
+        // so the live tiles (low token-tile index) spread over all eight instead of piling onto XCD 0 and 1, and they
+        // are dispatched before the tiles that only exit
+        const int per_ct = (int)(gridDim.x / mats.moe_ct_max); // experts * n_rb
+        ct = blockIdx.x / per_ct;
+        const int rem = blockIdx.x - ct * per_ct;
+        const int e = rem / n_rb;
+        rb = rem - e * n_rb;
+        const int cnt_e = mats.moe_cnt[e];
+        moe_left = cnt_e - ct * WD_COLS; // token slots of this tile that carry a row
+        if (moe_left <= 0)
+            return; // uniform over the work-group
+        ks = 0;
+        A = mats.A[0] + (size_t)e * mats.expert_bytes;
+        C = mats.C[0];
+        m = mats.m[0], ldc = mats.ldc[0];
+        n0 = (long)mats.moe_poff[e] + (long)ct * WD_COLS;
+    } else {
+        // XCD-aware order: block ids go round-robin over the 8 XCDs; give each XCD a contiguous run of the order
+        // (K-split index slowest, then super-tiles of 8 x 4 tiles, see tile_of)
+        const int n_tiles = n_rb * n_ct, n_wg = n_tiles * ks_n;
+        const int id = blockIdx.x, q8 = n_wg >> 3, r8 = n_wg & 7, xcd = id & 7;
+        const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3);
+        ks = L / n_tiles;
+        tile_of(L - ks * n_tiles, n_rb, n_ct, rb, ct);
+        int mj = 0;
 #pragma unroll
-    for (int jj = 1; jj < GEMM_MAX_MATS; jj++)
-        if (jj < mats.count && rb >= mats.rb_end[jj - 1])
-            mj = jj;
-    if (mj > 0)
-        rb -= mats.rb_end[mj - 1];
-    const uint8_t *__restrict__ A = mats.A[mj];
-    float *__restrict__ C = mats.C[mj];
-    const long m = mats.m[mj], ldc = mats.ldc[mj];
+        for (int jj = 1; jj < GEMM_MAX_MATS; jj++)
+            if (jj < mats.count && rb >= mats.rb_end[jj - 1])
+                mj = jj;
+        if (mj > 0)
+            rb -= mats.rb_end[mj - 1];
+        A = mats.A[mj];
+        C = mats.C[mj];
+        m = mats.m[mj], ldc = mats.ldc[mj];
+        n0 = (long)ct * WD_COLS;
+    }
     const long n_row_tiles = (m + 31) / 32;
     const int rw = wave & 3, ch = wave >> 2; // row tile and 64-token column half of this wave
     const long rt = (long)rb * 4 + rw;
     const bool active = rt < n_row_tiles;
-    const long n0 = (long)ct * WD_COLS;
-    const long k = (long)nb * 256;
     const int b0 = ks * nbs, b1 = min(nb, b0 + nbs), nit = b1 - b0; // this work-group's super-blocks
     if (nit <= 0)
         return; // uniform over the work-group
@@ -682,8 +710,12 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const gemm_mats mats, in
             for (int nt = 0; nt < 2; nt++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
-                    const long tok = n0 + ch * 64 + nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (tok < n) {
+                    const int tl = ch * 64 + nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const long tok = n0 + tl;
+                    if constexpr (MOE) {
+                        if (tl < moe_left)
+                            C[(long)mats.moe_slot_row[tok] * ldc + row] = acc[nt][r];
+                    } else if (tok < n) {
                         if (ks_n == 1)
                             C[tok * ldc + row] = acc[nt][r];
                         else
@@ -728,6 +760,7 @@ extern "C" hipError_t lfamd_launch_gemm_wide_multi(int Atype, int count, const v
     gemm_mats mats;
     int n_rb = 0;
     mats.count = 0;
+    mats.moe_cnt = mats.moe_poff = mats.moe_slot_row = nullptr, mats.expert_bytes = 0, mats.moe_ct_max = 0;
     for (int j = 0; j < count; j++) {
         if (m[j] <= 0)
             continue;
@@ -789,4 +822,34 @@ extern "C" hipError_t lfamd_launch_gemm_wide_multi(int Atype, int count, const v
 extern "C" hipError_t lfamd_launch_gemm_wide(int Atype, const void *A, long m, long k, const void *Xh, const void *d8T,
                                              const void *Xm, long n, long n_pad, float *C, long ldc, hipStream_t s) {
     return lfamd_launch_gemm_wide_multi(Atype, 1, &A, &m, k, Xh, d8T, Xm, n, n_pad, &C, &ldc, s);
+}
+
+// GGML_OP_MUL_MAT_ID batches: one launch over (expert, row block, token tile); see gemm_mats.  n_pad = slots staged by the
+// activation prep (>= poff[experts-1] + cnt, multiple of 128); ct_max = token tiles of the worst case (all rows to one expert).
+extern "C" hipError_t lfamd_launch_gemm_wide_moe(int Atype, const void *W, long expert_bytes, int experts, long m, long k,
+                                                 const void *Xh, const void *d8T, const void *Xm, long n_pad, const int *cnt,
+                                                 const int *poff, const int *slot_row, int ct_max, float *C, long ldc,
+                                                 hipStream_t s) {
+    if (m <= 0 || experts <= 0 || ct_max <= 0)
+        return hipSuccess;
+    const int nb = (int)(k / 256);
+    gemm_mats mats;
+    for (int i = 0; i < GEMM_MAX_MATS; i++)
+        mats.A[i] = (const uint8_t *)W, mats.C[i] = C, mats.m[i] = m, mats.ldc[i] = ldc, mats.rb_end[i] = 0;
+    mats.count = 1;
+    mats.moe_cnt = cnt, mats.moe_poff = poff, mats.moe_slot_row = slot_row, mats.expert_bytes = expert_bytes, mats.moe_ct_max = ct_max;
+    const int n_rb = (int)((m + 127) / 128);
+    const unsigned n_wg = (unsigned)experts * n_rb * ct_max;
+    if (Atype == LFAMD_TYPE_Q4_K)
+        gemm_wide_kernel<LFAMD_TYPE_Q4_K, true><<<n_wg, 512, 0, s>>>(mats, nb, (const _Float16 *)Xh, (const float *)d8T,
+                                                                      (const _Float16 *)Xm, n_pad, n_pad, n_rb, ct_max, 1, nb);
+    else if (Atype == LFAMD_TYPE_Q5_K)
+        gemm_wide_kernel<LFAMD_TYPE_Q5_K, true><<<n_wg, 512, 0, s>>>(mats, nb, (const _Float16 *)Xh, (const float *)d8T,
+                                                                      (const _Float16 *)Xm, n_pad, n_pad, n_rb, ct_max, 1, nb);
+    else if (Atype == LFAMD_TYPE_Q6_K)
+        gemm_wide_kernel<LFAMD_TYPE_Q6_K, true><<<n_wg, 512, 0, s>>>(mats, nb, (const _Float16 *)Xh, (const float *)d8T,
+                                                                      (const _Float16 *)Xm, n_pad, n_pad, n_rb, ct_max, 1, nb);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
 }

@@ -48,13 +48,91 @@ static inline size_t align_up_(size_t x, size_t a) {
     return (x + a - 1) / a * a;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Device-side routing for batches of K-quant experts: no read-back (the reference synchronises the stream and sorts on
+// the host, ggml-cuda.cu.patch:18528-18531).  One work-group: count the rows of every expert, give expert e the slot
+// range [poff[e], poff[e] + cnt[e]) with poff a multiple of the 128-token tile, and fill the ranges in (token, thinker)
+// order like build_row_pointers (tinyblas_cpu_mixmul.inc:297-320).  slot_row = result row of a slot, src_row = activation
+// row it reads (-1 for padding slots).  Rows with an out-of-range expert id get no slot (their result stays untouched).
+__global__ __launch_bounds__(256) void moe_route_kernel(const int32_t *__restrict__ plan, long tokens, int thinkers, int tasks,
+                                                        int experts, int n_slots, int *__restrict__ cnt, int *__restrict__ poff,
+                                                        int *__restrict__ slot_row, int *__restrict__ src_row) {
+    __shared__ int s_cnt[256], s_off[256];
+    extern __shared__ uint8_t s_plan[]; // expert id per row (0xFF: none): the ordered fill below scans LDS, not global memory
+    const long R = tokens * thinkers;
+    const int t = threadIdx.x;
+    s_cnt[t] = 0;
+    for (int sl = t; sl < n_slots; sl += 256)
+        slot_row[sl] = -1, src_row[sl] = -1;
+    __syncthreads();
+    for (long r = t; r < R; r += 256) {
+        const int e = plan[r];
+        const bool ok = e >= 0 && e < experts;
+        s_plan[r] = ok ? (uint8_t)e : (uint8_t)0xFF;
+        if (ok)
+            atomicAdd(&s_cnt[e], 1);
+    }
+    __syncthreads();
+    if (t == 0) {
+        int off = 0;
+        for (int e = 0; e < experts; e++) {
+            s_off[e] = off;
+            off += (s_cnt[e] + 127) / 128 * 128;
+        }
+    }
+    __syncthreads();
+    if (t < experts) {
+        cnt[t] = s_cnt[t];
+        poff[t] = s_off[t];
+        int sl = s_off[t];
+        long tok = 0;
+        int th = 0;
+        for (long r = 0; r < R; r++) { // stable: (token, thinker) order
+            if (s_plan[r] == t) {
+                slot_row[sl] = (int)r;
+                src_row[sl] = (int)(tok * tasks + th % tasks);
+                sl++;
+            }
+            if (++th == thinkers)
+                th = 0, tok++;
+        }
+    }
+}
+
+static bool moe_grouped_ok(int type, long tokens, int thinkers, int experts) {
+    return (type == LFAMD_TYPE_Q4_K || type == LFAMD_TYPE_Q5_K || type == LFAMD_TYPE_Q6_K) && experts < 255 &&
+           tokens * thinkers <= 60 * 1024; // the routing kernel keeps one byte per row in LDS
+}
+
+static size_t moe_grouped_slots(long tokens, int thinkers, int experts) {
+    return align_up_((size_t)tokens * thinkers, 128) + (size_t)experts * 128;
+}
+
+extern "C" hipError_t lfamd_launch_prep_q8k(const void *, size_t, long, long, long, void *, void *, void *, int, const int32_t *,
+                                            hipStream_t);
+extern "C" hipError_t lfamd_launch_prep_f32(const void *, size_t, long, long, long, void *, void *, void *, int, const int32_t *,
+                                            hipStream_t);
+extern "C" hipError_t lfamd_launch_gemm_wide_moe(int, const void *, long, int, long, long, const void *, const void *, const void *,
+                                                 long, const int *, const int *, const int *, int, float *, long, hipStream_t);
+
+static size_t moe_grouped_ws(long cols, long tokens, int thinkers, int experts) {
+    const size_t n_pad = moe_grouped_slots(tokens, thinkers, experts), nb = (size_t)(cols / 256);
+    return align_up_((2 * (size_t)experts + 2 * n_pad) * 4, 256) + align_up_(n_pad * (size_t)cols * 2, 256) +
+           align_up_(nb * n_pad * 4, 256) + align_up_(n_pad * nb * 32, 256);
+}
+
 extern "C" size_t lfamd_moe_workspace(int type, long rows, long cols, int experts, long tokens, int thinkers) {
     (void)experts;
     const size_t nr = (size_t)tokens * thinkers;
     const size_t brb = lfamd_row_size(lfamd_vec_dot_type(type), cols);
     const size_t inner = lfamd_mul_mat_workspace(type, rows, cols, (long)nr); // monotonic in n
-    return align_up_(nr * brb, 256) + align_up_(nr * (size_t)rows * 4, 256) + align_up_(nr * 4, 256) * 2 +
-           align_up_(inner, 256);
+    size_t host_path = align_up_(nr * brb, 256) + align_up_(nr * (size_t)rows * 4, 256) + align_up_(nr * 4, 256) * 2 +
+                       align_up_(inner, 256);
+    if (moe_grouped_ok(type, tokens, thinkers, experts) && cols % 256 == 0) {
+        size_t g = moe_grouped_ws(cols, tokens, thinkers, experts);
+        return g > host_path ? g : host_path;
+    }
+    return host_path;
 }
 
 extern "C" hipError_t lfamd_launch_moe(int type, const void *W, long rows, long cols, int experts, size_t expert_bytes,
@@ -89,6 +167,34 @@ extern "C" hipError_t lfamd_launch_moe(int type, const void *W, long rows, long 
             }
         }
         return hipSuccess;
+    }
+    // ---- batches of K-quant experts: device-side routing + ONE grouped launch of the 128 x 128 MFMA body over
+    // (expert, row block, token tile); asynchronous and graph-capturable.
+    if (tokens > 4 && moe_grouped_ok(type, tokens, thinkers, experts) && !(flags & LFAMD_FLAG_FORCE_GENERIC) &&
+        (Btype == LFAMD_TYPE_F32 || Btype == LFAMD_TYPE_Q8_K) && cols % 256 == 0 &&
+        ws_bytes >= moe_grouped_ws(cols, tokens, thinkers, experts)) {
+        const size_t n_pad = moe_grouped_slots(tokens, thinkers, experts), nbk = (size_t)(cols / 256);
+        uint8_t *p = (uint8_t *)ws;
+        int *cnt = (int *)p, *poff = cnt + experts, *slot_row = poff + experts, *src_row = slot_row + n_pad;
+        p += align_up_((2 * (size_t)experts + 2 * n_pad) * 4, 256);
+        void *Xh = p;
+        p += align_up_(n_pad * (size_t)cols * 2, 256);
+        void *d8T = p;
+        p += align_up_(nbk * n_pad * 4, 256);
+        void *Xm = p;
+        moe_route_kernel<<<1, 256, align_up_(nr, 16), s>>>(plan, tokens, thinkers, tasks, experts, (int)n_pad, cnt, poff, slot_row,
+                                                          src_row);
+        hipError_t e2 = hipGetLastError();
+        if (e2 != hipSuccess)
+            return e2;
+        e2 = Btype == LFAMD_TYPE_F32
+                 ? lfamd_launch_prep_f32(thought, b_row_bytes, (long)n_pad, (long)n_pad, cols, Xh, d8T, Xm, 0, src_row, s)
+                 : lfamd_launch_prep_q8k(thought, b_row_bytes, (long)n_pad, (long)n_pad, cols, Xh, d8T, Xm, 0, src_row, s);
+        if (e2 != hipSuccess)
+            return e2;
+        const int ct_max = (int)((nr + 127) / 128);
+        return lfamd_launch_gemm_wide_moe(type, W, (long)expert_bytes, experts, rows, cols, Xh, d8T, Xm, (long)n_pad, cnt, poff,
+                                          slot_row, ct_max, result, rows, s);
     }
     std::vector<int32_t> hplan(nr);
     hipError_t e = hipMemcpyAsync(hplan.data(), plan, nr * 4, hipMemcpyDeviceToHost, s);

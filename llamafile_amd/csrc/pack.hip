@@ -303,14 +303,17 @@ __global__ void pack_raw_kernel(const uint8_t *__restrict__ raw, size_t raw_row_
 
 // mins16: Xm holds the 16 bsums themselves (exact in f16, |sum| <= 2032) for the types with 16-wide sub-blocks (Q2_K)
 __global__ void prep_q8k_kernel(const uint8_t *__restrict__ B, size_t b_row_bytes, long n, long n_pad, int nb,
-                                _Float16 *__restrict__ Xh, float *__restrict__ d8T, _Float16 *__restrict__ Xm, int mins16) {
+                                _Float16 *__restrict__ Xh, float *__restrict__ d8T, _Float16 *__restrict__ Xm, int mins16,
+                                const int32_t *__restrict__ src_idx) {
     long blk = blockIdx.x; // (token, super-block)
     long tok = blk / nb;
     int b = (int)(blk % nb);
     int t = threadIdx.x; // 64 threads: 4 codes each
     _Float16 *xo = Xh + ((size_t)b * n_pad + tok) * 256;
-    if (tok < n) {
-        const lfamd_block_q8_K *y = (const lfamd_block_q8_K *)(B + tok * b_row_bytes) + b;
+    // src_idx (MUL_MAT_ID batches): token slot -> activation row, -1 = padding slot
+    const long src = src_idx ? (long)src_idx[tok] : (tok < n ? tok : -1);
+    if (src >= 0) {
+        const lfamd_block_q8_K *y = (const lfamd_block_q8_K *)(B + src * b_row_bytes) + b;
         uint32_t q = *(const uint32_t *)((const uint8_t *)y->qs + 4 * t); // 292-byte blocks are 4-aligned
         for (int e = 0; e < 4; e++)
             xo[4 * t + e] = (_Float16)(int)(int8_t)(q >> (8 * e));
@@ -341,14 +344,15 @@ __global__ void prep_q8k_kernel(const uint8_t *__restrict__ B, size_t b_row_byte
 // the Q8_K blocks.  One wave per (token, super-block), 4 values per lane.
 __global__ __launch_bounds__(64) void prep_f32_kernel(const uint8_t *__restrict__ X, size_t x_row_bytes, long n, long n_pad,
                                                       int nb, _Float16 *__restrict__ Xh, float *__restrict__ d8T,
-                                                      _Float16 *__restrict__ Xm, int mins16) {
+                                                      _Float16 *__restrict__ Xm, int mins16, const int32_t *__restrict__ src_idx) {
     long blk = blockIdx.x;
     long tok = blk / nb;
     int b = (int)(blk % nb);
     int t = threadIdx.x;
     _Float16 *xo = Xh + ((size_t)b * n_pad + tok) * 256;
     typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
-    if (tok >= n) {
+    const long src = src_idx ? (long)src_idx[tok] : (tok < n ? tok : -1); // as prep_q8k_kernel
+    if (src < 0) {
         half4_t z = {(_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0};
         *(half4_t *)(xo + 4 * t) = z;
         if (t == 0)
@@ -357,7 +361,7 @@ __global__ __launch_bounds__(64) void prep_f32_kernel(const uint8_t *__restrict_
             Xm[((size_t)b * n_pad + tok) * 16 + t] = (_Float16)0;
         return;
     }
-    const float4 f = *(const float4 *)((const float *)(X + tok * x_row_bytes) + (size_t)b * 256 + 4 * t);
+    const float4 f = *(const float4 *)((const float *)(X + src * x_row_bytes) + (size_t)b * 256 + 4 * t);
     const float v[4] = {f.x, f.y, f.z, f.w};
     float amax = 0.0f, val = 0.0f;
     int idx = 4 * t;
@@ -534,13 +538,13 @@ hipError_t lfamd_launch_pack_raw(const void *raw, size_t raw_row_bytes, long row
 }
 
 hipError_t lfamd_launch_prep_f32(const void *X, size_t x_row_bytes, long n, long n_pad, long cols, void *Xh, void *d8T,
-                                 void *Xm, int mins16, hipStream_t s) {
+                                 void *Xm, int mins16, const int32_t *src_idx, hipStream_t s) {
     int nb = (int)(cols / 256);
     long blocks = n_pad * nb;
     if (blocks == 0)
         return hipSuccess;
     prep_f32_kernel<<<(unsigned)blocks, 64, 0, s>>>((const uint8_t *)X, x_row_bytes, n, n_pad, nb, (_Float16 *)Xh,
-                                                     (float *)d8T, (_Float16 *)Xm, mins16);
+                                                     (float *)d8T, (_Float16 *)Xm, mins16, src_idx);
     return hipGetLastError();
 }
 
@@ -567,13 +571,13 @@ hipError_t lfamd_launch_prep80(int Btype, const void *B, size_t b_row_bytes, lon
 }
 
 hipError_t lfamd_launch_prep_q8k(const void *B, size_t b_row_bytes, long n, long n_pad, long cols, void *Xh, void *d8T,
-                                 void *Xm, int mins16, hipStream_t s) {
+                                 void *Xm, int mins16, const int32_t *src_idx, hipStream_t s) {
     int nb = (int)(cols / 256);
     long blocks = n_pad * nb;
     if (blocks == 0)
         return hipSuccess;
     prep_q8k_kernel<<<(unsigned)blocks, 64, 0, s>>>((const uint8_t *)B, b_row_bytes, n, n_pad, nb, (_Float16 *)Xh,
-                                                     (float *)d8T, (_Float16 *)Xm, mins16);
+                                                     (float *)d8T, (_Float16 *)Xm, mins16, src_idx);
     return hipGetLastError();
 }
 }

@@ -314,3 +314,41 @@ def test_legacy_types_gemm_vs_oracle(gpu, oracle, t, shape, f32in):
         C = gpu.mul_mat(W, torch.from_numpy(B).cuda(), vdt)
     torch.cuda.synchronize()
     assert rel_err(C.cpu().numpy(), G) <= TOL.get(t, DEFAULT_TOL)
+
+
+@pytest.mark.parametrize("t", [T.Q4_K, T.Q5_K, T.Q6_K], ids=lambda t: T.NAMES[t])
+@pytest.mark.parametrize("tokens,tasks", [(5, 1), (37, 2), (150, 1), (200, 2)])
+@pytest.mark.parametrize("f32in", [False, True], ids=["q8k", "f32"])
+def test_mul_mat_id_batches_grouped_on_device(gpu, oracle, t, tokens, tasks, f32in):
+    """GGML_OP_MUL_MAT_ID for batches: rows are grouped by expert ON THE DEVICE (no routing read-back) and all experts run
+    in one launch of the 128x128 MFMA body; skewed routing (one hot expert, one unused), an out-of-range id."""
+    from llamafile_amd import synth
+    rows, cols, experts, thinkers = 160, 512, 6, 2
+    Ws = [synth.random_weights(t, rows, cols, 950 + e) for e in range(experts)]
+    packed = torch.cat([gpu.upload_weights(t, W, rows, cols).data for W in Ws])
+    x = synth.random_activations(tokens * tasks, cols, 78)
+    xq = synth.quantize_activations(T.Q8_K, x)
+    rng = np.random.default_rng(6)
+    plan = rng.choice([0, 0, 0, 1, 2, 4, 5], size=(tokens, thinkers)).astype(np.int32)  # expert 3 never used, 0 hot
+    plan[-1, -1] = experts + 2  # invalid: row left untouched
+    if f32in:
+        thought = torch.from_numpy(x).cuda().view(torch.uint8).view(tokens * tasks, cols * 4)
+        bt = T.F32
+    else:
+        thought = torch.from_numpy(xq).cuda()
+        bt = T.Q8_K
+    res = gpu.mul_mat_id(packed, t, rows, cols, experts, thought, bt, tasks, tokens, torch.from_numpy(plan).cuda(), thinkers,
+                         prefill=-7.0)
+    torch.cuda.synchronize()
+    res = res.cpu().numpy()
+    tol = GEMM_TOL[t]
+    for ex in range(experts):
+        sel = [(tok, th) for tok in range(tokens) for th in range(thinkers) if plan[tok, th] == ex]
+        if not sel:
+            continue
+        Bx = np.stack([xq[tok * tasks + th % tasks] for tok, th in sel])
+        ok, G = oracle.sgemm(t, Ws[ex], T.Q8_K, Bx, rows, len(sel), cols)
+        assert ok == 1
+        got = np.stack([res[tok, th] for tok, th in sel])
+        assert rel_err(got, G) <= tol, (ex, rel_err(got, G))
+    assert (res[-1, -1] == -7.0).all()
