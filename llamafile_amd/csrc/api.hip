@@ -497,7 +497,7 @@ int lfamd_mul_mat_id(int type, const void *d_W, long rows, long cols, int expert
         return fail(LFAMD_ERR_INVALID, "mul_mat_id: bad shape%s", "");
     // f32 activations (the GGML_OP_MUL_MAT_ID boundary) are served by the decode path, which quantises in-kernel
     const bool f32_decode = Btype == LFAMD_TYPE_F32 && !(flags & LFAMD_FLAG_FORCE_GENERIC) &&
-                            ((tokens <= 4 && (type == LFAMD_TYPE_Q4_K || type == LFAMD_TYPE_Q6_K)) ||
+                            ((tokens <= 4 && (type == LFAMD_TYPE_Q4_K || type == LFAMD_TYPE_Q5_K || type == LFAMD_TYPE_Q6_K)) ||
                              (tokens > 4 && cols % 256 == 0 && experts < 255 && tokens * thinkers <= 60 * 1024 &&
                               (type == LFAMD_TYPE_Q4_K || type == LFAMD_TYPE_Q5_K || type == LFAMD_TYPE_Q6_K)));
     if (Btype != lfamd_vec_dot_type(type) && !f32_decode)

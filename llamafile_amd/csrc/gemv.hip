@@ -1146,7 +1146,8 @@ extern "C" hipError_t lfamd_launch_gemv_multi(int Atype, int count, const void *
 extern "C" hipError_t lfamd_launch_gemv_ids(int Atype, int count, const void *W, long expert_bytes, int experts,
                                             const int32_t *ids, const int *id_idx, long m, long k, int Btype, const void *B,
                                             size_t b_row_bytes, float *const *C, hipStream_t s) {
-    if (count <= 0 || count > GEMV_MAX_MATS || m <= 0 || (Atype != LFAMD_TYPE_Q4_K && Atype != LFAMD_TYPE_Q6_K))
+    if (count <= 0 || count > GEMV_MAX_MATS || m <= 0 ||
+        (Atype != LFAMD_TYPE_Q4_K && Atype != LFAMD_TYPE_Q5_K && Atype != LFAMD_TYPE_Q6_K))
         return hipErrorInvalidValue;
     if ((size_t)(k / 256) * XBLK > 150 * 1024)
         return hipErrorInvalidValue;
@@ -1166,6 +1167,9 @@ extern "C" hipError_t lfamd_launch_gemv_ids(int Atype, int count, const void *W,
     if (Atype == LFAMD_TYPE_Q4_K)
         return f32in ? launch_kq_ids<q4k_traits, LFAMD_TYPE_F32>(mats, n_ht, k, B, b_row_bytes, s)
                      : launch_kq_ids<q4k_traits, LFAMD_TYPE_Q8_K>(mats, n_ht, k, B, b_row_bytes, s);
+    if (Atype == LFAMD_TYPE_Q5_K)
+        return f32in ? launch_kq_ids<q5k_traits, LFAMD_TYPE_F32>(mats, n_ht, k, B, b_row_bytes, s)
+                     : launch_kq_ids<q5k_traits, LFAMD_TYPE_Q8_K>(mats, n_ht, k, B, b_row_bytes, s);
     return f32in ? launch_kq_ids<q6k_traits, LFAMD_TYPE_F32>(mats, n_ht, k, B, b_row_bytes, s)
                  : launch_kq_ids<q6k_traits, LFAMD_TYPE_Q8_K>(mats, n_ht, k, B, b_row_bytes, s);
 }

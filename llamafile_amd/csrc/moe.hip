@@ -144,7 +144,8 @@ extern "C" hipError_t lfamd_launch_moe(int type, const void *W, long rows, long 
     // kernel picks the expert from the device-resident routing table; thinkers that share their activations
     // (tasks == 1: ffn_gate / ffn_up) are fused into one launch.  Asynchronous and graph-capturable, unlike the
     // reference's host round trip (ggml-cuda.cu.patch:18528-18531).
-    if (tokens <= 4 && (type == LFAMD_TYPE_Q4_K || type == LFAMD_TYPE_Q6_K) && !(flags & LFAMD_FLAG_FORCE_GENERIC) &&
+    if (tokens <= 4 && (type == LFAMD_TYPE_Q4_K || type == LFAMD_TYPE_Q5_K || type == LFAMD_TYPE_Q6_K) &&
+        !(flags & LFAMD_FLAG_FORCE_GENERIC) &&
         (Btype == LFAMD_TYPE_F32 || Btype == LFAMD_TYPE_Q8_K) && (size_t)(cols / 256) * 384 <= 150 * 1024) {
         for (long t = 0; t < tokens; t++) {
             int th = 0;

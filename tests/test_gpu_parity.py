@@ -228,7 +228,7 @@ def test_experimental_lds3_gemm_variant(gpu, oracle, monkeypatch):
         assert rel_err(C, G) <= 2e-6, (m, n, k)
 
 
-@pytest.mark.parametrize("t", [T.Q4_K, T.Q6_K], ids=lambda t: T.NAMES[t])
+@pytest.mark.parametrize("t", [T.Q4_K, T.Q5_K, T.Q6_K], ids=lambda t: T.NAMES[t])
 @pytest.mark.parametrize("tokens,tasks", [(1, 1), (1, 2), (3, 1), (2, 2)])
 @pytest.mark.parametrize("f32in", [False, True], ids=["q8k", "f32"])
 def test_mul_mat_id_decode_on_device(gpu, oracle, t, tokens, tasks, f32in):
