@@ -15,6 +15,7 @@ hipError_t lfamd_launch_pack_q40(const void *, size_t, long, long, void *, hipSt
 hipError_t lfamd_launch_prep80(int, const void *, size_t, long, long, long, void *, void *, void *, hipStream_t);
 hipError_t lfamd_launch_wprep32(int, const void *, long, long, void *, hipStream_t);
 size_t lfamd_wprep32_bytes(long, long);
+hipError_t lfamd_launch_prep_float(int, int, const void *, size_t, long, long, long, void *, hipStream_t);
 hipError_t lfamd_launch_wprep8(int, const void *, long, long, void *, hipStream_t);
 size_t lfamd_wprep8_bytes(long, long);
 hipError_t lfamd_launch_pack_q5k(const void *, size_t, long, long, void *, hipStream_t);
@@ -250,6 +251,11 @@ static bool use_gemm_canon32(int Atype, long n, unsigned flags, long k) {
            (Atype == LFAMD_TYPE_Q4_1 || Atype == LFAMD_TYPE_Q5_0 || Atype == LFAMD_TYPE_Q5_1);
 }
 
+// F16 / BF16 weights, batches, rows of whole 256-element groups: MFMA body straight on the RAW rows
+static bool use_gemm_float(int Atype, long n, unsigned flags, long k) {
+    return !(flags & LFAMD_FLAG_FORCE_GENERIC) && n > 8 && k % 256 == 0 && (Atype == LFAMD_TYPE_F16 || Atype == LFAMD_TYPE_BF16);
+}
+
 // Q8_0 batches: the register-tiled bit-exact kernel (gemm_q80.hip)
 static bool use_gemm_q80(int Atype, long n, unsigned flags) {
     return !(flags & LFAMD_FLAG_FORCE_GENERIC) && n > 8 && Atype == LFAMD_TYPE_Q8_0;
@@ -277,6 +283,8 @@ size_t lfamd_mul_mat_workspace(int Atype, long m, long k, long n) {
     }
     if (use_gemm_q80(Atype, n, 0))
         return align_up(lfamd_gemm_q80_workspace(k, n), 256);
+    if (use_gemm_float(Atype, n, 0, k))
+        return align_up(align_up((size_t)n, 128) * (size_t)k * 2, 256);
     if (use_gemm_canon(Atype, n, 0))
         return gemm_act_ws(k, n) + align_up(Atype == LFAMD_TYPE_IQ4_XS ? lfamd_wprep8_bytes(m, k) : lfamd_wprep16_bytes(m, k), 256);
     if (use_gemm_canon32(Atype, n, 0, k)) { // Xh, d8T [nb*8][n_pad], sT [nb*8][n_pad], image
@@ -342,6 +350,15 @@ int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const v
             HIPCHK(lfamd_launch_gemm_kq(Atype, d_A, m, k, Xh, d8T, Xm, n, (long)n_pad, d_C, ldc, s), "gemm_kq");
         else
             HIPCHK(lfamd_launch_gemm_wide(Atype, d_A, m, k, Xh, d8T, Xm, n, (long)n_pad, d_C, ldc, s), "gemm_wide");
+        return LFAMD_OK;
+    }
+    if (use_gemm_float(Atype, n, flags, k)) {
+        size_t need = lfamd_mul_mat_workspace(Atype, m, k, n);
+        if (ws_bytes < need || !d_ws)
+            return fail(LFAMD_ERR_WORKSPACE, "mul_mat: workspace too small%s", "");
+        size_t n_pad = align_up((size_t)n, 128);
+        HIPCHK(lfamd_launch_prep_float(Atype, Btype, d_B, b_row_bytes, n, (long)n_pad, k, d_ws, s), "prep_float");
+        HIPCHK(lfamd_launch_gemm_wide(Atype, d_A, m, k, d_ws, d_ws, d_ws, n, (long)n_pad, d_C, ldc, s), "gemm_wide");
         return LFAMD_OK;
     }
     if (use_gemm_canon32(Atype, n, flags, k)) {

@@ -33,6 +33,7 @@ struct wide_w {
     u32x4 qh[2]; // Q6_K only
     uint32_t dw; // Q6_K only (f16 bits)
     u32x4 q8[4]; // IQ4_XS byte image: K-steps 8..15 (qs[] holds 0..7)
+    u32x4 f[16]; // F16 / BF16: the 16 K-step fragments of the lane's row, straight from the RAW row
 };
 
 template <int IMM>
@@ -139,6 +140,9 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const gemm_mats mats, in
     constexpr bool CANON16 = TYPE == LFAMD_TYPE_Q2_K || TYPE == LFAMD_TYPE_Q3_K;
     constexpr bool MINS16 = TYPE == LFAMD_TYPE_Q2_K;
     constexpr bool BYTES8 = TYPE == LFAMD_TYPE_IQ4_XS; // PC8 byte image built per call (generic.hip, wprep8)
+    // float tinyBLAS types (tinyblas_cpu.h:419-613): no dequantisation, no scales — the lane's 8 consecutive halves of a
+    // K-step are 16 contiguous bytes of the RAW row; f32 accumulate on the matrix cores like the reference's fmaf chains
+    constexpr bool FLT = TYPE == LFAMD_TYPE_F16 || TYPE == LFAMD_TYPE_BF16;
     __shared__ __attribute__((aligned(16))) float d8s[2][(LEGACY ? 8 : 1) * WD_COLS]; // d8 of the 128 tokens
     __shared__ __attribute__((aligned(16))) uint8_t xms[2][WD_COLS * 32]; // Q4_K mins operand rows; L1: the 8 x 128 f32 s values
     constexpr int TILE = (TYPE == LFAMD_TYPE_Q4_K || TYPE == LFAMD_TYPE_Q4_0) ? P4K_TILE : LEGACY ? PCL_TILE : TYPE == LFAMD_TYPE_Q5_K ? P5K_TILE : CANON16 ? PCK_TILE : BYTES8 ? PC8_TILE : P6K_TILE;
@@ -210,7 +214,12 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const gemm_mats mats, in
     const uint32_t xmo = (uint32_t)((32 * (wave & 3) + (lane >> 1)) * 32 + (lane & 1) * 16);
     const uint32_t d8o = (uint32_t)((lane >> 5) * n_pad * 4 + (lane & 31) * 16); // LEGACY d8 rows
     const uint8_t *xbase = (const uint8_t *)Xh + (size_t)n0 * 512;           // + b * n_pad * 512
-    const uint8_t *wbase = A + (size_t)(active ? rt : 0) * nb * TILE;
+    const uint8_t *wbase = A + (size_t)(active ? rt : 0) * nb * (FLT ? 32 * 512 : TILE);
+    constexpr int WSTEP = FLT ? 512 : TILE; // bytes from one super-block of this wave's rows to the next
+    // FLT: this lane's row of the tile (clamped to the matrix: the RAW tensor has exactly m rows), 8 h halves in
+    const long frow = min((active ? rt : 0) * 32 + (long)i, m - 1) - (active ? rt : 0) * 32;
+    const uint32_t fo = (uint32_t)(frow * (long)nb * 512 + h * 16);
+    (void)fo;
     const uint8_t *xmbase = (const uint8_t *)Xm + (size_t)n0 * 32;           // + b * n_pad * 32
     const uint32_t xs_a[2] = {lds_addr(xs[0]), lds_addr(xs[1])};
     const uint32_t d8_a[2] = {lds_addr(d8s[0]), lds_addr(d8s[1])};
@@ -225,7 +234,8 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const gemm_mats mats, in
         const uint32_t dst = xs_a[st] + wave * 8192;
         glds4(xb, dst, xo[0], xo[1], xo[2], xo[3]);
         glds4(xb, dst + 4096, xo[4], xo[5], xo[6], xo[7]);
-        if constexpr (LEGACY) { // 8 rows of 128 f32: waves 4..7 copy two rows each (one 16-byte piece)
+        if constexpr (FLT) {
+        } else if constexpr (LEGACY) { // 8 rows of 128 f32: waves 4..7 copy two rows each (one 16-byte piece)
             if (wave >= 4)
                 glds1x16(uniform_ptr(d8T + ((size_t)b * 8 + 2 * (wave - 4)) * n_pad + n0), d8_a[st] + (wave - 4) * 1024, d8o);
         } else if (wave >= 6) // d8 of tokens 64*(wave-6) + lane
@@ -238,13 +248,20 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const gemm_mats mats, in
             if (wave < 4)
                 glds1x16(uniform_ptr((const float *)Xm + ((size_t)b * 8 + 2 * wave) * n_pad + n0), xm_a[st] + wave * 1024, d8o);
         }
-        const uint8_t *tile = uniform_ptr(wbase + (size_t)b * TILE);
+        const uint8_t *tile = uniform_ptr(wbase + (size_t)b * WSTEP);
         const uint8_t *tile_h = uniform_ptr(tile + 4096), *tile_d = uniform_ptr(tile + P6K_D);
-        gload16<0>(w.qs[0], tile, wo);
-        gload16<1024>(w.qs[1], tile, wo);
-        gload16<2048>(w.qs[2], tile, wo);
-        gload16<3072>(w.qs[3], tile, wo);
-        if constexpr (BYTES8) {
+        if constexpr (!FLT) {
+            gload16<0>(w.qs[0], tile, wo);
+            gload16<1024>(w.qs[1], tile, wo);
+            gload16<2048>(w.qs[2], tile, wo);
+            gload16<3072>(w.qs[3], tile, wo);
+        }
+        if constexpr (FLT) {
+            gload16<0>(w.f[0], tile, fo), gload16<32>(w.f[1], tile, fo), gload16<64>(w.f[2], tile, fo), gload16<96>(w.f[3], tile, fo);
+            gload16<128>(w.f[4], tile, fo), gload16<160>(w.f[5], tile, fo), gload16<192>(w.f[6], tile, fo), gload16<224>(w.f[7], tile, fo);
+            gload16<256>(w.f[8], tile, fo), gload16<288>(w.f[9], tile, fo), gload16<320>(w.f[10], tile, fo), gload16<352>(w.f[11], tile, fo);
+            gload16<384>(w.f[12], tile, fo), gload16<416>(w.f[13], tile, fo), gload16<448>(w.f[14], tile, fo), gload16<480>(w.f[15], tile, fo);
+        } else if constexpr (BYTES8) {
             gload16<0>(w.q8[0], tile_h, wo);
             gload16<1024>(w.q8[1], tile_h, wo);
             gload16<2048>(w.q8[2], tile_h, wo);
@@ -277,13 +294,20 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const gemm_mats mats, in
     // small operands last; nothing is issued during the last five K-steps so the data lands before the barrier.
     auto prefetch_step = [&](int t, int b, int st, wide_w<TYPE> &w) {
         if (t == 0) {
-            const uint8_t *tile = uniform_ptr(wbase + (size_t)b * TILE);
+            const uint8_t *tile = uniform_ptr(wbase + (size_t)b * WSTEP);
             const uint8_t *tile_h = uniform_ptr(tile + 4096), *tile_d = uniform_ptr(tile + P6K_D);
-            gload16<0>(w.qs[0], tile, wo);
-            gload16<1024>(w.qs[1], tile, wo);
-            gload16<2048>(w.qs[2], tile, wo);
-            gload16<3072>(w.qs[3], tile, wo);
-            if constexpr (BYTES8) {
+            if constexpr (!FLT) {
+                gload16<0>(w.qs[0], tile, wo);
+                gload16<1024>(w.qs[1], tile, wo);
+                gload16<2048>(w.qs[2], tile, wo);
+                gload16<3072>(w.qs[3], tile, wo);
+            }
+            if constexpr (FLT) {
+                gload16<0>(w.f[0], tile, fo), gload16<32>(w.f[1], tile, fo), gload16<64>(w.f[2], tile, fo), gload16<96>(w.f[3], tile, fo);
+                gload16<128>(w.f[4], tile, fo), gload16<160>(w.f[5], tile, fo), gload16<192>(w.f[6], tile, fo), gload16<224>(w.f[7], tile, fo);
+                gload16<256>(w.f[8], tile, fo), gload16<288>(w.f[9], tile, fo), gload16<320>(w.f[10], tile, fo), gload16<352>(w.f[11], tile, fo);
+                gload16<384>(w.f[12], tile, fo), gload16<416>(w.f[13], tile, fo), gload16<448>(w.f[14], tile, fo), gload16<480>(w.f[15], tile, fo);
+            } else if constexpr (BYTES8) {
                 gload16<0>(w.q8[0], tile_h, wo);
                 gload16<1024>(w.q8[1], tile_h, wo);
                 gload16<2048>(w.q8[2], tile_h, wo);
@@ -312,7 +336,8 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const gemm_mats mats, in
             const int e = t - 1;
             glds1x16(uniform_ptr(xbase + (size_t)b * n_pad * 512), xs_a[st] + wave * 8192 + e * 1024, xo[e]);
         } else if (t == 9) {
-            if constexpr (LEGACY) {
+            if constexpr (FLT) {
+            } else if constexpr (LEGACY) {
                 if (wave >= 4)
                     glds1x16(uniform_ptr(d8T + ((size_t)b * 8 + 2 * (wave - 4)) * n_pad + n0), d8_a[st] + (wave - 4) * 1024, d8o);
             } else if (wave >= 6)
@@ -331,7 +356,14 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const gemm_mats mats, in
     // retire every load of the stage (this wave's), then meet the other waves: their LDS-DMA has landed too, and
     // everybody has finished reading the stage that the next prefetch overwrites
     auto arrive = [&](wide_w<TYPE> &w) {
-        if constexpr (L1 || L5)
+        if constexpr (FLT)
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier"
+                         : "+v"(w.f[0]), "+v"(w.f[1]), "+v"(w.f[2]), "+v"(w.f[3]), "+v"(w.f[4]), "+v"(w.f[5]), "+v"(w.f[6]), "+v"(w.f[7]),
+                           "+v"(w.f[8]), "+v"(w.f[9]), "+v"(w.f[10]), "+v"(w.f[11]), "+v"(w.f[12]), "+v"(w.f[13]), "+v"(w.f[14]),
+                           "+v"(w.f[15])
+                         :
+                         : "memory");
+        else if constexpr (L1 || L5)
             asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier"
                          : "+v"(w.qs[0]), "+v"(w.qs[1]), "+v"(w.qs[2]), "+v"(w.qs[3]), "+v"(w.hd), "+v"(w.qh[0]), "+v"(w.qh[1])
                          :
@@ -402,7 +434,29 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const gemm_mats mats, in
         float16_t_ tmp[2];
         const uint32_t qw[16] = {w.qs[0].x, w.qs[0].y, w.qs[0].z, w.qs[0].w, w.qs[1].x, w.qs[1].y, w.qs[1].z, w.qs[1].w,
                                  w.qs[2].x, w.qs[2].y, w.qs[2].z, w.qs[2].w, w.qs[3].x, w.qs[3].y, w.qs[3].z, w.qs[3].w};
-        if constexpr (MINS) {
+        if constexpr (FLT) {
+            typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+            half8_t F[2][2];
+            read_frags(F[0], 0);
+#pragma unroll
+            for (int t = 0; t < 16; t++) {
+                if (t + 1 < 16) {
+                    read_frags(F[(t + 1) & 1], t + 1);
+                    ds_wait<2>(F[t & 1][0], F[t & 1][1]);
+                } else {
+                    ds_wait<0>(F[t & 1][0], F[t & 1][1]);
+                }
+#pragma unroll
+                for (int nt = 0; nt < 2; nt++) {
+                    if constexpr (TYPE == LFAMD_TYPE_F16)
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F[t & 1][nt], __builtin_bit_cast(half8_t, w.f[t]), acc[nt], 0, 0, 0);
+                    else
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, F[t & 1][nt]),
+                                                                          __builtin_bit_cast(bf16x8_t, w.f[t]), acc[nt], 0, 0, 0);
+                }
+                prefetch_step(t, bn, st ^ 1, wn);
+            }
+        } else if constexpr (MINS) {
             const uint32_t hq5[4] = {w.qh[0].x, w.qh[0].y, w.qh[0].z, w.qh[0].w}; // Q5_K only
             (void)hq5;
             const float d = h2f((uint16_t)(w.hd.x & 0xffff)), dmin = h2f((uint16_t)(w.hd.x >> 16));
@@ -792,6 +846,12 @@ extern "C" hipError_t lfamd_launch_gemm_wide_multi(int Atype, int count, const v
                                                                 (const _Float16 *)Xm, n, n_pad, n_rb, n_ct, ks, nbs);
     else if (Atype == LFAMD_TYPE_Q3_K)
         gemm_wide_kernel<LFAMD_TYPE_Q3_K><<<n_wg, 512, 0, s>>>(mats, nb, (const _Float16 *)Xh, (const float *)d8T,
+                                                                (const _Float16 *)Xm, n, n_pad, n_rb, n_ct, ks, nbs);
+    else if (Atype == LFAMD_TYPE_F16)
+        gemm_wide_kernel<LFAMD_TYPE_F16><<<n_wg, 512, 0, s>>>(mats, nb, (const _Float16 *)Xh, (const float *)d8T,
+                                                               (const _Float16 *)Xm, n, n_pad, n_rb, n_ct, ks, nbs);
+    else if (Atype == LFAMD_TYPE_BF16)
+        gemm_wide_kernel<LFAMD_TYPE_BF16><<<n_wg, 512, 0, s>>>(mats, nb, (const _Float16 *)Xh, (const float *)d8T,
                                                                 (const _Float16 *)Xm, n, n_pad, n_rb, n_ct, ks, nbs);
     else if (Atype == LFAMD_TYPE_IQ4_XS)
         gemm_wide_kernel<LFAMD_TYPE_IQ4_XS><<<n_wg, 512, 0, s>>>(mats, nb, (const _Float16 *)Xh, (const float *)d8T,

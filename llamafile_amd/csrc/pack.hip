@@ -474,6 +474,41 @@ __global__ __launch_bounds__(256) void prep80_kernel(const uint8_t *__restrict__
     }
 }
 
+// Activation preparation for the float weight types (F16 / BF16): Xh [nb][n_pad][256] of 2-byte values — f32 rows
+// converted like ggml does before calling sgemm (f16: round to nearest even; bf16: ggml_compute_fp32_to_bf16, nearest even
+// with NaN quieting) or rows already in the weight's type copied.  One wave per (super-block, token).
+template <int OUT, bool F32IN>
+__global__ __launch_bounds__(256) void prep_float_kernel(const uint8_t *__restrict__ X, size_t x_row_bytes, long n, long n_pad,
+                                                        int nb, uint16_t *__restrict__ Xh) {
+    long blk = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (blk >= (long)nb * n_pad)
+        return;
+    int b = (int)(blk / n_pad);
+    long tok = blk - (long)b * n_pad;
+    int t = threadIdx.x & 63;
+    uint16_t o[4] = {0, 0, 0, 0};
+    if (tok < n) {
+        if constexpr (F32IN) {
+            const float4 f = *(const float4 *)((const float *)(X + tok * x_row_bytes) + (size_t)b * 256 + 4 * t);
+            const float v[4] = {f.x, f.y, f.z, f.w};
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                if constexpr (OUT == LFAMD_TYPE_F16) {
+                    o[e] = f2h_bits(v[e]);
+                } else {
+                    const uint32_t u = __builtin_bit_cast(uint32_t, v[e]);
+                    o[e] = (u & 0x7fffffffu) > 0x7f800000u ? (uint16_t)((u >> 16) | 64) : (uint16_t)((u + (0x7fffu + ((u >> 16) & 1))) >> 16);
+                }
+            }
+        } else {
+            const uint2 w = *(const uint2 *)(X + tok * x_row_bytes + ((size_t)b * 256 + 4 * t) * 2);
+            o[0] = (uint16_t)w.x, o[1] = (uint16_t)(w.x >> 16), o[2] = (uint16_t)w.y, o[3] = (uint16_t)(w.y >> 16);
+        }
+    }
+    *(uint2 *)(Xh + ((size_t)b * n_pad + tok) * 256 + 4 * t) =
+        make_uint2((uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16));
+}
+
 // ---------------------------------------------------------------------------------------------
 // host-callable launchers (used by api.hip)
 
@@ -566,6 +601,28 @@ hipError_t lfamd_launch_prep80(int Btype, const void *B, size_t b_row_bytes, lon
             prep80_kernel<true, false><<<grid, 256, 0, s>>>(X, b_row_bytes, n, n_pad, nb, (_Float16 *)Xh, (float *)d8T, nullptr);
         else
             prep80_kernel<false, false><<<grid, 256, 0, s>>>(X, b_row_bytes, n, n_pad, nb, (_Float16 *)Xh, (float *)d8T, nullptr);
+    }
+    return hipGetLastError();
+}
+
+hipError_t lfamd_launch_prep_float(int Atype, int Btype, const void *B, size_t b_row_bytes, long n, long n_pad, long cols, void *Xh,
+                                   hipStream_t s) {
+    int nb = (int)(cols / 256);
+    long blocks = n_pad * nb;
+    if (blocks == 0)
+        return hipSuccess;
+    const unsigned grid = (unsigned)((blocks + 3) / 4);
+    const uint8_t *X = (const uint8_t *)B;
+    if (Atype == LFAMD_TYPE_F16) {
+        if (Btype == LFAMD_TYPE_F32)
+            prep_float_kernel<LFAMD_TYPE_F16, true><<<grid, 256, 0, s>>>(X, b_row_bytes, n, n_pad, nb, (uint16_t *)Xh);
+        else
+            prep_float_kernel<LFAMD_TYPE_F16, false><<<grid, 256, 0, s>>>(X, b_row_bytes, n, n_pad, nb, (uint16_t *)Xh);
+    } else {
+        if (Btype == LFAMD_TYPE_F32)
+            prep_float_kernel<LFAMD_TYPE_BF16, true><<<grid, 256, 0, s>>>(X, b_row_bytes, n, n_pad, nb, (uint16_t *)Xh);
+        else
+            prep_float_kernel<LFAMD_TYPE_BF16, false><<<grid, 256, 0, s>>>(X, b_row_bytes, n, n_pad, nb, (uint16_t *)Xh);
     }
     return hipGetLastError();
 }

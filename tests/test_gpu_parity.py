@@ -218,6 +218,31 @@ def test_float_types_vs_oracle(gpu, oracle, ta, tb, shape):
         assert rel_err(C, O) <= 2e-6
 
 
+@pytest.mark.parametrize("ta,tb", [(T.F16, T.F16), (T.F16, T.F32), (T.BF16, T.BF16), (T.BF16, T.F32)], ids=lambda t: T.NAMES[t])
+@pytest.mark.parametrize("shape", [(128, 64, 512), (45, 100, 1024), (200, 130, 768), (33, 9, 256)], ids=str)
+def test_float_types_mfma_gemm(gpu, oracle, ta, tb, shape):
+    """F16 / BF16 weights, batches: MFMA (f16 / bf16 inputs, f32 accumulate) straight on the RAW rows; f32 activations
+    are converted like ggml does before it calls sgemm (f16 RNE; bf16 nearest-even with NaN quieting).  Criterion as
+    above: a double-accumulator GEMM on the converted operands (products are exact in f32 on both sides)."""
+    from llamafile_amd import synth
+    m, n, k = shape
+    A = synth.random_weights(ta, m, k, 91)
+    x = synth.random_activations(n, k, 92)
+    Bsame = synth.quantize_activations(ta, x)  # the activations in the weight's type
+    G = oracle.f64_gemm(ta, A, ta, Bsame, m, n, k)
+    W = gpu.upload_weights(ta, A, m, k)
+    if tb == T.F32:
+        C = gpu.mul_mat(W, torch.from_numpy(x).cuda().view(torch.uint8).view(n, k * 4), T.F32)
+    else:
+        C = gpu.mul_mat(W, torch.from_numpy(Bsame).cuda(), ta)
+    C = C.cpu().numpy()
+    assert not np.isnan(C).any()
+    assert rel_err(C, G) <= 2e-6
+    ok, O = oracle.sgemm(ta, A, ta, Bsame, m, n, k)
+    if ok == 1:
+        assert rel_err(C, O) <= 2e-6
+
+
 def test_experimental_lds3_gemm_variant(gpu, oracle, monkeypatch):
     """The hand-counted three-stage LDS-DMA Q4_K GEMM (LFAMD_GEMM_LDS3=1) stays correct."""
     monkeypatch.setenv("LFAMD_GEMM_LDS3", "1")
