@@ -114,6 +114,25 @@ __device__ static inline half8_t dequant_bytes(uint32_t d0, uint32_t d1, half2_t
     return f.v;
 }
 
+// The four dequantisation constants (S, O = -1024 S, S16 = S/16, O16 = -64 S) of TWO sub-blocks at once, lane-packed:
+// v_perm puts the two scale bytes into f16 slots as 1024 + sc, one packed add removes the 1024, three packed multiplies
+// give the rest: 5 VALU per sub-block pair instead of 12 (the K loop is VALU-issue bound: PMC shows VALU and MFMA
+// cycles adding up rather than overlapping).  Users pick a half with a broadcast shuffle (folded into op_sel).
+struct q4_consts2 {
+    half2_t S, O, S16, O16;
+};
+__device__ static inline q4_consts2 q4_consts_pair(uint32_t word, int byte_lo) { // scales = bytes byte_lo, byte_lo + 1 of word
+    q4_consts2 c;
+    const uint32_t sel = byte_lo == 0 ? 0x04010400u : 0x04030402u; // [b, 0x64, b', 0x64]
+    const half2_t m1024 = {(_Float16)-1024.0f, (_Float16)-1024.0f}, m64 = {(_Float16)-64.0f, (_Float16)-64.0f};
+    const half2_t r16 = {(_Float16)0.0625f, (_Float16)0.0625f};
+    c.S = as_half2(__builtin_amdgcn_perm(0x64646464u, word, sel)) + m1024;
+    c.O = c.S * m1024;
+    c.S16 = c.S * r16;
+    c.O16 = c.S * m64;
+    return c;
+}
+
 __device__ static inline uint32_t opaque_magic() {
     uint32_t magic = 0x64006400u;
     asm volatile("" : "+v"(magic)); // keep it a register value (see dequant_q4)

@@ -466,9 +466,11 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const gemm_mats mats, in
             read_frags(F[0], 0);
 #pragma unroll
             for (int j = 0; j < 8; j++) {
-                const float scf = (float)(((j < 4 ? sc03 : sc47) >> (8 * (j & 3))) & 0xff);
-                const half2_t S = bcast_h2(scf), O = bcast_h2(-1024.0f * scf);
-                const half2_t S16 = bcast_h2(scf * 0.0625f), O16 = bcast_h2(-64.0f * scf);
+                q4_consts2 cp; // constants of sub-blocks j & ~1, j | 1 (recomputed identically for the odd j: CSE'd)
+                cp = q4_consts_pair(j < 4 ? sc03 : sc47, (j & 2) ? 2 : 0);
+                const int hsel = j & 1;
+                const half2_t S = {cp.S[hsel], cp.S[hsel]}, O = {cp.O[hsel], cp.O[hsel]};
+                const half2_t S16 = {cp.S16[hsel], cp.S16[hsel]}, O16 = {cp.O16[hsel], cp.O16[hsel]};
 #pragma unroll
                 for (int e = 0; e < 2; e++) {
                     const int t = 2 * j + e;
