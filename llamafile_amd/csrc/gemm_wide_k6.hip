@@ -1,0 +1,4 @@
+// gemm_wide_k6.hip — instantiations of the 128x128 MFMA body (gemm_wide_impl.h) for one group of weight types
+#include "gemm_wide_impl.h"
+
+WIDE_INSTANTIATE_MOE(q6k, LFAMD_TYPE_Q6_K)

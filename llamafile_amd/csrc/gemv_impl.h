@@ -1,0 +1,1049 @@
+// gemv.hip — wave-reduction GEMV kernels for the batch-1 (decode) case and small batches n <= 8.
+//
+// Replaces the reference's mul_mat_vec_q + quantize_q8_1 pair (ggml-cuda.cu.patch:14428-14575,
+// 15259-15293: 32-wide warps, dp4a with a scalar fallback on gfx950) and follows the CPU
+// path's arithmetic:
+//   Q4_K / Q6_K x Q8_K : mul_mat_qX_K_q8_K_T (iqk_mul_mat.inc:601-643) — exact int8 block dots,
+//                        f32 scales; the -32 offset of Q6_K is folded into a sums term like
+//                        DequantizerQ6K does (iqk_mul_mat.inc:570-599).
+//   Q8_0 x Q8_0        : tinyBLAS_Q0_AVX2::gemm (tinyblas_cpu.h:934-971) BIT-EXACT: 8 f32 lanes per
+//                        output, blocks accumulated sequentially with fma (or Kahan), same hsum tree.
+//
+// Activations may arrive already quantised (the llamafile_sgemm boundary: Btype = Q8_K / Q8_0) or as
+// f32 (the GGML_OP_MUL_MAT boundary): then every work-group quantises the (tiny) activation vector
+// itself in its prologue, bit-identically to quantize_row_q8_K / q8_0, which removes one launch and
+// one HBM round trip per mat-mul.
+//
+// These are HBM-bandwidth kernels: weights stream once from the packed layout with one
+// global_load_dwordx4 per lane (1 KiB per wave instruction) straight into VGPRs — no LDS round
+// trip for the weights (cdna_hip_programming.md §5 "GEMV / M <= 16" row).  The first chunk of
+// weight loads is issued BEFORE the activation staging so HBM latency overlaps it, and the next
+// chunk is always in flight while the current one is consumed.
+#pragma once
+#include "lfamd_device.h"
+#include <stdlib.h>
+
+// LDS image of one Q8_K activation block for the K-quant GEMVs.  A lane = (gsel, h) reads its 64 code
+// bytes (two groups g = 2gsel+gi, four K-steps dd each) with four ds_read_b128, its 8 half-sums with
+// one more, its 4 sub-block sums with a ds_read_b64.
+//   [0,256)    codes: 8-byte groups at position pos = 16 gsel + 8 h + 4 gi + dd
+//   [256,320)  hb  : int16 sum of each 8-byte group, same position order
+//   [320,352)  ps  : int16 sum of K-step pairs (dd = 2e, 2e+1): position 8 gsel + 4 h + 2 gi + e
+//   [352,384)  d   : f32 block scale (Q8_K: one; Q8_0-quantised activations for the legacy 32-block types: eight)
+#define XBLK 384
+#define XBLK_HB 256
+#define XBLK_PS 320
+#define XBLK_D 352
+
+// Within every 8-byte group the codes (y0..y7) are stored as (y0,y4,y1,y5 | y2,y6,y3,y7): the order
+// in which (x & 0x0F0F0F0F) and ((x>>4) & 0x0F0F0F0F) expose the nibbles of a packed K-step dword.
+// grp = (k offset)/8 = 16 gsel + 8 gi + 2 dd + h.  Returns the group's code sum.
+__device__ static inline int put_group(uint8_t *dst, int grp, uint32_t y0, uint32_t y1) {
+    const uint32_t p0 = __builtin_amdgcn_perm(y1, y0, 0x05010400);
+    const uint32_t p1 = __builtin_amdgcn_perm(y1, y0, 0x07030602);
+    const int pos = (grp & 16) | ((grp & 1) << 3) | ((grp & 8) >> 1) | ((grp >> 1) & 3);
+    *(uint2 *)(dst + 8 * pos) = make_uint2(p0, p1);
+    int hs = sdot4(y0, 0x01010101u, 0);
+    hs = sdot4(y1, 0x01010101u, hs);
+    *(int16_t *)(dst + XBLK_HB + 2 * pos) = (int16_t)hs;
+    return hs;
+}
+
+// pair sum of groups grp (dd even) and grp+2 (dd odd), written by the even one
+__device__ static inline void put_pair(uint8_t *dst, int grp, int hs_even_plus_odd) {
+    const int pp = ((grp & 16) >> 1) | ((grp & 1) << 2) | ((grp & 8) >> 2) | ((grp >> 2) & 1);
+    *(int16_t *)(dst + XBLK_PS + 2 * pp) = (int16_t)hs_even_plus_odd;
+}
+
+// already-quantised Q8_K rows (llamafile field order {d, bsums[16], qs[256]}); blockDim % 32 == 0
+__device__ static inline void stage_q8k(uint8_t *lds, const uint8_t *B, size_t b_row_bytes, long col0, int nc, int nb) {
+    const int groups = nc * nb * 32; // 8-byte groups; a block's 32 groups sit in 32 consecutive lanes
+    for (int gidx = threadIdx.x; gidx < groups; gidx += blockDim.x) {
+        int c = gidx / (nb * 32), r = gidx % (nb * 32);
+        int b = r >> 5, grp = r & 31;
+        const uint8_t *y = B + (col0 + c) * b_row_bytes + (size_t)b * 292;
+        const uint32_t *src = (const uint32_t *)(y + 36 + 8 * grp);
+        uint8_t *dst = lds + (size_t)(c * nb + b) * XBLK;
+        const int hs = put_group(dst, grp, src[0], src[1]);
+        const int other = __shfl_xor(hs, 2, 64); // group grp ^ 2: the other K-step of the pair
+        if ((grp & 2) == 0)
+            put_pair(dst, grp, hs + other);
+        if (grp == 0)
+            *(float *)(dst + XBLK_D) = *(const float *)y;
+    }
+}
+
+// f32 rows, quantised here exactly like quantize_row_q8_K (upstream ggml-quants.c; restated in
+// quantize.hip): first index of the largest |x| fixes the sign of iscale = -128/max, codes are
+// nearest_int (round-half-even) clamped at 127, d = 1/iscale.  One "piece" = 16 consecutive floats;
+// 16 consecutive lanes share one 256-block.
+__device__ static inline void quantise_piece_q8k(uint8_t *dst, const float (&v)[16], int l16) {
+    float amax = 0.0f, val = 0.0f;
+    int idx = l16 * 16;
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+        float ax = fabsf(v[e]);
+        if (ax > amax) {
+            amax = ax;
+            val = v[e];
+            idx = l16 * 16 + e;
+        }
+    }
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) {
+        float oa = __shfl_xor(amax, off, 64);
+        int oi = __shfl_xor(idx, off, 64);
+        float ov = __shfl_xor(val, off, 64);
+        if (oa > amax || (oa == amax && oi < idx)) {
+            amax = oa;
+            idx = oi;
+            val = ov;
+        }
+    }
+    uint32_t y[4] = {0, 0, 0, 0};
+    float d = 0.0f;
+    if (amax != 0.0f) {
+        const float iscale = -128.0f / val;
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            int q = (int)rintf(iscale * v[e]);
+            q = q > 127 ? 127 : q;
+            y[e >> 2] |= (uint32_t)(q & 0xff) << (8 * (e & 3));
+        }
+        d = 1.0f / iscale;
+    }
+    // this lane's 16 codes = groups 2*l16 (h = 0) and 2*l16+1 (h = 1) of K-step dd = l16 & 3
+    const int hs0 = put_group(dst, 2 * l16 + 0, y[0], y[1]);
+    const int hs1 = put_group(dst, 2 * l16 + 1, y[2], y[3]);
+    const int o0 = __shfl_xor(hs0, 1, 64), o1 = __shfl_xor(hs1, 1, 64); // K-step dd ^ 1
+    if ((l16 & 1) == 0) {
+        put_pair(dst, 2 * l16 + 0, hs0 + o0);
+        put_pair(dst, 2 * l16 + 1, hs1 + o1);
+    }
+    if (l16 == 0)
+        *(float *)(dst + XBLK_D) = d;
+}
+
+__device__ static inline void load_piece(float (&v)[16], const float *x, int p) {
+    const float4 *src = (const float4 *)(x + (size_t)p * 16);
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        float4 f = src[e];
+        v[4 * e + 0] = f.x, v[4 * e + 1] = f.y, v[4 * e + 2] = f.z, v[4 * e + 3] = f.w;
+    }
+}
+
+__device__ static inline void stage_f32_as_q8k(uint8_t *lds, const uint8_t *X, size_t x_row_bytes, long col0, int nc,
+                                               int nb) {
+    const int pieces = nb * 16;
+    const int l16 = threadIdx.x & 15;
+    for (int c = 0; c < nc; c++) {
+        const float *x = (const float *)(X + (col0 + c) * x_row_bytes);
+        for (int p = threadIdx.x; p < pieces; p += blockDim.x) {
+            float v[16];
+            load_piece(v, x, p);
+            quantise_piece_q8k(lds + (size_t)(c * nb + (p >> 4)) * XBLK, v, l16);
+        }
+    }
+}
+
+// ---- activations of the legacy 32-block weight types (Q4_0 ...): Q8_0 quantisation (d = amax/127 per 32 values,
+// stored as f16; q = roundf(x/d): upstream quantize_row_q8_0), same code / group-sum / pair-sum image, eight scales.
+__device__ static inline void quantise_piece_q80(uint8_t *dst, const float (&v)[16], int l16) {
+    float amax = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 16; e++)
+        amax = fmaxf(amax, fabsf(v[e]));
+    amax = fmaxf(amax, __shfl_xor(amax, 1, 64)); // lanes 2b, 2b+1 hold the two halves of 32-block b
+    const float d = amax / 127.0f;
+    const float id = d != 0.0f ? 1.0f / d : 0.0f;
+    uint32_t y[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+        const int q = (int)roundf(v[e] * id);
+        y[e >> 2] |= (uint32_t)(q & 0xff) << (8 * (e & 3));
+    }
+    const int hs0 = put_group(dst, 2 * l16 + 0, y[0], y[1]);
+    const int hs1 = put_group(dst, 2 * l16 + 1, y[2], y[3]);
+    const int o0 = __shfl_xor(hs0, 1, 64), o1 = __shfl_xor(hs1, 1, 64);
+    if ((l16 & 1) == 0) {
+        put_pair(dst, 2 * l16 + 0, hs0 + o0);
+        put_pair(dst, 2 * l16 + 1, hs1 + o1);
+        *(float *)(dst + XBLK_D + 4 * (l16 >> 1)) = h2f(f2h_bits(d));
+    }
+}
+
+__device__ static inline void stage_f32_as_q80(uint8_t *lds, const uint8_t *X, size_t x_row_bytes, long col0, int nc,
+                                               int nb) {
+    const int pieces = nb * 16;
+    const int l16 = threadIdx.x & 15;
+    for (int c = 0; c < nc; c++) {
+        const float *x = (const float *)(X + (col0 + c) * x_row_bytes);
+        for (int p = threadIdx.x; p < pieces; p += blockDim.x) {
+            float v[16];
+            load_piece(v, x, p);
+            quantise_piece_q80(lds + (size_t)(c * nb + (p >> 4)) * XBLK, v, l16);
+        }
+    }
+}
+
+// already-quantised Q8_0 rows (34-byte blocks): one 8-byte group per lane, 32 consecutive lanes per 256 codes
+__device__ static inline void stage_q80_blocks(uint8_t *lds, const uint8_t *B, size_t b_row_bytes, long col0, int nc, int nb) {
+    const int groups = nc * nb * 32;
+    for (int gidx = threadIdx.x; gidx < groups; gidx += blockDim.x) {
+        int c = gidx / (nb * 32), r = gidx % (nb * 32);
+        int b = r >> 5, grp = r & 31;
+        const uint8_t *blk = B + (col0 + c) * b_row_bytes + (size_t)(b * 8 + (grp >> 2)) * 34;
+        const uint16_t *src = (const uint16_t *)(blk + 2 + 8 * (grp & 3));
+        const uint32_t y0 = (uint32_t)src[0] | ((uint32_t)src[1] << 16), y1 = (uint32_t)src[2] | ((uint32_t)src[3] << 16);
+        uint8_t *dst = lds + (size_t)(c * nb + b) * XBLK;
+        const int hs = put_group(dst, grp, y0, y1);
+        const int other = __shfl_xor(hs, 2, 64);
+        if ((grp & 2) == 0)
+            put_pair(dst, grp, hs + other);
+        if ((grp & 3) == 0)
+            *(float *)(dst + XBLK_D + 4 * (grp >> 2)) = h2f(*(const uint16_t *)blk);
+    }
+}
+
+template <int BT, int ACT>
+__device__ static inline void stage_x(uint8_t *lds, const uint8_t *B, size_t b_row_bytes, long col0, int nc, int nb) {
+    if constexpr (ACT == LFAMD_TYPE_Q8_K) {
+        if constexpr (BT == LFAMD_TYPE_F32)
+            stage_f32_as_q8k(lds, B, b_row_bytes, col0, nc, nb);
+        else
+            stage_q8k(lds, B, b_row_bytes, col0, nc, nb);
+    } else {
+        if constexpr (BT == LFAMD_TYPE_F32)
+            stage_f32_as_q80(lds, B, b_row_bytes, col0, nc, nb);
+        else
+            stage_q80_blocks(lds, B, b_row_bytes, col0, nc, nb);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K-quant GEMV skeleton.  PERSISTENT work-groups: the grid is sized to about two work-groups per CU and
+// each work-group walks half-tiles (16 weight rows) ht = blockIdx.x, +gridDim.x, ...  The activation
+// vector is quantised / staged ONCE per work-group and reused for all its tiles, and the weight
+// stream is software-pipelined across tiles: the loads of work item f+1 are issued before item f is
+// consumed, so every wave keeps 12+ KiB of HBM reads in flight for its whole life.
+//   work item = (tile, chunk of GEMV_CH super-blocks of this wave); wave w owns super-blocks w, w+NW, ...
+//   NW = 16 waves for a single activation row: a k = 4096 row (16 super-blocks) then costs each wave ONE
+//   super-block per tile, so the integer-dot phase that follows the arrival of the data is as short as it
+//   can be; unused chunk slots are never touched, so the register allocator drops them.
+//   lane = (i16 = lane&15, h = (lane>>4)&1, gsel = lane>>5) covers groups g = 2*gsel + gi (gi = 0,1).
+
+#define GEMV_CH_MAX 4
+
+struct q4k_traits {
+    static constexpr int ACT = LFAMD_TYPE_Q8_K; // activation quantisation the reference uses for this type
+    static constexpr int TILE = P4K_TILE;
+    struct chunk {
+        uint4 q0[GEMV_CH_MAX], q1[GEMV_CH_MAX], hd[GEMV_CH_MAX];
+    };
+    // `off` = byte offset of the super-block's tile inside the row-tile the descriptor covers
+    __device__ static inline void load(chunk &ch, int s, lfamd_rsrc r, uint32_t off, int gsel, int slot, int hrow) {
+        ch.q0[s] = buf_ld16_nt(r, off + (2 * gsel + 0) * 1024 + slot * 16);
+        ch.q1[s] = buf_ld16_nt(r, off + (2 * gsel + 1) * 1024 + slot * 16);
+        ch.hd[s] = buf_ld16_nt(r, off + P4K_HDR + hrow * 16);
+    }
+    // one super-block of this lane against one staged activation block; returns the f32 contribution
+    __device__ static inline float dot(const chunk &ch, int s, const uint8_t *xb, int gsel, int h) {
+        const uint4 q0 = ch.q0[s], q1 = ch.q1[s], hd = ch.hd[s];
+        const float d = h2f((uint16_t)(hd.x & 0xffff)), dmin = h2f((uint16_t)(hd.x >> 16));
+        uint32_t sc03, sc47, mn03, mn47;
+        q4k_scales_bytes(hd.y, hd.z, hd.w, sc03, sc47, mn03, mn47);
+        // this lane's four sub-blocks: j = 2g + e, g = 2*gsel + gi  ->  j = 4*gsel + 2*gi + e
+        const uint32_t scw = gsel ? sc47 : sc03, mnw = gsel ? mn47 : mn03;
+        const uint32_t qw[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+        const uint4 *yq = (const uint4 *)(xb + 128 * gsel + 64 * h);
+        const uint4 ya = yq[0], yb = yq[1], yc = yq[2], yd = yq[3];
+        const uint32_t yw[16] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w,
+                                 yc.x, yc.y, yc.z, yc.w, yd.x, yd.y, yd.z, yd.w};
+        const uint2 psw = *(const uint2 *)(xb + XBLK_PS + 16 * gsel + 8 * h);
+        const int ps[4] = {(int)(int16_t)(psw.x & 0xffff), (int)(int16_t)(psw.x >> 16), (int)(int16_t)(psw.y & 0xffff),
+                           (int)(int16_t)(psw.y >> 16)};
+        int sumi = 0, summ = 0;
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) { // jj = 2 gi + e
+            int isum = 0;
+#pragma unroll
+            for (int d2 = 0; d2 < 2; d2++) {
+                const int t8 = 2 * jj + d2; // = 4 gi + dd
+                const uint32_t x = qw[t8];
+                isum = sdot4(x & 0x0F0F0F0F, yw[2 * t8], isum);
+                isum = sdot4((x >> 4) & 0x0F0F0F0F, yw[2 * t8 + 1], isum);
+            }
+            sumi += (int)((scw >> (8 * jj)) & 0xff) * isum;
+            summ += (int)((mnw >> (8 * jj)) & 0xff) * ps[jj];
+        }
+        const float d8 = *(const float *)(xb + XBLK_D);
+        // d*d8*sumi - dmin*d8*summ  (iqk_mul_mat.inc:284-291, 632)
+        return fmaf(d * d8, (float)sumi, -(dmin * d8) * (float)summ);
+    }
+};
+
+// Q4_0 (legacy 32-blocks, activations Q8_0; mul_mat_qX_0_q8_0_T, iqk_mul_mat.inc:998-1349): the P4K nibble image with
+// eight f16 block scales per row as header; w = d*(q - 8).  Per 32-block: d*d8*(<q, q8> - 8*sum(q8)), the sum taken
+// from the staged pair sums like the Q4_K mins.
+struct q40_traits {
+    static constexpr int ACT = LFAMD_TYPE_Q8_0;
+    static constexpr int TILE = P4K_TILE;
+    struct chunk {
+        uint4 q0[GEMV_CH_MAX], q1[GEMV_CH_MAX];
+        uint2 hd[GEMV_CH_MAX];
+    };
+    __device__ static inline void load(chunk &ch, int s, lfamd_rsrc r, uint32_t off, int gsel, int slot, int hrow) {
+        ch.q0[s] = buf_ld16_nt(r, off + (2 * gsel + 0) * 1024 + slot * 16);
+        ch.q1[s] = buf_ld16_nt(r, off + (2 * gsel + 1) * 1024 + slot * 16);
+        ch.hd[s] = buf_ld8(r, off + P4K_HDR + hrow * 16 + gsel * 8); // scales of blocks 4 gsel .. 4 gsel + 3
+    }
+    __device__ static inline float dot(const chunk &ch, int s, const uint8_t *xb, int gsel, int h) {
+        const uint4 q0 = ch.q0[s], q1 = ch.q1[s];
+        const uint2 hd = ch.hd[s];
+        const uint32_t qw[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+        const uint4 *yq = (const uint4 *)(xb + 128 * gsel + 64 * h);
+        const uint4 ya = yq[0], yb = yq[1], yc = yq[2], yd = yq[3];
+        const uint32_t yw[16] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w,
+                                 yc.x, yc.y, yc.z, yc.w, yd.x, yd.y, yd.z, yd.w};
+        const uint2 psw = *(const uint2 *)(xb + XBLK_PS + 16 * gsel + 8 * h);
+        const int ps[4] = {(int)(int16_t)(psw.x & 0xffff), (int)(int16_t)(psw.x >> 16), (int)(int16_t)(psw.y & 0xffff),
+                           (int)(int16_t)(psw.y >> 16)};
+        const float4 d8 = *(const float4 *)(xb + XBLK_D + 16 * gsel);
+        const float d8v[4] = {d8.x, d8.y, d8.z, d8.w};
+        float acc = 0.0f;
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) { // block 4 gsel + jj
+            int isum = 0;
+#pragma unroll
+            for (int d2 = 0; d2 < 2; d2++) {
+                const int t8 = 2 * jj + d2;
+                const uint32_t x = qw[t8];
+                isum = sdot4(x & 0x0F0F0F0F, yw[2 * t8], isum);
+                isum = sdot4((x >> 4) & 0x0F0F0F0F, yw[2 * t8 + 1], isum);
+            }
+            const uint32_t dw = jj < 2 ? hd.x : hd.y;
+            const float d = h2f((uint16_t)((jj & 1) ? (dw >> 16) : (dw & 0xffff)));
+            acc = fmaf(d * d8v[jj], (float)(isum - 8 * ps[jj]), acc);
+        }
+        return acc;
+    }
+};
+
+// Q5_K: Q4_K with a fifth bit per weight (DequantizerQ5K, iqk_mul_mat.inc:496-511): codes 0..31, same scales / mins.
+struct q5k_traits {
+    static constexpr int ACT = LFAMD_TYPE_Q8_K; // activation quantisation the reference uses for this type
+    static constexpr int TILE = P5K_TILE;
+    struct chunk {
+        uint4 q0[GEMV_CH_MAX], q1[GEMV_CH_MAX], hd[GEMV_CH_MAX];
+        uint2 hq[GEMV_CH_MAX];
+    };
+    __device__ static inline void load(chunk &ch, int s, lfamd_rsrc r, uint32_t off, int gsel, int slot, int hrow) {
+        ch.q0[s] = buf_ld16_nt(r, off + (2 * gsel + 0) * 1024 + slot * 16);
+        ch.q1[s] = buf_ld16_nt(r, off + (2 * gsel + 1) * 1024 + slot * 16);
+        ch.hd[s] = buf_ld16_nt(r, off + P5K_HDR + hrow * 16);
+        ch.hq[s] = buf_ld8(r, off + P5K_QH + slot * 16 + gsel * 8); // fifth bits of groups 2 gsel, 2 gsel + 1
+    }
+    __device__ static inline float dot(const chunk &ch, int s, const uint8_t *xb, int gsel, int h) {
+        const uint4 q0 = ch.q0[s], q1 = ch.q1[s], hd = ch.hd[s];
+        const uint32_t hw[2] = {ch.hq[s].x, ch.hq[s].y};
+        const float d = h2f((uint16_t)(hd.x & 0xffff)), dmin = h2f((uint16_t)(hd.x >> 16));
+        uint32_t sc03, sc47, mn03, mn47;
+        q4k_scales_bytes(hd.y, hd.z, hd.w, sc03, sc47, mn03, mn47);
+        const uint32_t scw = gsel ? sc47 : sc03, mnw = gsel ? mn47 : mn03;
+        const uint32_t qw[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+        const uint4 *yq = (const uint4 *)(xb + 128 * gsel + 64 * h);
+        const uint4 ya = yq[0], yb = yq[1], yc = yq[2], yd = yq[3];
+        const uint32_t yw[16] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w,
+                                 yc.x, yc.y, yc.z, yc.w, yd.x, yd.y, yd.z, yd.w};
+        const uint2 psw = *(const uint2 *)(xb + XBLK_PS + 16 * gsel + 8 * h);
+        const int ps[4] = {(int)(int16_t)(psw.x & 0xffff), (int)(int16_t)(psw.x >> 16), (int)(int16_t)(psw.y & 0xffff),
+                           (int)(int16_t)(psw.y >> 16)};
+        int sumi = 0, summ = 0;
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) { // jj = 2 gi + e
+            int isum = 0;
+#pragma unroll
+            for (int d2 = 0; d2 < 2; d2++) {
+                const int t8 = 2 * jj + d2; // = 4 gi + dd
+                const uint32_t x = qw[t8];
+                const uint32_t Hd = hw[t8 >> 2] >> (t8 & 3);
+                const uint32_t c0 = (x & 0x0F0F0F0F) | (Hd & 0x10101010);
+                const uint32_t c1 = ((x >> 4) & 0x0F0F0F0F) | ((Hd >> 4) & 0x00100010) | ((Hd << 12) & 0x10001000);
+                isum = sdot4(c0, yw[2 * t8], isum);
+                isum = sdot4(c1, yw[2 * t8 + 1], isum);
+            }
+            sumi += (int)((scw >> (8 * jj)) & 0xff) * isum;
+            summ += (int)((mnw >> (8 * jj)) & 0xff) * ps[jj];
+        }
+        const float d8 = *(const float *)(xb + XBLK_D);
+        return fmaf(d * d8, (float)sumi, -(dmin * d8) * (float)summ);
+    }
+};
+
+// Q6_K: sub-blocks are 16 wide (one per K-step), codes are 6 bit, offset -32 handled as
+// sum sc*(dot(code,q8) - 32*sum(q8)) like DequantizerQ6K (iqk_mul_mat.inc:570-599).
+struct q6k_traits {
+    static constexpr int ACT = LFAMD_TYPE_Q8_K; // activation quantisation the reference uses for this type
+    static constexpr int TILE = P6K_TILE;
+    struct chunk {
+        uint4 l0[GEMV_CH_MAX], l1[GEMV_CH_MAX], hq[GEMV_CH_MAX];
+        uint2 sc[GEMV_CH_MAX];
+        uint32_t d[GEMV_CH_MAX];
+    };
+    __device__ static inline void load(chunk &ch, int s, lfamd_rsrc r, uint32_t off, int gsel, int slot, int hrow) {
+        ch.l0[s] = buf_ld16_nt(r, off + (2 * gsel + 0) * 1024 + slot * 16);
+        ch.l1[s] = buf_ld16_nt(r, off + (2 * gsel + 1) * 1024 + slot * 16);
+        ch.hq[s] = buf_ld16_nt(r, off + P6K_QH + gsel * 1024 + slot * 16);
+        ch.sc[s] = buf_ld8(r, off + P6K_SC + hrow * 16 + gsel * 8); // scales of K-steps 8*gsel..+7
+        ch.d[s] = buf_ld2(r, off + P6K_D + hrow * 2);
+    }
+    __device__ static inline float dot(const chunk &ch, int s, const uint8_t *xb, int gsel, int h) {
+        const uint4 l0 = ch.l0[s], l1 = ch.l1[s], hq = ch.hq[s];
+        const uint2 scb = ch.sc[s];
+        const float d = h2f((uint16_t)ch.d[s]);
+        const uint32_t lw[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+        const uint32_t hw[4] = {hq.x, hq.y, hq.z, hq.w}; // [gi*2 + e]
+        const uint4 *yq = (const uint4 *)(xb + 128 * gsel + 64 * h);
+        const uint4 ya = yq[0], yb = yq[1], yc = yq[2], yd = yq[3];
+        const uint32_t yw[16] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w,
+                                 yc.x, yc.y, yc.z, yc.w, yd.x, yd.y, yd.z, yd.w};
+        const uint4 hbw = *(const uint4 *)(xb + XBLK_HB + 32 * gsel + 16 * h);
+        const uint32_t hbv[4] = {hbw.x, hbw.y, hbw.z, hbw.w};
+        int sumi = 0;
+#pragma unroll
+        for (int t8 = 0; t8 < 8; t8++) { // t8 = 4 gi + dd
+            const uint32_t x = lw[t8];
+            uint32_t H = hw[t8 >> 1];
+            if (t8 & 1)
+                H >>= 2;
+            // lo bytes (j0,j4,j1,j5): high fields at bits 4-5 of each byte already
+            const uint32_t clo = (x & 0x0F0F0F0F) | (H & 0x30303030);
+            // hi bytes (j2,j6,j3,j7): fields at bits 8-9 / 0-1 / 24-25 / 16-17
+            const uint32_t chi = ((x >> 4) & 0x0F0F0F0F) | ((H >> 4) & 0x00300030) | ((H << 12) & 0x30003000);
+            int isum = sdot4(clo, yw[2 * t8], 0);
+            isum = sdot4(chi, yw[2 * t8 + 1], isum);
+            const int hs = (int)(int16_t)((hbv[t8 >> 1] >> (16 * (t8 & 1))) & 0xffff);
+            const int sc = (int)(int8_t)(((t8 < 4 ? scb.x : scb.y) >> (8 * (t8 & 3))) & 0xff);
+            sumi += sc * (isum - 32 * hs);
+        }
+        const float d8 = *(const float *)(xb + XBLK_D);
+        return (d * d8) * (float)sumi;
+    }
+};
+
+// Up to GEMV_MAX_MATS weight matrices of one type and row length that consume the SAME activations
+// (attn_q/k/v, ffn_gate/up) are served by one launch: their half-tiles are concatenated.
+#define GEMV_MAX_MATS 4
+struct gemv_mats {
+    const uint8_t *A[GEMV_MAX_MATS];
+    float *C[GEMV_MAX_MATS];
+    long m[GEMV_MAX_MATS];
+    long ldc[GEMV_MAX_MATS];
+    int ht_end[GEMV_MAX_MATS]; // exclusive prefix of half-tile counts
+    int count;
+    // GGML_OP_MUL_MAT_ID at decode (IDS kernels only): matrix j is expert ids[id_idx[j]] of the stack at A[j]
+    const int32_t *ids;
+    long expert_bytes;
+    int id_idx[GEMV_MAX_MATS];
+    int experts;
+};
+
+#ifndef GEMV_DIAG
+#define GEMV_DIAG 0
+#endif
+#if GEMV_DIAG // development: in-kernel s_memtime stamps of two work-groups (never in the product build)
+static __device__ unsigned long long g_gemv_stamps[4 * 16 * 16];
+extern "C" __attribute__((weak)) int lfamd_debug_gemv_stamps(unsigned long long *dst) { // per TU; dev only
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_gemv_stamps), sizeof(g_gemv_stamps));
+}
+#define GSTAMP()                                                                                                 \
+    do {                                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                       \
+        if ((blockIdx.x == 0 || blockIdx.x == 100) && lane == 0 && stamp_n < 16)                                  \
+            g_gemv_stamps[((blockIdx.x ? 1 : 0) * 16 + wave) * 16 + stamp_n++] = __builtin_amdgcn_s_memrealtime(); \
+        __builtin_amdgcn_sched_barrier(0);                                                                       \
+    } while (0)
+#else
+#define GSTAMP()
+#endif
+
+template <typename TR, int NC, int BT, int NW, int GEMV_CH, bool IDS = false>
+__global__ __launch_bounds__(NW * 64) void gemv_kq_kernel(const gemv_mats mats, int nb, const uint8_t *__restrict__ B,
+                                                          size_t b_row_bytes, long col0, int n_ht) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i16 = lane & 15, h = (lane >> 4) & 1, gsel = lane >> 5;
+    float *red = (float *)(lds + (size_t)NC * nb * XBLK); // [2][NW][NC][16]
+#if GEMV_DIAG
+    int stamp_n = 0;
+#endif
+    GSTAMP();
+
+    const int sb_per_wave = (nb + NW - 1) / NW;
+    const int cpt = (sb_per_wave + GEMV_CH - 1) / GEMV_CH; // chunks per tile
+    const int ntile = (n_ht - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int total = ntile * cpt;
+
+    // Loads are issued UNCONDITIONALLY through a bounds-checked buffer descriptor: a branch around a load
+    // makes hipcc fall back to s_waitcnt vmcnt(0) (the prefetch of the next item is lost), whereas a
+    // descriptor with zero records ("no item f") or an offset past the row-tile ("no super-block b")
+    // returns zeros without touching memory and keeps the counted waits exact.
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const uint32_t rt_bytes = (uint32_t)nb * TR::TILE;
+    auto issue = [&](typename TR::chunk &ch, int f) {
+        const int tile_i = f / cpt, chunk_i = f - tile_i * cpt;
+        long ht = (long)blockIdx.x + (long)tile_i * gridDim.x;
+        int j = 0;
+#pragma unroll
+        for (int jj = 1; jj < GEMV_MAX_MATS; jj++)
+            if (jj < mats.count && ht >= mats.ht_end[jj - 1])
+                j = jj;
+        const uint8_t *A = mats.A[j];
+        bool have = f < total;
+        if constexpr (IDS) { // expert picked on the device: no routing-table read-back, graph-capturable
+            const int ex = mats.ids[mats.id_idx[j]];
+            const bool ok = ex >= 0 && ex < mats.experts;
+            A += (size_t)(ok ? ex : 0) * mats.expert_bytes;
+            have = have && ok;
+        }
+        if (j > 0)
+            ht -= mats.ht_end[j - 1];
+        const int hh = (int)(ht & 1);
+        const lfamd_rsrc r = make_rsrc(A + (size_t)(ht >> 1) * rt_bytes, have ? rt_bytes : 0u);
+        const int slot = h * 32 + hh * 16 + i16, hrow = hh * 16 + i16;
+#pragma unroll
+        for (int s = 0; s < GEMV_CH; s++) {
+            const int b = wave_u + NW * (chunk_i * GEMV_CH + s); // b >= nb lands past the descriptor: zeros
+            TR::load(ch, s, r, (uint32_t)b * TR::TILE, gsel, slot, hrow);
+        }
+    };
+
+    float acc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++)
+        acc[c] = 0.0f;
+
+    auto consume = [&](const typename TR::chunk &ch, int f) {
+        const int tile_i = f / cpt, chunk_i = f - tile_i * cpt;
+#pragma unroll
+        for (int s = 0; s < GEMV_CH; s++) {
+            const int b = wave + NW * (chunk_i * GEMV_CH + s);
+            const int bc = b < nb ? b : nb - 1;
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                // a super-block beyond the row was loaded as zeros (d = 0): contributes exactly 0
+                acc[c] += TR::dot(ch, s, lds + (size_t)(c * nb + bc) * XBLK, gsel, h);
+            }
+        }
+        if (chunk_i == cpt - 1) { // tile finished: 4 lanes per row (h, gsel), then the waves through LDS
+            float *rb = red + (tile_i & 1) * (NW * NC * 16);
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                float v = acc[c];
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 32, 64);
+                if (lane < 16)
+                    rb[(wave * NC + c) * 16 + lane] = v;
+                acc[c] = 0.0f;
+            }
+            GSTAMP();
+            __syncthreads();
+            GSTAMP();
+            if (threadIdx.x < 16 * NC) {
+                const int c = threadIdx.x >> 4, i = threadIdx.x & 15;
+                float v = 0.0f;
+#pragma unroll
+                for (int w = 0; w < NW; w++)
+                    v += rb[(w * NC + c) * 16 + i];
+                long ht = (long)blockIdx.x + (long)tile_i * gridDim.x;
+                int j = 0;
+#pragma unroll
+                for (int jj = 1; jj < GEMV_MAX_MATS; jj++)
+                    if (jj < mats.count && ht >= mats.ht_end[jj - 1])
+                        j = jj;
+                if (j > 0)
+                    ht -= mats.ht_end[j - 1];
+                const long row = (ht >> 1) * 32 + (ht & 1) * 16 + i;
+                bool ok = true;
+                if constexpr (IDS) { // an out-of-range expert id leaves its result row untouched (the host path skips it)
+                    const int ex = mats.ids[mats.id_idx[j]];
+                    ok = ex >= 0 && ex < mats.experts;
+                }
+                if (row < mats.m[j] && ok)
+                    mats.C[j][(col0 + c) * mats.ldc[j] + row] = v;
+            }
+        }
+    };
+
+    typename TR::chunk bufA, bufB;
+    if (total <= 0)
+        return; // (whole work-group: total is uniform)
+    // vmcnt retires in order: whatever is loaded first is waited for first.  In the decode case (one f32
+    // row, at most one piece per thread) fetch the activations BEFORE the first weight chunk, so the
+    // quantisation below only waits for them and the weights keep flying.
+    if (BT == LFAMD_TYPE_F32 && NC == 1 && nb * 16 <= NW * 64) {
+        float v[16];
+        const bool mine = (int)threadIdx.x < nb * 16;
+        if (mine)
+            load_piece(v, (const float *)(B + col0 * b_row_bytes), threadIdx.x);
+        issue(bufA, 0);
+        GSTAMP();
+        if (mine) {
+            if constexpr (TR::ACT == LFAMD_TYPE_Q8_K)
+                quantise_piece_q8k(lds + (size_t)(threadIdx.x >> 4) * XBLK, v, threadIdx.x & 15);
+            else
+                quantise_piece_q80(lds + (size_t)(threadIdx.x >> 4) * XBLK, v, threadIdx.x & 15);
+        }
+        GSTAMP();
+    } else {
+        issue(bufA, 0); // in flight during the staging below
+        stage_x<BT, TR::ACT>(lds, B, b_row_bytes, col0, NC, nb);
+    }
+    __syncthreads();
+    GSTAMP();
+
+    // (issuing bufB before the staging as well, and re-issuing each buffer right after its consume, measured
+    // 10-25 % SLOWER on every decode shape: the counted waits degrade and the activation loads queue behind more
+    // weight traffic)
+    for (int f = 0; f < total; f += 2) {
+        issue(bufB, f + 1);
+        consume(bufA, f);
+        GSTAMP();
+        issue(bufA, f + 2);
+        if (f + 1 < total)
+            consume(bufB, f + 1);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Q8_0 x Q8_0, bit-exact restatement of tinyBLAS_Q0_AVX2::gemm (tinyblas_cpu.h:934-971).
+// One wave = 8 weight rows, lane = (r = lane>>3, j = lane&7) owns f32 lane j of row r's accumulator
+// Cv; blocks are visited in order l = 0..nblocks-1 exactly like the reference's loop, so every
+// rounding is the same:  a = f32(dA)*f32(dB);  b = f32(int dot of bytes 4j..4j+3);
+// Cv = fma(a, b, Cv)   or, on a PRECISE tile, madder (tinyblas_cpu.h:203-209) with the compiler's
+// contraction of sub(mul(a,b),e) into fma(a,b,-e).
+
+// LDS image of the Q8_0 activations, per QUAD of four 32-blocks (the unit a weight tile covers): for each of the
+// eight dword positions j the four blocks' dwords side by side (a lane = (row r, position j) takes its four
+// activation dwords with ONE ds_read_b128; the eight rows of a wave read the same 128 bytes: broadcast), then the
+// four block scales as f32 (one more ds_read_b128, uniform).  8 ds_read_b32 per quad became 2 ds_read_b128.
+#define X80_QUAD 144
+#define X80_QD 128
+// quads (1 KiB per wave each) kept in flight per wave: the row's blocks MUST be visited in order by one lane
+// (bit-exact f32 chain), so a matrix offers only m/8 waves (2 per CU at m = 4096) and memory-level parallelism
+// has to come from depth.  n = 1: 32 (a whole k = 4096 row group in flight, 192 ring VGPRs); batches: 16.
+#define Q80_WAVES 2  // waves per work-group (8 rows each) sharing one staged activation image
+
+// MODE: 0 = every output plain fma, 1 = every output Kahan (uniform for n = 1: tinyblas_cpu.h:797-925),
+// 2 = per-output choice from the mnpack geometry (small batches n > 1)
+// sibling matrices that share the activations (attn_q/k/v, ffn_gate/up) run as ONE launch over their concatenated
+// 8-row groups: a 1024-row matrix alone is 128 waves, each a serial k-long chain — three such launches cost three times
+// the chain latency, one launch costs it once.  The mnpack geometry (Kahan choice) stays per matrix.
+struct q80_mats {
+    const uint8_t *A[GEMV_MAX_MATS];
+    float *C[GEMV_MAX_MATS];
+    long m[GEMV_MAX_MATS];
+    long ldc[GEMV_MAX_MATS];
+    long rg_end[GEMV_MAX_MATS]; // exclusive prefix of row-group counts
+    int count;
+};
+
+template <int NC, int BT, int MODE, int Q80_DEPTH>
+__global__ __launch_bounds__(Q80_WAVES * 64) void gemv_q80_kernel(const q80_mats mats, long n_total, int nblocks, int nquads,
+                                                                 const uint8_t *__restrict__ B, size_t b_row_bytes, long col0,
+                                                                 int vregs32, int precise) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane >> 3, j = lane & 7;
+#if GEMV_DIAG
+    int stamp_n = 0;
+#endif
+    GSTAMP();
+    long rg = (long)blockIdx.x * Q80_WAVES + wave;
+    int mj = 0;
+#pragma unroll
+    for (int jj = 1; jj < GEMV_MAX_MATS; jj++)
+        if (jj < mats.count && rg >= mats.rg_end[jj - 1])
+            mj = jj;
+    if (mj > 0)
+        rg -= mats.rg_end[mj - 1];
+    const uint8_t *__restrict__ A = mats.A[mj];
+    float *__restrict__ C = mats.C[mj];
+    const long m = mats.m[mj], ldc = mats.ldc[mj];
+    const long n_rg = (m + 7) / 8;
+    const long row = rg * 8 + r;
+    // bounds-checked, unconditional weight loads (zeros past the row group / for an idle wave): keeps
+    // hipcc's counted vmcnt exact so Q80_DEPTH KiB per wave really stay in flight
+    const uint32_t rg_bytes = (uint32_t)nquads * P80_TILE;
+    const lfamd_rsrc rA = make_rsrc(A + (size_t)(rg < n_rg ? rg : 0) * rg_bytes, rg < n_rg ? rg_bytes : 0u);
+
+    uint4 qa[Q80_DEPTH];
+    uint2 ds[Q80_DEPTH];
+    auto issue = [&](int s, int L) {
+        qa[s] = buf_ld16_nt(rA, (uint32_t)L * P80_TILE + lane * 16);
+        ds[s] = buf_ld8(rA, (uint32_t)L * P80_TILE + P80_D + r * 8);
+    };
+
+    if constexpr (BT == LFAMD_TYPE_F32) {
+        // quantize_row_q8_0 (upstream): d = amax/127, id = 1/d, q = roundf(x*id); 16 floats per lane,
+        // two lanes per 32-block.  The first piece of each thread is fetched BEFORE the weights (vmcnt
+        // retires in order), the weights are issued, then the activations are quantised under their flight.
+        const int pieces = nblocks * 2, nthr = Q80_WAVES * 64;
+        for (int c = 0; c < NC; c++) {
+            const float *x = (const float *)(B + (col0 + c) * b_row_bytes);
+            // two pieces per thread and round: both loads go out together (one memory latency per round, not two)
+            for (int p0 = 0; p0 < pieces; p0 += 2 * nthr) {
+                const int pa = p0 + threadIdx.x, pb = pa + nthr;
+                float va[16], vb[16];
+                if (pa < pieces)
+                    load_piece(va, x, pa);
+                if (pb < pieces)
+                    load_piece(vb, x, pb);
+                if (c == 0 && p0 == 0) {
+#pragma unroll
+                    for (int s = 0; s < Q80_DEPTH; s++)
+                        issue(s, s);
+                }
+                auto quantise = [&](const float (&v)[16], int p) {
+                    float amax = 0.0f;
+#pragma unroll
+                    for (int e = 0; e < 16; e++)
+                        amax = fmaxf(amax, fabsf(v[e]));
+                    amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+                    const float d = amax / 127.0f;
+                    const float id = d != 0.0f ? 1.0f / d : 0.0f;
+                    uint32_t y[4] = {0, 0, 0, 0};
+#pragma unroll
+                    for (int e = 0; e < 16; e++) {
+                        int q = (int)roundf(v[e] * id);
+                        y[e >> 2] |= (uint32_t)(q & 0xff) << (8 * (e & 3));
+                    }
+                    const int l = p >> 1, hf = p & 1;
+                    uint8_t *dst = lds + (size_t)(c * nquads + (l >> 2)) * X80_QUAD + (l & 3) * 4;
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        *(uint32_t *)(dst + (4 * hf + e) * 16) = y[e];
+                    if (hf == 0)
+                        *(float *)(dst + X80_QD) = h2f(f2h_bits(d)); // the block stores d as f16
+                };
+                // (pieces is even and nthr a multiple of 64: the lane pair (2i, 2i+1) of a block is either both in or out)
+                if (pa < pieces)
+                    quantise(va, pa);
+                if (pb < pieces)
+                    quantise(vb, pb);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < Q80_DEPTH; s++)
+            issue(s, s);
+        for (int idx = threadIdx.x; idx < NC * nblocks * 9; idx += Q80_WAVES * 64) {
+            int c = idx / (nblocks * 9), rem = idx % (nblocks * 9);
+            int l = rem / 9, w = rem % 9;
+            const uint8_t *y = B + (col0 + c) * b_row_bytes + (size_t)l * 34;
+            uint32_t v;
+            if (w < 8) {
+                const uint16_t *p = (const uint16_t *)(y + 2 + 4 * w); // 34-byte blocks: 2-byte aligned
+                v = (uint32_t)p[0] | ((uint32_t)p[1] << 16);
+            } else {
+                v = __builtin_bit_cast(uint32_t, h2f(*(const uint16_t *)y));
+            }
+            *(uint32_t *)(lds + (size_t)(c * nquads + (l >> 2)) * X80_QUAD + (l & 3) * 4 + (w < 8 ? w * 16 : X80_QD)) = v;
+        }
+    }
+    GSTAMP();
+    __syncthreads();
+    GSTAMP();
+
+    bool kahan[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++)
+        kahan[c] = MODE == 2 ? q0_is_kahan(row < m ? row : m - 1, col0 + c, m, n_total, vregs32 != 0, precise != 0) : MODE == 1;
+
+    float Cv[NC], Ce[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++)
+        Cv[c] = Ce[c] = 0.0f;
+
+    // One block: a = f32(dA)*f32(dB), b = f32(int dot of bytes 4j..4j+3), then the reference's update.  The update is a
+    // chain of dependent f32 ops (four per block under Kahan) that ONE lane must run in block order; everything else
+    // (scale products, integer dots) is independent of it.  A row offers a single wave no other work, so the loop is
+    // software-pipelined by hand: the products of quad L+1 are prepared (prep) before the chain of quad L runs and
+    // fill its latency bubbles (measured: the fused form spent ~80 cycles per block, 4-5 us per k = 4096 row).
+    struct prepd {
+        float a[4][NC], b[4][NC];
+    };
+    auto prep = [&](int sl, int L, prepd &P) {
+        const uint4 q4 = qa[sl];
+        const uint2 d2 = ds[sl];
+        const uint32_t qw[4] = {q4.x, q4.y, q4.z, q4.w};
+        const float da[4] = {h2f((uint16_t)(d2.x & 0xffff)), h2f((uint16_t)(d2.x >> 16)), h2f((uint16_t)(d2.y & 0xffff)),
+                             h2f((uint16_t)(d2.y >> 16))};
+        const int Lc = L < nquads ? L : nquads - 1; // clamped: the LDS reads are unconditional
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            const uint8_t *xb = lds + (size_t)(c * nquads + Lc) * X80_QUAD;
+            const uint4 xq4 = *(const uint4 *)(xb + j * 16);
+            const float4 xd4 = *(const float4 *)(xb + X80_QD);
+            const uint32_t xq[4] = {xq4.x, xq4.y, xq4.z, xq4.w};
+            const float xd[4] = {xd4.x, xd4.y, xd4.z, xd4.w};
+#pragma unroll
+            for (int dd = 0; dd < 4; dd++) {
+                P.a[dd][c] = da[dd] * xd[dd];
+                P.b[dd][c] = (float)sdot4(qw[dd], xq[dd], 0);
+            }
+        }
+    };
+    auto chain = [&](const prepd &P, int dd) {
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            const float a = P.a[dd][c], bq = P.b[dd][c];
+            if constexpr (MODE == 0) {
+                Cv[c] = __builtin_fmaf(a, bq, Cv[c]);
+            } else if constexpr (MODE == 1) {
+                const float y = __builtin_fmaf(a, bq, -Ce[c]);
+                const float t = Cv[c] + y;
+                Ce[c] = (t - Cv[c]) - y;
+                Cv[c] = t;
+            } else { // branch-free select
+                const float plain = __builtin_fmaf(a, bq, Cv[c]);
+                const float y = __builtin_fmaf(a, bq, -Ce[c]);
+                const float t = Cv[c] + y;
+                const float e2 = (t - Cv[c]) - y;
+                Cv[c] = kahan[c] ? t : plain;
+                Ce[c] = kahan[c] ? e2 : 0.0f;
+            }
+        }
+    };
+
+    // Blocks past the row (zero padding of the last quad, zero-filled prefetch slots) must NOT run: a Kahan
+    // step with a*b = 0 still folds the pending compensation into the sum.  Full quads run unguarded.
+    const int nq_full = nblocks >> 2;
+    prepd P[2];
+    prep(0, 0, P[0]);
+    issue(0, Q80_DEPTH);
+    // rounds of Q80_DEPTH full quads run without a branch in the body (k = 4096 and 14336: every round);
+    // the remainder round carries the guards
+    int L0 = 0;
+    for (; L0 + Q80_DEPTH <= nq_full; L0 += Q80_DEPTH) {
+#pragma unroll
+        for (int s = 0; s < Q80_DEPTH; s++) {
+            const int sn = (s + 1) % Q80_DEPTH;
+            prep(sn, L0 + s + 1, P[(s + 1) & 1]); // slot sn holds quad L+1
+            issue(sn, L0 + s + 1 + Q80_DEPTH);    // and is refilled as soon as its registers are read
+            const prepd &Pc = P[s & 1];
+            chain(Pc, 0);
+            chain(Pc, 1);
+            chain(Pc, 2);
+            chain(Pc, 3);
+        }
+    }
+    if (L0 < nquads) {
+#pragma unroll
+        for (int s = 0; s < Q80_DEPTH; s++) {
+            const int L = L0 + s;
+            const int sn = (s + 1) % Q80_DEPTH;
+            prep(sn, L + 1, P[(s + 1) & 1]);
+            const prepd &Pc = P[s & 1];
+            if (L < nq_full) {
+                chain(Pc, 0);
+                chain(Pc, 1);
+                chain(Pc, 2);
+                chain(Pc, 3);
+            } else if (L == nq_full) {
+                if (4 * L + 0 < nblocks)
+                    chain(Pc, 0);
+                if (4 * L + 1 < nblocks)
+                    chain(Pc, 1);
+                if (4 * L + 2 < nblocks)
+                    chain(Pc, 2);
+            }
+        }
+    }
+    GSTAMP();
+    // hsum(__m256), tinyblas_cpu.h:277-296: ((v0+v4)+(v2+v6)) + ((v1+v5)+(v3+v7))
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        float v = Cv[c];
+        v = v + __shfl_xor(v, 4, 64);
+        v = v + __shfl_xor(v, 2, 64);
+        v = v + __shfl_xor(v, 1, 64);
+        if (j == 0 && row < m)
+            C[(col0 + c) * ldc + row] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+
+// ---------------------------------------------------------------------------------------------
+
+static int g_num_cus = 0;
+
+static int num_cus() {
+    if (!g_num_cus) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess)
+            g_num_cus = p.multiProcessorCount;
+        if (g_num_cus <= 0)
+            g_num_cus = 256;
+    }
+    return g_num_cus;
+}
+
+template <typename TR, int NC, int BT, int NW, int CH>
+static hipError_t launch_kq(const gemv_mats &mats, int n_ht, long k, const void *B, size_t brb, long col0, hipStream_t s) {
+    int nb = (int)(k / 256);
+    size_t smem = (size_t)NC * nb * XBLK + 2 * NW * NC * 16 * sizeof(float);
+    auto kernel = gemv_kq_kernel<TR, NC, BT, NW, CH>;
+    if (smem > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess)
+            return e;
+    }
+    // persistent grid: 16 waves per CU, every work-group the same number of half-tiles
+    const int max_wg = (16 / NW) * num_cus();
+    const int per_wg = (n_ht + max_wg - 1) / max_wg;
+    const int grid = (n_ht + per_wg - 1) / per_wg;
+    kernel<<<grid, NW * 64, smem, s>>>(mats, nb, (const uint8_t *)B, brb, col0, n_ht);
+    return hipGetLastError();
+}
+
+template <typename TR, int BT>
+static hipError_t launch_kq_ids(const gemv_mats &mats, int n_ht, long k, const void *B, size_t brb, hipStream_t s) {
+    const int nb = (int)(k / 256);
+    constexpr int NW = 16;
+    const size_t smem = (size_t)nb * XBLK + 2 * NW * 16 * sizeof(float);
+    const int max_wg = num_cus();
+    const int per_wg = (n_ht + max_wg - 1) / max_wg;
+    const int grid = (n_ht + per_wg - 1) / per_wg;
+    if (nb <= 16) {
+        auto kernel = gemv_kq_kernel<TR, 1, BT, NW, 1, true>;
+        kernel<<<grid, NW * 64, smem, s>>>(mats, nb, (const uint8_t *)B, brb, 0, n_ht);
+    } else {
+        auto kernel = gemv_kq_kernel<TR, 1, BT, NW, 2, true>;
+        if (smem > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            if (e != hipSuccess)
+                return e;
+        }
+        kernel<<<grid, NW * 64, smem, s>>>(mats, nb, (const uint8_t *)B, brb, 0, n_ht);
+    }
+    return hipGetLastError();
+}
+
+template <typename TR, int NC, int BT>
+static hipError_t launch_kq_pick(const gemv_mats &mats, int n_ht, long k, const void *B, size_t brb, long col0,
+                                 hipStream_t s) {
+    const long nb = k / 256;
+    if constexpr (NC == 1) {
+        if (nb <= 16)
+            return launch_kq<TR, NC, BT, 16, 1>(mats, n_ht, k, B, brb, col0, s);
+        return launch_kq<TR, NC, BT, 16, 2>(mats, n_ht, k, B, brb, col0, s);
+    } else {
+        if (nb <= 16)
+            return launch_kq<TR, NC, BT, 8, 2>(mats, n_ht, k, B, brb, col0, s);
+        return launch_kq<TR, NC, BT, 8, 4>(mats, n_ht, k, B, brb, col0, s);
+    }
+}
+
+template <int NC, int BT>
+static hipError_t launch_q4k(const gemv_mats &mats, int n_ht, long k, const void *B, size_t brb, long col0, hipStream_t s) {
+    return launch_kq_pick<q4k_traits, NC, BT>(mats, n_ht, k, B, brb, col0, s);
+}
+
+template <int NC, int BT>
+static hipError_t launch_q40(const gemv_mats &mats, int n_ht, long k, const void *B, size_t brb, long col0, hipStream_t s) {
+    return launch_kq_pick<q40_traits, NC, BT>(mats, n_ht, k, B, brb, col0, s);
+}
+
+template <int NC, int BT>
+static hipError_t launch_q5k(const gemv_mats &mats, int n_ht, long k, const void *B, size_t brb, long col0, hipStream_t s) {
+    return launch_kq_pick<q5k_traits, NC, BT>(mats, n_ht, k, B, brb, col0, s);
+}
+
+template <int NC, int BT>
+static hipError_t launch_q6k(const gemv_mats &mats, int n_ht, long k, const void *B, size_t brb, long col0, hipStream_t s) {
+    return launch_kq_pick<q6k_traits, NC, BT>(mats, n_ht, k, B, brb, col0, s);
+}
+
+template <int NC, int BT>
+static hipError_t launch_q80(const q80_mats &mats, long n_total, long k, const void *B, size_t brb, long col0, int vregs32,
+                             int precise, hipStream_t s) {
+    int nblocks = (int)(k / 32), nquads = (nblocks + 3) / 4;
+    size_t smem = (size_t)NC * nquads * X80_QUAD;
+    const long rgs = mats.rg_end[GEMV_MAX_MATS - 1];
+    unsigned grid = (unsigned)((rgs + Q80_WAVES - 1) / Q80_WAVES);
+    // n = 1: the whole problem is one column of 2x1 / 1x1 tiles, so the summation mode is uniform
+    const int mode = n_total == 1 ? ((vregs32 || precise) ? 1 : 0) : 2;
+#define Q80_GO(MODE)                                                                                                   \
+    do {                                                                                                               \
+        auto kernel = gemv_q80_kernel<NC, BT, MODE, 16>;                                                               \
+        if (smem > 64 * 1024) {                                                                                        \
+            hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+            if (e != hipSuccess)                                                                                       \
+                return e;                                                                                              \
+        }                                                                                                              \
+        kernel<<<grid, Q80_WAVES * 64, smem, s>>>(mats, n_total, nblocks, nquads, (const uint8_t *)B, brb, col0, vregs32, \
+                                                  precise);                                                            \
+    } while (0)
+    if (mode == 0)
+        Q80_GO(0);
+    else if (mode == 1)
+        Q80_GO(1);
+    else
+        Q80_GO(2);
+#undef Q80_GO
+    return hipGetLastError();
+}
+
+
+#define DISPATCH_NC(FN, BT, nc, ...)                                                                                   \
+    switch (nc) {                                                                                                      \
+    case 1:                                                                                                            \
+        e = FN<1, BT>(__VA_ARGS__);                                                                                    \
+        break;                                                                                                         \
+    case 2:                                                                                                            \
+        e = FN<2, BT>(__VA_ARGS__);                                                                                    \
+        break;                                                                                                         \
+    case 3:                                                                                                            \
+        e = FN<3, BT>(__VA_ARGS__);                                                                                    \
+        break;                                                                                                         \
+    case 4:                                                                                                            \
+        e = FN<4, BT>(__VA_ARGS__);                                                                                    \
+        break;                                                                                                         \
+    case 5:                                                                                                            \
+        e = FN<5, BT>(__VA_ARGS__);                                                                                    \
+        break;                                                                                                         \
+    case 6:                                                                                                            \
+        e = FN<6, BT>(__VA_ARGS__);                                                                                    \
+        break;                                                                                                         \
+    case 7:                                                                                                            \
+        e = FN<7, BT>(__VA_ARGS__);                                                                                    \
+        break;                                                                                                         \
+    default:                                                                                                           \
+        e = FN<8, BT>(__VA_ARGS__);                                                                                    \
+        break;                                                                                                         \
+    }
+
+
+// ---- one translation unit per weight type (gemv_*.hip) instantiates its kernels through these stamps (the 8 column
+// counts x 2 activation types x chunk variants of every type used to compile serially in one 140-second file)
+#define GEMV_GO_ARGS int nc, int f32in, const gemv_mats &mats, int n_ht, long k, const void *B, size_t brb, long col0, hipStream_t s
+#define GEMV_INSTANTIATE(NAME, TRAITS, QTYPE)                                                                          \
+    hipError_t lfamd_gemv_go_##NAME(GEMV_GO_ARGS) {                                                                    \
+        hipError_t e = hipSuccess;                                                                                     \
+        if (f32in) {                                                                                                   \
+            DISPATCH_NC(launch_##NAME, LFAMD_TYPE_F32, nc, mats, n_ht, k, B, brb, col0, s)                             \
+        } else {                                                                                                       \
+            DISPATCH_NC(launch_##NAME, QTYPE, nc, mats, n_ht, k, B, brb, col0, s)                                      \
+        }                                                                                                              \
+        return e;                                                                                                      \
+    }
+#define GEMV_INSTANTIATE_IDS(NAME, TRAITS)                                                                             \
+    hipError_t lfamd_gemv_ids_go_##NAME(int f32in, const gemv_mats &mats, int n_ht, long k, const void *B, size_t brb,  \
+                                        hipStream_t s) {                                                               \
+        return f32in ? launch_kq_ids<TRAITS, LFAMD_TYPE_F32>(mats, n_ht, k, B, brb, s)                                 \
+                     : launch_kq_ids<TRAITS, LFAMD_TYPE_Q8_K>(mats, n_ht, k, B, brb, s);                               \
+    }
