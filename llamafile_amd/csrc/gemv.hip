@@ -8,7 +8,8 @@ hipError_t lfamd_gemv_go_q40(GEMV_GO_ARGS);
 hipError_t lfamd_gemv_ids_go_q4k(int, const gemv_mats &, int, long, const void *, size_t, hipStream_t);
 hipError_t lfamd_gemv_ids_go_q5k(int, const gemv_mats &, int, long, const void *, size_t, hipStream_t);
 hipError_t lfamd_gemv_ids_go_q6k(int, const gemv_mats &, int, long, const void *, size_t, hipStream_t);
-hipError_t lfamd_gemv_go_q80(int, int, const q80_mats &, long, long, const void *, size_t, long, int, int, hipStream_t);
+hipError_t lfamd_gemv_go_q80_f32(int, const q80_mats &, long, long, const void *, size_t, long, int, int, hipStream_t);
+hipError_t lfamd_gemv_go_q80_q80(int, const q80_mats &, long, long, const void *, size_t, long, int, int, hipStream_t);
 
 // LDS budget: keep one launch's activation image under 160 KiB; otherwise split the columns.
 static int max_cols_for(size_t per_col_bytes) {
@@ -54,7 +55,8 @@ extern "C" hipError_t lfamd_launch_gemv_multi(int Atype, int count, const void *
                 qm.A[i] = qm.A[0], qm.C[i] = qm.C[0], qm.m[i] = 0, qm.ldc[i] = 0, qm.rg_end[i] = rgs;
             for (long col0 = 0; col0 < n && e == hipSuccess; col0 += step) {
                 int nc = (int)((n - col0) < step ? (n - col0) : step);
-                e = lfamd_gemv_go_q80(nc, f32in ? 1 : 0, qm, n, k, B, b_row_bytes, col0, vregs32, precise, s);
+                e = f32in ? lfamd_gemv_go_q80_f32(nc, qm, n, k, B, b_row_bytes, col0, vregs32, precise, s)
+                          : lfamd_gemv_go_q80_q80(nc, qm, n, k, B, b_row_bytes, col0, vregs32, precise, s);
             }
         }
         return e;
