@@ -46,6 +46,7 @@ enum lfamd_status {
 #define LFAMD_FLAG_FORCE_GENERIC 4u /* debugging: route through the generic (untuned) kernel */
 #define LFAMD_FLAG_GEMM_NARROW 8u   /* testing: force the 128x64 split-K MFMA body (default: chosen by grid size) */
 #define LFAMD_FLAG_GEMM_WIDE 16u    /* testing: force the 128x128 MFMA body */
+#define LFAMD_FLAG_GEMM_PLAIN 32u   /* testing: the 128x128 body without loader waves (Q4_K / Q5_K default to them) */
 
 int lfamd_abi_version(void);
 const char *lfamd_last_error(void);

@@ -18,6 +18,7 @@ FLAG_PRECISE = 2
 FLAG_FORCE_GENERIC = 4
 FLAG_GEMM_NARROW = 8
 FLAG_GEMM_WIDE = 16
+FLAG_GEMM_PLAIN = 32
 
 
 class LfamdError(RuntimeError):

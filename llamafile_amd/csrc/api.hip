@@ -34,6 +34,7 @@ hipError_t lfamd_launch_gemv_multi(int, int, const void *const *, const long *, 
 hipError_t lfamd_launch_gemm_q80(const void *, long, long, int, const void *, size_t, long, float *, long, void *, int, int,
                                  hipStream_t);
 size_t lfamd_gemm_q80_workspace(long, long);
+void lfamd_gemm_wide_plain(int);
 hipError_t lfamd_launch_gemm_wide_multi(int, int, const void *const *, const long *, long, const void *, const void *,
                                         const void *, long, long, float *const *, const long *, hipStream_t);
 hipError_t lfamd_launch_gemm_wide(int, const void *, long, long, const void *, const void *, const void *, long, long,
@@ -299,7 +300,8 @@ size_t lfamd_mul_mat_workspace(int Atype, long m, long k, long n) {
 
 int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const void *d_B, size_t b_row_bytes, long n,
                   float *d_C, long ldc, void *d_ws, size_t ws_bytes, unsigned flags, void *stream) {
-    (void)hipGetLastError(); // a stale error of an earlier call (e.g. an invalidated stream capture) must not fail this one
+    (void)hipGetLastError();
+    lfamd_gemm_wide_plain((flags & LFAMD_FLAG_GEMM_PLAIN) ? 1 : 0); // a stale error of an earlier call (e.g. an invalidated stream capture) must not fail this one
     if (!type_known(Atype))
         return fail(LFAMD_ERR_UNSUPPORTED, "mul_mat: unsupported weight type%s", "");
     if (m < 0 || n < 0 || k < 0 || ldc < m || k % lfamd_blck_size(Atype))
@@ -439,6 +441,8 @@ int lfamd_mul_mat_multi(int Atype, int count, const void *const *d_A, const long
                         size_t b_row_bytes, long n, float *const *d_C, const long *ldc, void *d_ws, size_t ws_bytes,
                         unsigned flags, void *stream) {
     (void)hipGetLastError(); // a stale error of an earlier call (e.g. an invalidated stream capture) must not fail this one
+    lfamd_gemm_wide_plain((flags & LFAMD_FLAG_GEMM_PLAIN) ? 1 : 0);
+    lfamd_gemm_wide_plain((flags & LFAMD_FLAG_GEMM_PLAIN) ? 1 : 0);
     if (count <= 0)
         return LFAMD_OK;
     // one fused launch when the GEMV path applies to every matrix; otherwise one mul_mat per matrix
@@ -507,6 +511,7 @@ int lfamd_mul_mat_id(int type, const void *d_W, long rows, long cols, int expert
                      size_t b_row_bytes, int tasks, long tokens, const int32_t *d_plan, int thinkers, float *d_result,
                      void *d_ws, size_t ws_bytes, unsigned flags, void *stream) {
     (void)hipGetLastError(); // a stale error of an earlier call (e.g. an invalidated stream capture) must not fail this one
+    lfamd_gemm_wide_plain((flags & LFAMD_FLAG_GEMM_PLAIN) ? 1 : 0);
     if (!type_known(type))
         return fail(LFAMD_ERR_UNSUPPORTED, "mul_mat_id: unsupported weight type%s", "");
     if (rows < 0 || cols < 0 || cols % lfamd_blck_size(type) || experts <= 0 || tasks <= 0 || thinkers <= 0 ||

@@ -1,0 +1,364 @@
+// gemm_lw.hip — prefill GEMM, "loader-wave" body for the resident Q4_K / Q5_K layouts.
+//
+// Same arithmetic as gemm_wide / gemm_mfma (exact integer codes on v_mfma_f32_32x32x16_f16, f32 scales once per
+// super-block; reference mul_mat_qX_K_q8_K_T, iqk_mul_mat.inc:601-643).  What changes is who does what:
+//
+//   * waves 0-3 COMPUTE: 32 weight rows x 128 tokens each (work-group tile 128 x 128).  One dequantised fragment (9-11
+//     VALU instructions) feeds FOUR MFMAs; with the per-super-block scaling that is ~6 VALU per MFMA — the 32 x 64 wave
+//     tile of gemm_wide needs ~10 and is vector-issue bound (PMC: VALU and MFMA cycles add up instead of overlapping).
+//     Weights are read from LDS (no register double buffer), so the wave stays inside the 256 registers that two
+//     waves per SIMD allow.
+//   * waves 4-7 LOAD: every LDS-DMA piece of the work-group (activation codes, packed weights, headers, d8, mins
+//     operand) is issued by them, two stages ahead, with counted vmcnt.  An LDS-DMA piece blocks its issuer for
+//     100-200 cycles; here that time belongs to a wave with nothing else to do, on a SIMD whose other wave computes.
+//   * stage = HALF a super-block (128 k): 32 KiB of activation codes + 8 KiB of nibbles (+ headers / d8 / mins operand
+//     with the first half), three stages in LDS (157.5 KiB), ONE s_barrier per half super-block.
+#include "gemm_wide_impl.h"
+
+#define LW_X 0          // 128 tokens x 256 B, XOR-swizzled 16-byte chunks
+#define LW_W 32768      // 4 row tiles x 2 KiB (the two nibble groups of this half)
+#define LW_HDR 40960    // 4 x 1 KiB: 512 B {d, dmin, scales[12]} per row, written twice (a DMA piece is a whole wave) (first half only)
+#define LW_QH 45056     // Q5_K: 4 x 1 KiB of fifth bits                  (first half only)
+#define LW_D8 49152     // 128 f32                                        (first half only)
+#define LW_XM 49664     // 128 x 32 B mins operand                        (first half only)
+#define LW_SLOT 53760
+#define LW_STAGES 3
+
+#if GEMM_DIAG == 4 // development: s_memtime stamps around every barrier of work-group 0 (wave 0 computes, wave 4 loads)
+__device__ unsigned long long g_lw_stamps[2 * 128];
+extern "C" int lfamd_debug_lw_stamps(unsigned long long *dst) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_lw_stamps), sizeof(g_lw_stamps));
+}
+#define LSTAMP(role)                                                                                             \
+    do {                                                                                                         \
+        if (blockIdx.x == 0 && lane == 0 && (wave & 3) == 0 && stamp_n < 128)                                     \
+            g_lw_stamps[(role)*128 + stamp_n++] = __builtin_amdgcn_s_memtime();                                  \
+    } while (0)
+#else
+#define LSTAMP(role)
+#endif
+
+template <int TYPE, bool MOE>
+__global__ __launch_bounds__(512) void gemm_lw_kernel(const gemm_mats mats, int nb, const _Float16 *__restrict__ Xh,
+                                                      const float *__restrict__ d8T, const _Float16 *__restrict__ Xm, long n,
+                                                      long n_pad, int n_rb, int n_ct) {
+    static_assert(TYPE == LFAMD_TYPE_Q4_K || TYPE == LFAMD_TYPE_Q5_K, "resident Q4_K-family layouts only");
+    constexpr bool Q5 = TYPE == LFAMD_TYPE_Q5_K;
+    constexpr int TILE = Q5 ? P5K_TILE : P4K_TILE;
+    __shared__ __attribute__((aligned(16))) uint8_t lds[LW_STAGES * LW_SLOT];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = lane & 31, h = lane >> 5;
+
+    // ---- tile of this work-group (same orders as gemm_wide)
+    int rb, ct, moe_left = 0;
+    const uint8_t *__restrict__ A;
+    float *__restrict__ C;
+    long m, ldc, n0;
+    if constexpr (MOE) {
+        const int per_ct = (int)(gridDim.x / mats.moe_ct_max);
+        ct = blockIdx.x / per_ct;
+        const int rem = blockIdx.x - ct * per_ct;
+        const int e = rem / n_rb;
+        rb = rem - e * n_rb;
+        moe_left = mats.moe_cnt[e] - ct * WD_COLS;
+        if (moe_left <= 0)
+            return;
+        A = mats.A[0] + (size_t)e * mats.expert_bytes;
+        C = mats.C[0];
+        m = mats.m[0], ldc = mats.ldc[0];
+        n0 = (long)mats.moe_poff[e] + (long)ct * WD_COLS;
+    } else {
+        const int n_wg = n_rb * n_ct;
+        const int id = blockIdx.x, q8 = n_wg >> 3, r8 = n_wg & 7, xcd = id & 7;
+        const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3);
+        tile_of(L, n_rb, n_ct, rb, ct);
+        int mj = 0;
+#pragma unroll
+        for (int jj = 1; jj < GEMM_MAX_MATS; jj++)
+            if (jj < mats.count && rb >= mats.rb_end[jj - 1])
+                mj = jj;
+        if (mj > 0)
+            rb -= mats.rb_end[mj - 1];
+        A = mats.A[mj];
+        C = mats.C[mj];
+        m = mats.m[mj], ldc = mats.ldc[mj];
+        n0 = (long)ct * WD_COLS;
+    }
+    const long n_row_tiles = (m + 31) / 32;
+    const int H = 2 * nb; // half super-blocks
+#if GEMM_DIAG == 4
+    int stamp_n = 0;
+#endif
+    const uint32_t lds0 = lds_addr(lds);
+
+    if (wave >= 4) {
+        // =================================== loader waves ===================================
+        const int lw = wave - 4;
+        const long rtl = (long)rb * 4 + lw; // the row tile whose weights this wave copies
+        const uint8_t *wt0 = A + (size_t)(rtl < n_row_tiles ? rtl : 0) * nb * TILE;
+        // activation pieces: piece p = 8 lw + e holds token rows 4p .. 4p+3; lane = (row 4p + (lane >> 4), slot lane & 15)
+        uint32_t xo[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const int row = 4 * (8 * lw + e) + (lane >> 4);
+            xo[e] = (uint32_t)(row * 512 + (((lane & 15) ^ (row & 15)) * 16));
+        }
+        const uint32_t xmo = (uint32_t)((32 * lw + (lane >> 1)) * 32 + (lane & 1) * 16);
+        const uint8_t *xbase = (const uint8_t *)Xh + (size_t)n0 * 512;
+        const uint8_t *xmbase = (const uint8_t *)Xm + (size_t)n0 * 32;
+
+        auto issue = [&](int hb, auto halfc) { // all LDS-DMA of stage hb (clamped at the end: rewrites a dead slot)
+            constexpr int half = decltype(halfc)::value;
+            const int hbc = hb < H ? hb : H - 2 + half;
+            const int b = hbc >> 1;
+            const uint32_t slot = lds0 + (uint32_t)(hb % LW_STAGES) * LW_SLOT;
+            const uint8_t *xs = uniform_ptr(xbase + (size_t)b * n_pad * 512 + half * 256);
+#pragma unroll
+            for (int e = 0; e < 8; e++)
+                glds1x16(xs, slot + LW_X + (8 * lw + e) * 1024, xo[e]);
+            const uint8_t *tile = uniform_ptr(wt0 + (size_t)b * TILE);
+            const uint8_t *wg0 = uniform_ptr(tile + (2 * half) * 1024), *wg1 = uniform_ptr(tile + (2 * half + 1) * 1024);
+            glds1x16(wg0, slot + LW_W + lw * 2048, (uint32_t)(lane * 16));
+            glds1x16(wg1, slot + LW_W + lw * 2048 + 1024, (uint32_t)(lane * 16));
+            if constexpr (half == 0) {
+                // 512-byte header: the upper half-wave copies the same rows again into the second half of the 1 KiB slot
+                glds1x16(uniform_ptr(tile + P4K_HDR), slot + LW_HDR + lw * 1024, (uint32_t)((lane & 31) * 16));
+                if constexpr (Q5)
+                    glds1x16(uniform_ptr(tile + P5K_QH), slot + LW_QH + lw * 1024, (uint32_t)(lane * 16));
+                glds1x4(uniform_ptr(d8T + (size_t)b * n_pad + n0), slot + LW_D8 + (lw & 1) * 256, (uint32_t)((lw & 1) * 256 + lane * 4));
+                glds1x16(uniform_ptr(xmbase + (size_t)b * n_pad * 32), slot + LW_XM + lw * 1024, xmo);
+            }
+        };
+        constexpr int C0 = 8 + 2 + 1 + (Q5 ? 1 : 0) + 1 + 1, C1 = 8 + 2; // pieces per stage of a first / second half
+        using H0 = std::integral_constant<int, 0>;
+        using H1 = std::integral_constant<int, 1>;
+        issue(0, H0{});
+        issue(1, H1{});
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(C1) : "memory"); // stage 0 landed
+        for (int hb = 0; hb < H; hb += 2) {
+            LSTAMP(1);
+            issue(hb + 2, H0{});
+            LSTAMP(1);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C0) : "memory");
+            LSTAMP(1);
+            asm volatile("s_barrier" ::: "memory"); // stage hb+1 landed; everybody done with hb
+            LSTAMP(1);
+            issue(hb + 3, H1{});
+            LSTAMP(1);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C1) : "memory");
+            LSTAMP(1);
+            asm volatile("s_barrier" ::: "memory"); // stage hb+2 landed; everybody done with hb+1
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // nothing may land after the work-group has left
+        return;
+    }
+
+    // =================================== compute waves ===================================
+    const int rw = wave;
+    const long rt = (long)rb * 4 + rw;
+    const bool active = rt < n_row_tiles;
+    float16_t_ acc[4], tmp[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; nt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+            acc[nt][r] = 0.0f, tmp[nt][r] = 0.0f;
+    // fragment chunk of K-step t8 (0..7 inside the half): row i, logical chunk 2 t8 + h, slot = chunk ^ (i & 15)
+    uint32_t xoff[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+        xoff[u] = (uint32_t)(i * 256 + (((2 * u + h) ^ (i & 15)) * 16)) + LW_X;
+    const float16_t_ zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const uint32_t magic = opaque_magic();
+    u32x4 hd = {0, 0, 0, 0}, hq = {0, 0, 0, 0};
+
+    auto half_step = [&](uint32_t slot, uint32_t slot_first, auto halfc) {
+        constexpr int half = decltype(halfc)::value;
+        // this half's 8 K-step dwords (two groups) and, with the first half, the row header
+        u32x4 qa, qb;
+        if constexpr (half == 0) {
+            asm volatile("ds_read_b128 %0, %3 offset:%4\n\tds_read_b128 %1, %3 offset:%4+1024\n\tds_read_b128 %2, %5 offset:%6\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(qa), "=&v"(qb), "=&v"(hd)
+                         : "v"(slot + rw * 2048 + lane * 16), "n"(LW_W), "v"(slot + rw * 1024 + i * 16), "n"(LW_HDR));
+            if constexpr (Q5)
+                asm volatile("ds_read_b128 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=v"(hq) : "v"(slot + rw * 1024 + lane * 16), "n"(LW_QH));
+        } else {
+            asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%3+1024\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(qa), "=&v"(qb)
+                         : "v"(slot + rw * 2048 + lane * 16), "n"(LW_W));
+        }
+        const uint32_t qw[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+        const uint32_t hq5[4] = {hq.x, hq.y, hq.z, hq.w};
+        (void)hq5;
+        uint32_t sc03, sc47, mn03, mn47;
+        q4k_scales_bytes(hd.y, hd.z, hd.w, sc03, sc47, mn03, mn47);
+        const uint32_t scw = half ? sc47 : sc03;
+
+        auto read_frags = [&](half8_t(&f)[4], int t8) {
+            const uint32_t a = xoff[t8] + slot;
+            dsr16<0>(f[0], a);
+            dsr16<8192>(f[1], a);
+            dsr16<16384>(f[2], a);
+            dsr16<24576>(f[3], a);
+        };
+        // K loop, software-pipelined by one K-step: the fragment of K-step t8+1 is dequantised BETWEEN the four MFMAs of
+        // K-step t8 (a wave blocks on MFMA issue while the pipe is busy; VALU work issued right after an MFMA runs in
+        // its shadow, up to ~24 cycles per MFMA — four MFMAs back to back followed by eleven VALU hide only the last
+        // gap).  sched_group_barrier pins the interleave: 1 MFMA, 3 VALU, four times.
+        auto consts = [&](int jj, half2_t &S, half2_t &O, half2_t &S16, half2_t &O16) {
+            const q4_consts2 cp = q4_consts_pair(scw, (jj & 2) ? 2 : 0);
+            const int hsel = jj & 1;
+            S = half2_t{cp.S[hsel], cp.S[hsel]}, O = half2_t{cp.O[hsel], cp.O[hsel]};
+            S16 = half2_t{cp.S16[hsel], cp.S16[hsel]}, O16 = half2_t{cp.O16[hsel], cp.O16[hsel]};
+        };
+        auto dequant = [&](int t8) -> half8_t {
+            half2_t S, O, S16, O16;
+            consts(t8 >> 1, S, O, S16, O16);
+            if constexpr (Q5) // K-step 8 half + t8: group (8 half + t8) >> 2, position & 3
+                return dequant_q5(qw[t8], hq5[2 * half + (t8 >> 2)] >> (t8 & 3), S, O, S16, O16, magic);
+            else
+                return dequant_q4(qw[t8], S, O, S16, O16, magic);
+        };
+        half8_t F[3][4]; // fragments two K-steps ahead: an LDS read takes ~200 cycles here, a K-step 128
+        // epilogue operands (mins fragment + 16 token scales) of token tile nt, two tiles in flight
+        half8_t exm[2];
+        float4_t_ ed8[2][4];
+        auto read_epi = [&](int nt) {
+            asm volatile("ds_read_b128 %0, %5 offset:%6\n\tds_read_b128 %1, %7 offset:%8\n\tds_read_b128 %2, %7 offset:%8+32\n\t"
+                         "ds_read_b128 %3, %7 offset:%8+64\n\tds_read_b128 %4, %7 offset:%8+96"
+                         : "=&v"(exm[nt & 1]), "=&v"(ed8[nt & 1][0]), "=&v"(ed8[nt & 1][1]), "=&v"(ed8[nt & 1][2]), "=&v"(ed8[nt & 1][3])
+                         : "v"(slot_first + (nt * 32 + i) * 32 + h * 16), "n"(LW_XM), "v"(slot_first + (nt * 32 + 4 * h) * 4), "n"(LW_D8));
+        };
+        read_frags(F[0], 0);
+        read_frags(F[1], 1);
+        half8_t wf = dequant(0);
+#pragma unroll
+        for (int t8 = 0; t8 < 8; t8++) {
+#define LW_WAITF(N) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(F[t8 % 3][0]), "+v"(F[t8 % 3][1]), "+v"(F[t8 % 3][2]), "+v"(F[t8 % 3][3]))
+            if (t8 + 2 < 8) {
+                read_frags(F[(t8 + 2) % 3], t8 + 2);
+                LW_WAITF(8);
+            } else if (t8 + 1 < 8) {
+                if constexpr (half == 1) {
+                    read_epi(0);
+                    LW_WAITF(9);
+                } else {
+                    LW_WAITF(4);
+                }
+            } else {
+                if constexpr (half == 1) {
+                    read_epi(1);
+                    LW_WAITF(10);
+                } else {
+                    LW_WAITF(0);
+                }
+            }
+#undef LW_WAITF
+            half8_t wn = wf;
+            if (t8 + 1 < 8)
+                wn = dequant(t8 + 1);
+#pragma unroll
+            for (int nt = 0; nt < 4; nt++)
+                tmp[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F[t8 % 3][nt], wf, (half == 0 && t8 == 0) ? zero16 : tmp[nt], 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0); // three VALU in its shadow
+            }
+            wf = wn;
+        }
+        if constexpr (half == 1) {
+            // ---- super-block done: mins (one MFMA per token tile) and acc += d8 * (d * tmp - dmin * tm)
+            const float d = h2f((uint16_t)(hd.x & 0xffff)), dmin = h2f((uint16_t)(hd.x >> 16));
+            frag_u wm;
+            const float mscale = h ? 64.0f : 1.0f;
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                const uint32_t mw = p < 2 ? mn03 : mn47;
+                const float m0 = (float)((mw >> (16 * (p & 1))) & 0xff), m1 = (float)((mw >> (16 * (p & 1) + 8)) & 0xff);
+                half2_t v = {(_Float16)(m0 * mscale), (_Float16)(m1 * mscale)};
+                wm.p[p] = v;
+            }
+#pragma unroll
+            for (int nt = 0; nt < 4; nt++) {
+                const int b = nt & 1;
+                if (nt < 3)
+                    asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(exm[b]), "+v"(ed8[b][0]), "+v"(ed8[b][1]), "+v"(ed8[b][2]), "+v"(ed8[b][3]));
+                else
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(exm[b]), "+v"(ed8[b][0]), "+v"(ed8[b][1]), "+v"(ed8[b][2]), "+v"(ed8[b][3]));
+                const float16_t_ tm = __builtin_amdgcn_mfma_f32_32x32x16_f16(exm[b], wm.v, zero16, 0, 0, 0);
+#pragma unroll
+                for (int r4 = 0; r4 < 4; r4++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const int r = 4 * r4 + e;
+                        const float u = fmaf(-dmin, tm[r], d * tmp[nt][r]);
+                        acc[nt][r] = fmaf(u, ed8[b][r4][e], acc[nt][r]);
+                    }
+                if (nt + 2 < 4) {
+                    asm volatile("" : "+v"(acc[nt])); // the tile's scaling is done before its operand registers are reloaded
+                    read_epi(nt + 2);
+                }
+            }
+            asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])); // keep the scaling here (cf. gemm_wide LEGACY)
+        }
+    };
+
+    using H0 = std::integral_constant<int, 0>;
+    using H1 = std::integral_constant<int, 1>;
+    asm volatile("s_barrier" ::: "memory"); // stage 0 landed (loaders waited before their arrival)
+    for (int hb = 0; hb < H; hb += 2) {
+        const uint32_t s0 = lds0 + (uint32_t)(hb % LW_STAGES) * LW_SLOT, s1 = lds0 + (uint32_t)((hb + 1) % LW_STAGES) * LW_SLOT;
+        LSTAMP(0);
+        half_step(s0, s0, H0{});
+        LSTAMP(0);
+        asm volatile("s_barrier" ::: "memory");
+        LSTAMP(0);
+        half_step(s1, s0, H1{});
+        LSTAMP(0);
+        asm volatile("s_barrier" ::: "memory");
+    }
+
+    // ---- store: reg r of token tile nt is token n0 + 32nt + (r&3) + 8(r>>2) + 4h, weight row 32rt + i
+    if (active) {
+        const long row = rt * 32 + i;
+        if (row < m) {
+#pragma unroll
+            for (int nt = 0; nt < 4; nt++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int tl = nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const long tok = n0 + tl;
+                    if constexpr (MOE) {
+                        if (tl < moe_left)
+                            C[(long)mats.moe_slot_row[tok] * ldc + row] = acc[nt][r];
+                    } else if (tok < n) {
+                        C[tok * ldc + row] = acc[nt][r];
+                    }
+                }
+        }
+    }
+}
+
+hipError_t lfamd_lw_go(int Atype, const gemm_mats &mats, int nb, const void *Xh, const void *d8T, const void *Xm, long n, long n_pad,
+                       int n_rb, int n_ct, unsigned n_wg, int moe, hipStream_t s) {
+#define LW_GO(T, M)                                                                                                    \
+    gemm_lw_kernel<T, M><<<n_wg, 512, 0, s>>>(mats, nb, (const _Float16 *)Xh, (const float *)d8T, (const _Float16 *)Xm, n, n_pad, \
+                                              n_rb, n_ct)
+    if (Atype == LFAMD_TYPE_Q4_K) {
+        if (moe)
+            LW_GO(LFAMD_TYPE_Q4_K, true);
+        else
+            LW_GO(LFAMD_TYPE_Q4_K, false);
+    } else if (Atype == LFAMD_TYPE_Q5_K) {
+        if (moe)
+            LW_GO(LFAMD_TYPE_Q5_K, true);
+        else
+            LW_GO(LFAMD_TYPE_Q5_K, false);
+    } else {
+        return hipErrorInvalidValue;
+    }
+#undef LW_GO
+    return hipGetLastError();
+}

@@ -1,5 +1,6 @@
 // gemm_wide.hip — launchers of the 128 x 128 MFMA body (kernel: gemm_wide_impl.h; instantiations: gemm_wide_*.hip)
 #include "gemm_wide_impl.h"
+#include <stdlib.h>
 
 hipError_t lfamd_wide_go_q4k(WIDE_ARGS);
 hipError_t lfamd_wide_go_q5k(WIDE_ARGS);
@@ -14,7 +15,19 @@ hipError_t lfamd_wide_go_iq4xs(WIDE_ARGS);
 hipError_t lfamd_wide_go_f16(WIDE_ARGS);
 hipError_t lfamd_wide_go_bf16(WIDE_ARGS);
 
+hipError_t lfamd_lw_go(int Atype, const gemm_mats &mats, int nb, const void *Xh, const void *d8T, const void *Xm, long n, long n_pad,
+                       int n_rb, int n_ct, unsigned n_wg, int moe, hipStream_t s);
+
+// Q4_K / Q5_K without K split run the loader-wave body (gemm_lw.hip) unless the caller asks for the plain one
+static int g_plain_wide = 0;
+extern "C" void lfamd_gemm_wide_plain(int on) {
+    g_plain_wide = on;
+}
+
 static hipError_t wide_go(int Atype, WIDE_ARGS) {
+    static const bool env_plain = getenv("LFAMD_GEMM_NO_LW") != nullptr;
+    if ((Atype == LFAMD_TYPE_Q4_K || Atype == LFAMD_TYPE_Q5_K) && ks == 1 && !g_plain_wide && !env_plain)
+        return lfamd_lw_go(Atype, mats, nb, Xh, d8T, Xm, n, n_pad, n_rb, n_ct, n_wg, moe, s);
     switch (Atype) {
     case LFAMD_TYPE_Q4_K:
         return lfamd_wide_go_q4k(mats, nb, Xh, d8T, Xm, n, n_pad, n_rb, n_ct, ks, nbs, n_wg, moe, s);

@@ -66,7 +66,7 @@ def test_q8_0_bit_exact(gpu, oracle, variant, precise, shape):
 @pytest.mark.parametrize("t", [T.Q4_K, T.Q5_K, T.Q6_K], ids=lambda t: T.NAMES[t])
 @pytest.mark.parametrize("shape", [(128, 64, 512), (96, 100, 1024), (33, 9, 256), (256, 512, 2048), (64, 130, 768)],
                          ids=str)
-@pytest.mark.parametrize("body", ["narrow", "wide"])
+@pytest.mark.parametrize("body", ["narrow", "wide", "wide_plain"])
 def test_mfma_gemm_vs_oracle(gpu, oracle, t, shape, body):
     """Both MFMA bodies (128x64 split-K, gemm_mfma.hip; 128x128, gemm_wide.hip) on every shape, ragged m / n
     included; the default picks by grid size, which small test shapes would never send to the wide body."""
@@ -75,7 +75,8 @@ def test_mfma_gemm_vs_oracle(gpu, oracle, t, shape, body):
     A, B, bt = make_case(t, m, n, k, seed=300 + t)
     ok, G = oracle.sgemm(t, A, bt, B, m, n, k, nth=4)
     assert ok == 1
-    flag = _hip.FLAG_GEMM_NARROW if body == "narrow" else _hip.FLAG_GEMM_WIDE
+    # "wide": Q4_K / Q5_K run the loader-wave body (gemm_lw.hip); "wide_plain": the same tile without loader waves
+    flag = {"narrow": _hip.FLAG_GEMM_NARROW, "wide": _hip.FLAG_GEMM_WIDE, "wide_plain": _hip.FLAG_GEMM_WIDE | _hip.FLAG_GEMM_PLAIN}[body]
     C = run_gpu(gpu, t, A, B, bt, m, n, k, flags=gpu.host_variant_flags() | flag)
     assert not np.isnan(C).any()
     assert rel_err(C, G) <= GEMM_TOL[t], (T.NAMES[t], shape, rel_err(C, G))
@@ -308,7 +309,7 @@ def test_tuned_types_random_shapes(gpu, oracle, t):
         assert ok == 1
         bodies = [0]
         if n > 8 and t in (T.Q4_K, T.Q5_K, T.Q6_K):
-            bodies = [_hip.FLAG_GEMM_NARROW, _hip.FLAG_GEMM_WIDE]
+            bodies = [_hip.FLAG_GEMM_NARROW, _hip.FLAG_GEMM_WIDE, _hip.FLAG_GEMM_WIDE | _hip.FLAG_GEMM_PLAIN]
         for body in bodies:
             C = run_gpu(gpu, t, A, B, bt, m, n, k, flags=gpu.host_variant_flags() | body)
             if t == T.Q8_0:
