@@ -34,7 +34,8 @@ hipError_t lfamd_launch_gemv_multi(int, int, const void *const *, const long *, 
 hipError_t lfamd_launch_gemm_q80(const void *, long, long, int, const void *, size_t, long, float *, long, void *, int, int,
                                  hipStream_t);
 size_t lfamd_gemm_q80_workspace(long, long);
-void lfamd_gemm_wide_plain(int);
+void lfamd_gemm_wide_mode(int);
+int lfamd_gemm_wide_scaled_ok(int, int, const long *, long, long, int);
 hipError_t lfamd_launch_gemm_wide_multi(int, int, const void *const *, const long *, long, const void *, const void *,
                                         const void *, long, long, float *const *, const long *, hipStream_t);
 hipError_t lfamd_launch_gemm_wide(int, const void *, long, long, const void *, const void *, const void *, long, long,
@@ -300,8 +301,9 @@ size_t lfamd_mul_mat_workspace(int Atype, long m, long k, long n) {
 
 int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const void *d_B, size_t b_row_bytes, long n,
                   float *d_C, long ldc, void *d_ws, size_t ws_bytes, unsigned flags, void *stream) {
-    (void)hipGetLastError();
-    lfamd_gemm_wide_plain((flags & LFAMD_FLAG_GEMM_PLAIN) ? 1 : 0); // a stale error of an earlier call (e.g. an invalidated stream capture) must not fail this one
+    (void)hipGetLastError(); // a stale error of an earlier call (e.g. an invalidated stream capture) must not fail this one
+    const int plain = (flags & LFAMD_FLAG_GEMM_PLAIN) ? 1 : 0;
+    lfamd_gemm_wide_mode(plain);
     if (!type_known(Atype))
         return fail(LFAMD_ERR_UNSUPPORTED, "mul_mat: unsupported weight type%s", "");
     if (m < 0 || n < 0 || k < 0 || ldc < m || k % lfamd_blck_size(Atype))
@@ -336,10 +338,6 @@ int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const v
             HIPCHK(lfamd_launch_gemm_wide(Atype, d_A, m, k, Xh, d8T, nullptr, n, (long)n_pad, d_C, ldc, s), "gemm_wide");
             return LFAMD_OK;
         }
-        if (Btype == LFAMD_TYPE_F32)
-            HIPCHK(lfamd_launch_prep_f32(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, 0, nullptr, s), "prep_f32");
-        else
-            HIPCHK(lfamd_launch_prep_q8k(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, 0, nullptr, s), "prep_q8k");
         // two bodies: 128 x 128 tiles, K streamed once (gemm_wide.hip) when that grid fills the 256 CUs; the
         // 128 x 64 split-K body (gemm_mfma.hip) for smaller grids.  LFAMD_GEMM_BODY=narrow|wide forces one.
         static const char *body = getenv("LFAMD_GEMM_BODY");
@@ -348,6 +346,14 @@ int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const v
                             : (flags & LFAMD_FLAG_GEMM_WIDE) ? false
                             : body                           ? body[0] == 'n'
                                                              : tiles128 < 192;
+        // Q4_K / Q5_K on the loader-wave body: scaled operands (one f16 rounding each, ~1e-4 relative) unless the
+        // caller wants the exact integer-code arithmetic (LFAMD_FLAG_PRECISE)
+        const int scaled = (!narrow && !precise) ? lfamd_gemm_wide_scaled_ok(Atype, 1, &m, k, (long)n_pad, plain) : 0;
+        lfamd_gemm_wide_mode(plain | (scaled << 1));
+        if (Btype == LFAMD_TYPE_F32)
+            HIPCHK(lfamd_launch_prep_f32(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, scaled ? 2 : 0, nullptr, s), "prep_f32");
+        else
+            HIPCHK(lfamd_launch_prep_q8k(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, scaled ? 2 : 0, nullptr, s), "prep_q8k");
         if (narrow)
             HIPCHK(lfamd_launch_gemm_kq(Atype, d_A, m, k, Xh, d8T, Xm, n, (long)n_pad, d_C, ldc, s), "gemm_kq");
         else
@@ -441,8 +447,8 @@ int lfamd_mul_mat_multi(int Atype, int count, const void *const *d_A, const long
                         size_t b_row_bytes, long n, float *const *d_C, const long *ldc, void *d_ws, size_t ws_bytes,
                         unsigned flags, void *stream) {
     (void)hipGetLastError(); // a stale error of an earlier call (e.g. an invalidated stream capture) must not fail this one
-    lfamd_gemm_wide_plain((flags & LFAMD_FLAG_GEMM_PLAIN) ? 1 : 0);
-    lfamd_gemm_wide_plain((flags & LFAMD_FLAG_GEMM_PLAIN) ? 1 : 0);
+    const int plain = (flags & LFAMD_FLAG_GEMM_PLAIN) ? 1 : 0;
+    lfamd_gemm_wide_mode(plain);
     if (count <= 0)
         return LFAMD_OK;
     // one fused launch when the GEMV path applies to every matrix; otherwise one mul_mat per matrix
@@ -486,10 +492,12 @@ int lfamd_mul_mat_multi(int Atype, int count, const void *const *d_A, const long
             void *Xh = ws;
             void *d8T = ws + align_up(n_pad * (size_t)k * 2, 256);
             void *Xm = (uint8_t *)d8T + align_up(nb * n_pad * 4, 256);
+            const int scaled = (flags & LFAMD_FLAG_PRECISE) ? 0 : lfamd_gemm_wide_scaled_ok(Atype, count, m, k, (long)n_pad, plain);
+            lfamd_gemm_wide_mode(plain | (scaled << 1));
             if (Btype == LFAMD_TYPE_F32)
-                HIPCHK(lfamd_launch_prep_f32(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, 0, nullptr, s), "prep_f32");
+                HIPCHK(lfamd_launch_prep_f32(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, scaled ? 2 : 0, nullptr, s), "prep_f32");
             else
-                HIPCHK(lfamd_launch_prep_q8k(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, 0, nullptr, s), "prep_q8k");
+                HIPCHK(lfamd_launch_prep_q8k(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, scaled ? 2 : 0, nullptr, s), "prep_q8k");
             HIPCHK(lfamd_launch_gemm_wide_multi(Atype, count, d_A, m, k, Xh, d8T, Xm, n, (long)n_pad, d_C, ldc, s),
                    "gemm_wide_multi");
             return LFAMD_OK;
@@ -511,7 +519,7 @@ int lfamd_mul_mat_id(int type, const void *d_W, long rows, long cols, int expert
                      size_t b_row_bytes, int tasks, long tokens, const int32_t *d_plan, int thinkers, float *d_result,
                      void *d_ws, size_t ws_bytes, unsigned flags, void *stream) {
     (void)hipGetLastError(); // a stale error of an earlier call (e.g. an invalidated stream capture) must not fail this one
-    lfamd_gemm_wide_plain((flags & LFAMD_FLAG_GEMM_PLAIN) ? 1 : 0);
+    lfamd_gemm_wide_mode((flags & LFAMD_FLAG_GEMM_PLAIN) ? 1 : 0);
     if (!type_known(type))
         return fail(LFAMD_ERR_UNSUPPORTED, "mul_mat_id: unsupported weight type%s", "");
     if (rows < 0 || cols < 0 || cols % lfamd_blck_size(type) || experts <= 0 || tasks <= 0 || thinkers <= 0 ||

@@ -133,6 +133,20 @@ __device__ static inline q4_consts2 q4_consts_pair(uint32_t word, int byte_lo) {
     return c;
 }
 
+// the same with the row's f16 super-block scale folded in (scaled-operand GEMM: S = d * sc rounded to f16; the three
+// derived constants are exact multiples of it)
+__device__ static inline q4_consts2 q4_consts_pair_scaled(uint32_t word, int byte_lo, half2_t d2) {
+    q4_consts2 c;
+    const uint32_t sel = byte_lo == 0 ? 0x04010400u : 0x04030402u;
+    const half2_t m1024 = {(_Float16)-1024.0f, (_Float16)-1024.0f}, m64 = {(_Float16)-64.0f, (_Float16)-64.0f};
+    const half2_t r16 = {(_Float16)0.0625f, (_Float16)0.0625f};
+    c.S = (as_half2(__builtin_amdgcn_perm(0x64646464u, word, sel)) + m1024) * d2;
+    c.O = c.S * m1024;
+    c.S16 = c.S * r16;
+    c.O16 = c.S * m64;
+    return c;
+}
+
 __device__ static inline uint32_t opaque_magic() {
     uint32_t magic = 0x64006400u;
     asm volatile("" : "+v"(magic)); // keep it a register value (see dequant_q4)

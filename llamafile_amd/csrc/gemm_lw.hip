@@ -23,6 +23,7 @@
 #define LW_XM 49664     // 128 x 32 B mins operand                        (first half only)
 #define LW_SLOT 53760
 #define LW_STAGES 3
+#define LW_FLAG (LW_STAGES * LW_SLOT) // landed-stage counter (FAST compute waves read ahead of the barrier)
 
 #if GEMM_DIAG == 4 // development: s_memtime stamps around every barrier of work-group 0 (wave 0 computes, wave 4 loads)
 __device__ unsigned long long g_lw_stamps[2 * 128];
@@ -38,14 +39,14 @@ extern "C" int lfamd_debug_lw_stamps(unsigned long long *dst) {
 #define LSTAMP(role)
 #endif
 
-template <int TYPE, bool MOE>
+template <int TYPE, bool MOE, bool FAST>
 __global__ __launch_bounds__(512) void gemm_lw_kernel(const gemm_mats mats, int nb, const _Float16 *__restrict__ Xh,
                                                       const float *__restrict__ d8T, const _Float16 *__restrict__ Xm, long n,
                                                       long n_pad, int n_rb, int n_ct) {
     static_assert(TYPE == LFAMD_TYPE_Q4_K || TYPE == LFAMD_TYPE_Q5_K, "resident Q4_K-family layouts only");
     constexpr bool Q5 = TYPE == LFAMD_TYPE_Q5_K;
     constexpr int TILE = Q5 ? P5K_TILE : P4K_TILE;
-    __shared__ __attribute__((aligned(16))) uint8_t lds[LW_STAGES * LW_SLOT];
+    __shared__ __attribute__((aligned(16))) uint8_t lds[LW_STAGES * LW_SLOT + 16];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 31, h = lane >> 5;
 
@@ -88,8 +89,13 @@ __global__ __launch_bounds__(512) void gemm_lw_kernel(const gemm_mats mats, int 
     const int H = 2 * nb; // half super-blocks
 #if GEMM_DIAG == 4
     int stamp_n = 0;
+    const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), real0 = __builtin_amdgcn_s_memrealtime();
 #endif
     const uint32_t lds0 = lds_addr(lds);
+    const uint32_t flag_addr = lds0 + LW_FLAG;
+    if (threadIdx.x == 0)
+        asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(flag_addr), "v"(0u) : "memory");
+    asm volatile("s_barrier" ::: "memory");
 
     if (wave >= 4) {
         // =================================== loader waves ===================================
@@ -107,47 +113,70 @@ __global__ __launch_bounds__(512) void gemm_lw_kernel(const gemm_mats mats, int 
         const uint8_t *xbase = (const uint8_t *)Xh + (size_t)n0 * 512;
         const uint8_t *xmbase = (const uint8_t *)Xm + (size_t)n0 * 32;
 
-        auto issue = [&](int hb, auto halfc) { // all LDS-DMA of stage hb (clamped at the end: rewrites a dead slot)
-            constexpr int half = decltype(halfc)::value;
+        // all LDS-DMA of stage hb (clamped at the end: rewrites a dead slot), in two parts: A = the first four activation
+        // pieces, B = the rest
+        auto issue = [&](int hb, auto halfc, auto partc) {
+            constexpr int half = decltype(halfc)::value, part = decltype(partc)::value;
             const int hbc = hb < H ? hb : H - 2 + half;
             const int b = hbc >> 1;
             const uint32_t slot = lds0 + (uint32_t)(hb % LW_STAGES) * LW_SLOT;
             const uint8_t *xs = uniform_ptr(xbase + (size_t)b * n_pad * 512 + half * 256);
 #pragma unroll
-            for (int e = 0; e < 8; e++)
+            for (int e = 4 * part; e < 4 * part + 4; e++)
                 glds1x16(xs, slot + LW_X + (8 * lw + e) * 1024, xo[e]);
-            const uint8_t *tile = uniform_ptr(wt0 + (size_t)b * TILE);
-            const uint8_t *wg0 = uniform_ptr(tile + (2 * half) * 1024), *wg1 = uniform_ptr(tile + (2 * half + 1) * 1024);
-            glds1x16(wg0, slot + LW_W + lw * 2048, (uint32_t)(lane * 16));
-            glds1x16(wg1, slot + LW_W + lw * 2048 + 1024, (uint32_t)(lane * 16));
-            if constexpr (half == 0) {
-                // 512-byte header: the upper half-wave copies the same rows again into the second half of the 1 KiB slot
-                glds1x16(uniform_ptr(tile + P4K_HDR), slot + LW_HDR + lw * 1024, (uint32_t)((lane & 31) * 16));
-                if constexpr (Q5)
-                    glds1x16(uniform_ptr(tile + P5K_QH), slot + LW_QH + lw * 1024, (uint32_t)(lane * 16));
-                glds1x4(uniform_ptr(d8T + (size_t)b * n_pad + n0), slot + LW_D8 + (lw & 1) * 256, (uint32_t)((lw & 1) * 256 + lane * 4));
-                glds1x16(uniform_ptr(xmbase + (size_t)b * n_pad * 32), slot + LW_XM + lw * 1024, xmo);
+            if constexpr (part == 1) {
+                const uint8_t *tile = uniform_ptr(wt0 + (size_t)b * TILE);
+                const uint8_t *wg0 = uniform_ptr(tile + (2 * half) * 1024), *wg1 = uniform_ptr(tile + (2 * half + 1) * 1024);
+                glds1x16(wg0, slot + LW_W + lw * 2048, (uint32_t)(lane * 16));
+                glds1x16(wg1, slot + LW_W + lw * 2048 + 1024, (uint32_t)(lane * 16));
+                if constexpr (half == 0) {
+                    // 512-byte header: the upper half-wave copies the same rows again into the second half of the 1 KiB slot
+                    glds1x16(uniform_ptr(tile + P4K_HDR), slot + LW_HDR + lw * 1024, (uint32_t)((lane & 31) * 16));
+                    if constexpr (Q5)
+                        glds1x16(uniform_ptr(tile + P5K_QH), slot + LW_QH + lw * 1024, (uint32_t)(lane * 16));
+                    glds1x4(uniform_ptr(d8T + (size_t)b * n_pad + n0), slot + LW_D8 + (lw & 1) * 256, (uint32_t)((lw & 1) * 256 + lane * 4));
+                    glds1x16(uniform_ptr(xmbase + (size_t)b * n_pad * 32), slot + LW_XM + lw * 1024, xmo);
+                }
             }
         };
-        constexpr int C0 = 8 + 2 + 1 + (Q5 ? 1 : 0) + 1 + 1, C1 = 8 + 2; // pieces per stage of a first / second half
         using H0 = std::integral_constant<int, 0>;
         using H1 = std::integral_constant<int, 1>;
-        issue(0, H0{});
-        issue(1, H1{});
-        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(C1) : "memory"); // stage 0 landed
+        // Protocol.  Barrier B_s closes half-step s: every compute wave is done with stage s, so its slot may be refilled
+        // (stage s+3).  That a stage has LANDED is published apart from the barrier, by a counter in LDS (+1 per loader
+        // wave and stage): after B_(s-1) the loader issues part A of stage s+2, waits until only those four pieces are in
+        // flight (stage s+1, issued a half-step ago, is then complete), bumps the counter and issues part B.  The FAST
+        // compute waves poll the counter late in half-step s and fetch their first operands of stage s+1 BEFORE B_s
+        // (no LDS round trip without MFMAs in flight at the start of a half-step).
+        auto landed = [&]() {
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            if (lane == 0)
+                asm volatile("ds_add_u32 %0, %1" ::"v"(flag_addr), "v"(1u) : "memory");
+        };
+        issue(0, H0{}, H0{});
+        issue(0, H0{}, H1{});
+        issue(1, H1{}, H0{});
+        issue(1, H1{}, H1{});
+        asm volatile("s_waitcnt vmcnt(10)\n\ts_barrier" ::: "memory"); // stage 0 landed (stage 1 = 10 pieces in flight)
+#ifdef LW_EXP_NODMA // development: timing without the steady-state DMA (results are garbage)
+#define LW_DMA_IF if (hb == 0)
+#else
+#define LW_DMA_IF
+#endif
         for (int hb = 0; hb < H; hb += 2) {
             LSTAMP(1);
-            issue(hb + 2, H0{});
+            LW_DMA_IF issue(hb + 2, H0{}, H0{});
+            landed(); // stage hb+1
             LSTAMP(1);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C0) : "memory");
+            LW_DMA_IF issue(hb + 2, H0{}, H1{});
             LSTAMP(1);
-            asm volatile("s_barrier" ::: "memory"); // stage hb+1 landed; everybody done with hb
+            asm volatile("s_barrier" ::: "memory"); // B_hb
             LSTAMP(1);
-            issue(hb + 3, H1{});
+            LW_DMA_IF issue(hb + 3, H1{}, H0{});
+            landed(); // stage hb+2
             LSTAMP(1);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C1) : "memory");
+            LW_DMA_IF issue(hb + 3, H1{}, H1{});
             LSTAMP(1);
-            asm volatile("s_barrier" ::: "memory"); // stage hb+2 landed; everybody done with hb+1
+            asm volatile("s_barrier" ::: "memory"); // B_(hb+1)
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // nothing may land after the work-group has left
         return;
@@ -308,6 +337,143 @@ __global__ __launch_bounds__(512) void gemm_lw_kernel(const gemm_mats mats, int 
     using H0 = std::integral_constant<int, 0>;
     using H1 = std::integral_constant<int, 1>;
     asm volatile("s_barrier" ::: "memory"); // stage 0 landed (loaders waited before their arrival)
+    if constexpr (FAST) {
+        // ---- scaled operands (pack.hip prep mode 2): Xh = f16(d8 * code), the weight fragment = f16(d * sc * q), the
+        // mins one more MFMA per token tile with f16(d8 * S_j) x f16(-dmin * m_j): everything accumulates straight into
+        // acc, nothing is scaled per super-block.  The K-step pipeline runs ACROSS the half-step barriers: the first
+        // operands of the next stage are fetched during K-steps 6 and 7 of this one (see the loader's protocol).
+        u32x4 qa, qb, qan = {0, 0, 0, 0}, qbn = {0, 0, 0, 0}, hdn = {0, 0, 0, 0}, hqn = {0, 0, 0, 0};
+        half8_t F[4][4], fxm[4];
+        uint32_t fl = 0;
+        auto read_frags = [&](half8_t(&f)[4], uint32_t slot, int t8) {
+            const uint32_t a = xoff[t8] + slot;
+            dsr16<0>(f[0], a);
+            dsr16<8192>(f[1], a);
+            dsr16<16384>(f[2], a);
+            dsr16<24576>(f[3], a);
+        };
+        auto dq = [&](auto halfc, int t8) -> half8_t { // weight fragment of K-step t8 of a half, from the CURRENT qa/qb/hd/hq
+            constexpr int half = decltype(halfc)::value;
+            uint32_t sc03, sc47, mn03, mn47;
+            q4k_scales_bytes(hd.y, hd.z, hd.w, sc03, sc47, mn03, mn47);
+            const uint32_t scw = half ? sc47 : sc03;
+            const half2_t dh2 = as_half2(__builtin_amdgcn_perm(hd.x, hd.x, 0x01000100u));
+            const q4_consts2 cp = q4_consts_pair_scaled(scw, (t8 & 4) ? 2 : 0, dh2);
+            const int hsel = (t8 >> 1) & 1;
+            const half2_t S = {cp.S[hsel], cp.S[hsel]}, O = {cp.O[hsel], cp.O[hsel]};
+            const half2_t S16 = {cp.S16[hsel], cp.S16[hsel]}, O16 = {cp.O16[hsel], cp.O16[hsel]};
+            const uint32_t qw[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+            if constexpr (Q5) {
+                const uint32_t hq5[4] = {hq.x, hq.y, hq.z, hq.w};
+                return dequant_q5(qw[t8], hq5[2 * half + (t8 >> 2)] >> (t8 & 3), S, O, S16, O16, magic);
+            } else {
+                return dequant_q4(qw[t8], S, O, S16, O16, magic);
+            }
+        };
+        const uint32_t wq_off = (uint32_t)(rw * 2048 + lane * 16) + LW_W, hd_off = (uint32_t)(rw * 1024 + i * 16) + LW_HDR;
+        const uint32_t hq_off = (uint32_t)(rw * 1024 + lane * 16) + LW_QH, xm_off = (uint32_t)(i * 32 + h * 16) + LW_XM;
+        half8_t wf;
+
+        auto fast_half = [&](uint32_t slot, uint32_t slot_next, uint32_t slot_first, uint32_t need, auto halfc) {
+            constexpr int half = decltype(halfc)::value;
+            using HN = std::integral_constant<int, 1 - half>;
+#pragma unroll
+            for (int t8 = 0; t8 < 8; t8++) {
+#define LW_FW(N) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(F[t8 & 3][0]), "+v"(F[t8 & 3][1]), "+v"(F[t8 & 3][2]), "+v"(F[t8 & 3][3]))
+                if (t8 < 6) {
+                    if (t8 == 4)
+                        asm volatile("ds_read_b32 %0, %1" : "=v"(fl) : "v"(flag_addr));
+                    read_frags(F[(t8 + 2) & 3], slot, t8 + 2);
+                    if (t8 < 4)
+                        LW_FW(8);
+                    else
+                        LW_FW(9); // the counter read sits between K-step 5's and K-step 6's fragments
+                } else if (t8 == 6) {
+                    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(F[2][0]), "+v"(F[2][1]), "+v"(F[2][2]), "+v"(F[2][3]), "+v"(fl));
+                    uint32_t fv = __builtin_amdgcn_readfirstlane(fl);
+                    while (fv < need) { // the next stage has not landed yet (rare: the loaders run a stage ahead)
+                        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(fl) : "v"(flag_addr) : "memory");
+                        fv = __builtin_amdgcn_readfirstlane(fl);
+                    }
+                    if constexpr (half == 1)
+                        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\t"
+                                     "ds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072"
+                                     : "=&v"(fxm[0]), "=&v"(fxm[1]), "=&v"(fxm[2]), "=&v"(fxm[3])
+                                     : "v"(slot_first + xm_off));
+                    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024" : "=&v"(qan), "=&v"(qbn) : "v"(slot_next + wq_off));
+                    if constexpr (half == 1) {
+                        asm volatile("ds_read_b128 %0, %1" : "=v"(hdn) : "v"(slot_next + hd_off));
+                        if constexpr (Q5)
+                            asm volatile("ds_read_b128 %0, %1" : "=v"(hqn) : "v"(slot_next + hq_off));
+                    }
+                    read_frags(F[0], slot_next, 0);
+                } else {
+                    // younger than K-step 7's fragments: [mins 4] + qa/qb 2 + [header 1 (+ fifth bits 1)] + fragments 4
+                    constexpr int N7 = (half ? 4 : 0) + 2 + (half ? 1 + (Q5 ? 1 : 0) : 0) + 4;
+                    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(F[3][0]), "+v"(F[3][1]), "+v"(F[3][2]), "+v"(F[3][3]) : "n"(N7));
+                    read_frags(F[1], slot_next, 1);
+                }
+#undef LW_FW
+                half8_t wn = wf;
+                if (t8 + 1 < 8)
+                    wn = dq(halfc, t8 + 1);
+#pragma unroll
+                for (int nt = 0; nt < 4; nt++)
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F[t8 & 3][nt], wf, acc[nt], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); // one MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0); // three VALU in its shadow
+                }
+                wf = wn;
+            }
+            // everything older than the two fragment groups of the next stage: its nibbles / header, this super-block's mins
+            asm volatile("s_waitcnt lgkmcnt(8)"
+                         : "+v"(qan), "+v"(qbn), "+v"(hdn), "+v"(hqn), "+v"(fxm[0]), "+v"(fxm[1]), "+v"(fxm[2]), "+v"(fxm[3]));
+            if constexpr (half == 1) {
+                uint32_t sc03, sc47, mn03, mn47;
+                q4k_scales_bytes(hd.y, hd.z, hd.w, sc03, sc47, mn03, mn47);
+                const float ndmin = -h2f((uint16_t)(hd.x >> 16));
+                frag_u wm;
+#pragma unroll
+                for (int p = 0; p < 4; p++) {
+                    const uint32_t mw = p < 2 ? mn03 : mn47;
+                    const float m0 = (float)((mw >> (16 * (p & 1))) & 0xff), m1 = (float)((mw >> (16 * (p & 1) + 8)) & 0xff);
+                    half2_t v = {(_Float16)(h ? 0.0f : m0 * ndmin), (_Float16)(h ? 0.0f : m1 * ndmin)};
+                    wm.p[p] = v;
+                }
+#pragma unroll
+                for (int nt = 0; nt < 4; nt++)
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fxm[nt], wm.v, acc[nt], 0, 0, 0);
+                hd = hdn, hq = hqn;
+            }
+            qa = qan, qb = qbn;
+            wf = dq(HN{}, 0);
+        };
+
+        // prologue: stage 0
+        asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:1024\n\tds_read_b128 %2, %4\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(qa), "=&v"(qb), "=&v"(hd)
+                     : "v"(lds0 + wq_off), "v"(lds0 + hd_off));
+        if constexpr (Q5)
+            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(hq) : "v"(lds0 + hq_off));
+        read_frags(F[0], lds0, 0);
+        read_frags(F[1], lds0, 1);
+        wf = dq(H0{}, 0);
+        for (int hb = 0; hb < H; hb += 2) {
+            const uint32_t s0 = lds0 + (uint32_t)(hb % LW_STAGES) * LW_SLOT, s1 = lds0 + (uint32_t)((hb + 1) % LW_STAGES) * LW_SLOT;
+            const uint32_t s2 = lds0 + (uint32_t)((hb + 2) % LW_STAGES) * LW_SLOT;
+            LSTAMP(0);
+            fast_half(s0, s1, s0, 4u * (uint32_t)(hb + 1), H0{});
+            LSTAMP(0);
+            asm volatile("s_barrier" ::: "memory");
+            LSTAMP(0);
+            fast_half(s1, s2, s0, 4u * (uint32_t)(hb + 2), H1{});
+            LSTAMP(0);
+            asm volatile("s_barrier" ::: "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the look-ahead reads of the (clamped) stage past the end
+    } else {
     for (int hb = 0; hb < H; hb += 2) {
         const uint32_t s0 = lds0 + (uint32_t)(hb % LW_STAGES) * LW_SLOT, s1 = lds0 + (uint32_t)((hb + 1) % LW_STAGES) * LW_SLOT;
         LSTAMP(0);
@@ -319,7 +485,14 @@ __global__ __launch_bounds__(512) void gemm_lw_kernel(const gemm_mats mats, int 
         LSTAMP(0);
         asm volatile("s_barrier" ::: "memory");
     }
+    }
 
+#if GEMM_DIAG == 4 // shader clock against the 100 MHz reference over the whole K loop
+    if (blockIdx.x == 0 && lane == 0 && wave == 0) {
+        g_lw_stamps[126] = __builtin_amdgcn_s_memtime() - clk0;
+        g_lw_stamps[127] = __builtin_amdgcn_s_memrealtime() - real0;
+    }
+#endif
     // ---- store: reg r of token tile nt is token n0 + 32nt + (r&3) + 8(r>>2) + 4h, weight row 32rt + i
     if (active) {
         const long row = rt * 32 + i;
@@ -339,26 +512,34 @@ __global__ __launch_bounds__(512) void gemm_lw_kernel(const gemm_mats mats, int 
                 }
         }
     }
+#if GEMM_DIAG == 4 // cycles of this wave's C store, to the last write acknowledged
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (blockIdx.x == 0 && lane == 0 && wave == 0)
+        g_lw_stamps[125] = __builtin_amdgcn_s_memtime() - clk0 - g_lw_stamps[126];
+#endif
 }
 
 hipError_t lfamd_lw_go(int Atype, const gemm_mats &mats, int nb, const void *Xh, const void *d8T, const void *Xm, long n, long n_pad,
-                       int n_rb, int n_ct, unsigned n_wg, int moe, hipStream_t s) {
-#define LW_GO(T, M)                                                                                                    \
-    gemm_lw_kernel<T, M><<<n_wg, 512, 0, s>>>(mats, nb, (const _Float16 *)Xh, (const float *)d8T, (const _Float16 *)Xm, n, n_pad, \
-                                              n_rb, n_ct)
-    if (Atype == LFAMD_TYPE_Q4_K) {
-        if (moe)
-            LW_GO(LFAMD_TYPE_Q4_K, true);
-        else
-            LW_GO(LFAMD_TYPE_Q4_K, false);
-    } else if (Atype == LFAMD_TYPE_Q5_K) {
-        if (moe)
-            LW_GO(LFAMD_TYPE_Q5_K, true);
-        else
-            LW_GO(LFAMD_TYPE_Q5_K, false);
-    } else {
+                       int n_rb, int n_ct, unsigned n_wg, int moe, int fast, hipStream_t s) {
+#define LW_GO(T, M, F)                                                                                                 \
+    gemm_lw_kernel<T, M, F><<<n_wg, 512, 0, s>>>(mats, nb, (const _Float16 *)Xh, (const float *)d8T, (const _Float16 *)Xm, n, n_pad, \
+                                                 n_rb, n_ct)
+#define LW_GO2(T)                                                                                                      \
+    do {                                                                                                               \
+        if (moe)                                                                                                       \
+            LW_GO(T, true, false);                                                                                     \
+        else if (fast)                                                                                                 \
+            LW_GO(T, false, true);                                                                                     \
+        else                                                                                                           \
+            LW_GO(T, false, false);                                                                                    \
+    } while (0)
+    if (Atype == LFAMD_TYPE_Q4_K)
+        LW_GO2(LFAMD_TYPE_Q4_K);
+    else if (Atype == LFAMD_TYPE_Q5_K)
+        LW_GO2(LFAMD_TYPE_Q5_K);
+    else
         return hipErrorInvalidValue;
-    }
+#undef LW_GO2
 #undef LW_GO
     return hipGetLastError();
 }

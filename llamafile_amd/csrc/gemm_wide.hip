@@ -16,18 +16,25 @@ hipError_t lfamd_wide_go_f16(WIDE_ARGS);
 hipError_t lfamd_wide_go_bf16(WIDE_ARGS);
 
 hipError_t lfamd_lw_go(int Atype, const gemm_mats &mats, int nb, const void *Xh, const void *d8T, const void *Xm, long n, long n_pad,
-                       int n_rb, int n_ct, unsigned n_wg, int moe, hipStream_t s);
+                       int n_rb, int n_ct, unsigned n_wg, int moe, int fast, hipStream_t s);
 
-// Q4_K / Q5_K without K split run the loader-wave body (gemm_lw.hip) unless the caller asks for the plain one
-static int g_plain_wide = 0;
-extern "C" void lfamd_gemm_wide_plain(int on) {
-    g_plain_wide = on;
+// Q4_K / Q5_K without K split run the loader-wave body (gemm_lw.hip) unless the caller asks for the plain one.
+// mode bit 0: plain body; bit 1: the activations were staged SCALED (pack.hip, prep mode 2) for the scaled-operand
+// loader-wave body — only set when lfamd_gemm_wide_scaled_ok() said that body will run.
+static int g_plain_wide = 0, g_scaled = 0;
+extern "C" void lfamd_gemm_wide_mode(int mode) {
+    g_plain_wide = mode & 1, g_scaled = (mode >> 1) & 1;
+}
+static bool lw_allowed() {
+    static const bool env_plain = getenv("LFAMD_GEMM_NO_LW") != nullptr;
+    return !g_plain_wide && !env_plain;
 }
 
 static hipError_t wide_go(int Atype, WIDE_ARGS) {
-    static const bool env_plain = getenv("LFAMD_GEMM_NO_LW") != nullptr;
-    if ((Atype == LFAMD_TYPE_Q4_K || Atype == LFAMD_TYPE_Q5_K) && ks == 1 && !g_plain_wide && !env_plain)
-        return lfamd_lw_go(Atype, mats, nb, Xh, d8T, Xm, n, n_pad, n_rb, n_ct, n_wg, moe, s);
+    if ((Atype == LFAMD_TYPE_Q4_K || Atype == LFAMD_TYPE_Q5_K) && ks == 1 && lw_allowed())
+        return lfamd_lw_go(Atype, mats, nb, Xh, d8T, Xm, n, n_pad, n_rb, n_ct, n_wg, moe, moe ? 0 : g_scaled, s);
+    if (g_scaled)
+        return hipErrorInvalidValue; // scaled activations reached a body that expects integer codes
     switch (Atype) {
     case LFAMD_TYPE_Q4_K:
         return lfamd_wide_go_q4k(mats, nb, Xh, d8T, Xm, n, n_pad, n_rb, n_ct, ks, nbs, n_wg, moe, s);
@@ -78,6 +85,17 @@ static int wide_ksplit(int n_tiles, int nb) {
 extern "C" int lfamd_gemm_wide_ksplit(long m, long k, long n_pad) {
     const int n_rb = (int)((m + 127) / 128), n_ct = (int)(n_pad / WD_COLS);
     return wide_ksplit(n_rb * n_ct, (int)(k / 256));
+}
+
+// Will a wide launch of these (fused) matrices run the loader-wave body, i.e. may the caller stage scaled activations?
+extern "C" int lfamd_gemm_wide_scaled_ok(int Atype, int count, const long *m, long k, long n_pad, int plain) {
+    static const bool env_off = getenv("LFAMD_GEMM_NO_SCALED") != nullptr, env_plain = getenv("LFAMD_GEMM_NO_LW") != nullptr;
+    if (env_off || env_plain || plain || (Atype != LFAMD_TYPE_Q4_K && Atype != LFAMD_TYPE_Q5_K))
+        return 0;
+    int n_rb = 0;
+    for (int j = 0; j < count; j++)
+        n_rb += (int)((m[j] + 127) / 128);
+    return wide_ksplit(n_rb * (int)(n_pad / WD_COLS), (int)(k / 256)) == 1;
 }
 
 extern "C" hipError_t lfamd_launch_gemm_wide_multi(int Atype, int count, const void *const *A, const long *m, long k,

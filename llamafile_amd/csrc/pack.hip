@@ -301,7 +301,12 @@ __global__ void pack_raw_kernel(const uint8_t *__restrict__ raw, size_t raw_row_
 //                             (|S_j| <= 4096) the split S_j = 64*hi_j + lo_j, lo in [0,63]:
 //                             elements 0..7 = lo_j, 8..15 = hi_j (both exact in f16)
 
-// mins16: Xm holds the 16 bsums themselves (exact in f16, |sum| <= 2032) for the types with 16-wide sub-blocks (Q2_K)
+// mins16 == 1: Xm holds the 16 bsums themselves (exact in f16, |sum| <= 2032) for the types with 16-wide sub-blocks (Q2_K)
+// mins16 == 2: SCALED staging for the scaled-operand body (gemm_lw.hip, FAST): Xh = f16(d8 * code), Xm = f16(d8 * S_j) in
+//              elements 0..7 and zeros in 8..15 — one f16 rounding per operand, no per-super-block scaling in the GEMM
+__device__ static inline _Float16 sat_f16(float v) {
+    return (_Float16)fminf(fmaxf(v, -65504.0f), 65504.0f);
+}
 __global__ void prep_q8k_kernel(const uint8_t *__restrict__ B, size_t b_row_bytes, long n, long n_pad, int nb,
                                 _Float16 *__restrict__ Xh, float *__restrict__ d8T, _Float16 *__restrict__ Xm, int mins16,
                                 const int32_t *__restrict__ src_idx) {
@@ -315,11 +320,18 @@ __global__ void prep_q8k_kernel(const uint8_t *__restrict__ B, size_t b_row_byte
     if (src >= 0) {
         const lfamd_block_q8_K *y = (const lfamd_block_q8_K *)(B + src * b_row_bytes) + b;
         uint32_t q = *(const uint32_t *)((const uint8_t *)y->qs + 4 * t); // 292-byte blocks are 4-aligned
+        const float xs = mins16 == 2 ? y->d : 1.0f;
         for (int e = 0; e < 4; e++)
-            xo[4 * t + e] = (_Float16)(int)(int8_t)(q >> (8 * e));
+            xo[4 * t + e] = sat_f16((float)(int)(int8_t)(q >> (8 * e)) * xs);
         if (t == 0)
             d8T[(size_t)b * n_pad + tok] = y->d;
-        if (mins16) {
+        if (mins16 == 2) {
+            if (t < 8) {
+                _Float16 *mo = Xm + ((size_t)b * n_pad + tok) * 16;
+                mo[t] = sat_f16((float)((int)y->bsums[2 * t] + (int)y->bsums[2 * t + 1]) * xs);
+                mo[8 + t] = (_Float16)0;
+            }
+        } else if (mins16) {
             if (t < 16)
                 Xm[((size_t)b * n_pad + tok) * 16 + t] = (_Float16)(int)y->bsums[t];
         } else if (t < 8) {
@@ -396,15 +408,22 @@ __global__ __launch_bounds__(64) void prep_f32_kernel(const uint8_t *__restrict_
         }
         d = 1.0f / iscale;
     }
-    half4_t h4 = {(_Float16)q[0], (_Float16)q[1], (_Float16)q[2], (_Float16)q[3]};
+    const float xs = mins16 == 2 ? d : 1.0f;
+    half4_t h4 = {sat_f16((float)q[0] * xs), sat_f16((float)q[1] * xs), sat_f16((float)q[2] * xs), sat_f16((float)q[3] * xs)};
     *(half4_t *)(xo + 4 * t) = h4;
     int S = q[0] + q[1] + q[2] + q[3]; // pair sum j = t/8 covers codes 32j..32j+31 = lanes 8j..8j+7
     S += __shfl_xor(S, 1, 64);
     S += __shfl_xor(S, 2, 64);
-    if (mins16 && (t & 3) == 0) // bsums[t/4]: codes 16(t/4) .. +15
+    if (mins16 == 1 && (t & 3) == 0) // bsums[t/4]: codes 16(t/4) .. +15
         Xm[((size_t)b * n_pad + tok) * 16 + (t >> 2)] = (_Float16)S;
     S += __shfl_xor(S, 4, 64);
-    if (!mins16 && (t & 7) == 0) {
+    if (mins16 == 2) {
+        if ((t & 7) == 0) {
+            _Float16 *mo = Xm + ((size_t)b * n_pad + tok) * 16;
+            mo[t >> 3] = sat_f16((float)S * xs);
+            mo[8 + (t >> 3)] = (_Float16)0;
+        }
+    } else if (!mins16 && (t & 7) == 0) {
         int j = t >> 3;
         int lo = S & 63, hi = (S - lo) / 64;
         _Float16 *mo = Xm + ((size_t)b * n_pad + tok) * 16;

@@ -13,6 +13,9 @@ torch.cuda.synchronize()
 buf = (C.c_ulonglong * 256)()
 print("rc", _hip.lib().lfamd_debug_lw_stamps(buf))
 a = np.array(buf[:], dtype=np.int64).reshape(2, 128)
+print("memtime", a[0,126], "realtime", a[0,127], "clock MHz", a[0,126] / max(a[0,127],1) * 100)
+print("store cycles", a[0,125])
+a[0,125:] = 0
 t0 = a[a > 0].min()
 for r, name in ((0, "compute"), (1, "loader")):
     t = a[r][a[r] > 0]
