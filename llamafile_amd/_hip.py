@@ -43,6 +43,7 @@ _SIGS = {
     "lfamd_stream_sync": (_i, [_vp]),
     "lfamd_packed_size": (_sz, [_i, _l, _l]),
     "lfamd_pack_weights": (_i, [_i, _l, _l, _vp, _sz, _vp, _vp]),
+    "lfamd_scaled_gemm_ok": (_i, [_i, _l, _l, _vp, _vp]),
     "lfamd_quantize_rows": (_i, [_i, _vp, _l, _l, _sz, _vp, _sz, _vp]),
     "lfamd_mul_mat_workspace": (_sz, [_i, _l, _l, _l]),
     "lfamd_mul_mat": (_i, [_i, _vp, _l, _l, _i, _vp, _sz, _l, _vp, _l, _vp, _sz, _u, _vp]),

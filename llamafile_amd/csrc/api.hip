@@ -35,6 +35,7 @@ hipError_t lfamd_launch_gemm_q80(const void *, long, long, int, const void *, si
                                  hipStream_t);
 size_t lfamd_gemm_q80_workspace(long, long);
 void lfamd_gemm_wide_mode(int);
+hipError_t lfamd_launch_scaled_ok(int, long, long, const void *, int *, hipStream_t);
 int lfamd_gemm_wide_scaled_ok(int, int, const long *, long, long, int);
 hipError_t lfamd_launch_gemm_wide_multi(int, int, const void *const *, const long *, long, const void *, const void *,
                                         const void *, long, long, float *const *, const long *, hipStream_t);
@@ -209,6 +210,29 @@ int lfamd_pack_weights(int type, long rows, long cols, const void *d_raw, size_t
         HIPCHK(lfamd_launch_pack_raw(d_raw, raw_row_bytes, rows, lfamd_row_size(type, cols), d_packed, s), "pack_raw");
     }
     return LFAMD_OK;
+}
+
+int lfamd_scaled_gemm_ok(int type, long rows, long cols, const void *d_packed, void *stream) {
+    (void)hipGetLastError();
+    if (!type_known(type))
+        return fail(LFAMD_ERR_UNSUPPORTED, "scaled_gemm_ok: unsupported ggml type%s", "");
+    if ((type != LFAMD_TYPE_Q4_K && type != LFAMD_TYPE_Q5_K) || rows <= 0 || cols <= 0)
+        return 1;
+    if (cols % 256 || !d_packed)
+        return fail(LFAMD_ERR_INVALID, "scaled_gemm_ok: bad shape%s", "");
+    hipStream_t s = (hipStream_t)stream;
+    int *d_flag = nullptr, h_flag = 0;
+    HIPCHK(hipMalloc(&d_flag, sizeof(int)), "hipMalloc");
+    hipError_t e = hipMemsetAsync(d_flag, 0, sizeof(int), s);
+    if (e == hipSuccess)
+        e = lfamd_launch_scaled_ok(type, rows, cols, d_packed, d_flag, s);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(&h_flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(s);
+    (void)hipFree(d_flag);
+    HIPCHK(e, "scaled_gemm_ok");
+    return h_flag ? 0 : 1;
 }
 
 int lfamd_quantize_rows(int vec_dot_type, const float *d_x, long nrows, long cols, size_t x_row_bytes, void *d_y,

@@ -418,8 +418,8 @@ __global__ __launch_bounds__(512) void gemm_lw_kernel(const gemm_mats mats, int 
                 if (t8 + 1 < 8)
                     wn = dq(halfc, t8 + 1);
 #pragma unroll
-                for (int nt = 0; nt < 4; nt++)
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F[t8 & 3][nt], wf, acc[nt], 0, 0, 0);
+                for (int nt = 0; nt < 4; nt++) // weights are the A operand here: a lane ends up with 4 consecutive ROWS per token
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, F[t8 & 3][nt], acc[nt], 0, 0, 0);
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); // one MFMA
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(512) void gemm_lw_kernel(const gemm_mats mats, int 
                 }
 #pragma unroll
                 for (int nt = 0; nt < 4; nt++)
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fxm[nt], wm.v, acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wm.v, fxm[nt], acc[nt], 0, 0, 0);
                 hd = hdn, hq = hqn;
             }
             qa = qan, qb = qbn;
@@ -493,8 +493,34 @@ __global__ __launch_bounds__(512) void gemm_lw_kernel(const gemm_mats mats, int 
         g_lw_stamps[127] = __builtin_amdgcn_s_memrealtime() - real0;
     }
 #endif
-    // ---- store: reg r of token tile nt is token n0 + 32nt + (r&3) + 8(r>>2) + 4h, weight row 32rt + i
-    if (active) {
+    // ---- store.  FAST: lane (i, h) holds token n0 + 32nt + i, reg r = weight row 32rt + (r&3) + 8(r>>2) + 4h: four
+    // consecutive rows per register quad -> 16 dwordx4 stores per wave instead of 64 dword stores (the store tail is
+    // issue-bound: 6.1k cycles of a 62k-cycle work-group with dword stores)
+    if constexpr (FAST) {
+        if (active) {
+            const bool vec = (ldc & 3) == 0 && (m & 3) == 0 && (((uintptr_t)C) & 15) == 0;
+#pragma unroll
+            for (int nt = 0; nt < 4; nt++) {
+                const long tok = n0 + nt * 32 + i;
+                if (tok >= n)
+                    continue;
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const long row0 = rt * 32 + 8 * g + 4 * h;
+                    float *dst = C + tok * ldc + row0;
+                    if (vec) {
+                        if (row0 < m)
+                            *(float4 *)dst = make_float4(acc[nt][4 * g], acc[nt][4 * g + 1], acc[nt][4 * g + 2], acc[nt][4 * g + 3]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; e++)
+                            if (row0 + e < m)
+                                dst[e] = acc[nt][4 * g + e];
+                    }
+                }
+            }
+        }
+    } else if (active) {
         const long row = rt * 32 + i;
         if (row < m) {
 #pragma unroll

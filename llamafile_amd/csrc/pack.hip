@@ -657,3 +657,29 @@ hipError_t lfamd_launch_prep_q8k(const void *B, size_t b_row_bytes, long n, long
     return hipGetLastError();
 }
 }
+
+// ---------------------------------------------------------------------------------------------
+// Range check for the scaled-operand GEMM (gemm_lw.hip FAST): every row header of a P4K / P5K image.
+
+__global__ void scaled_ok_kernel(const uint8_t *__restrict__ img, long tiles, int tile_bytes, int *__restrict__ bad) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; // (tile, row in tile)
+    if (idx >= tiles * 32)
+        return;
+    const uint32_t dd = *(const uint32_t *)(img + (size_t)(idx >> 5) * tile_bytes + P4K_HDR + (idx & 31) * 16);
+    union {
+        uint16_t u;
+        _Float16 h;
+    } d, dm;
+    d.u = (uint16_t)(dd & 0xffff), dm.u = (uint16_t)(dd >> 16);
+    const float fd = fabsf((float)d.h), fm = fabsf((float)dm.h);
+    if (!(fd * 63.0f < 64.0f) || !(fm * 63.0f <= 65504.0f)) // also catches NaN / inf
+        atomicOr(bad, 1);
+}
+
+extern "C" hipError_t lfamd_launch_scaled_ok(int type, long rows, long cols, const void *packed, int *d_flag, hipStream_t s) {
+    const long tiles = ((rows + 31) / 32) * (cols / 256);
+    const int tile_bytes = type == LFAMD_TYPE_Q5_K ? P5K_TILE : P4K_TILE;
+    const long threads = tiles * 32;
+    scaled_ok_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>((const uint8_t *)packed, tiles, tile_bytes, d_flag);
+    return hipGetLastError();
+}

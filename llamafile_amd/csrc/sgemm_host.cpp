@@ -39,6 +39,7 @@ struct HipApi {
     decltype(&lfamd_stream_sync) sync;
     decltype(&lfamd_packed_size) packed_size;
     decltype(&lfamd_pack_weights) pack_weights;
+    decltype(&lfamd_scaled_gemm_ok) scaled_ok;
     decltype(&lfamd_quantize_rows) quantize_rows;
     decltype(&lfamd_mul_mat_workspace) mul_mat_workspace;
     decltype(&lfamd_mul_mat) mul_mat;
@@ -58,6 +59,7 @@ struct CachedWeights {
     uint64_t fingerprint;
     void *d_packed;
     size_t bytes;
+    bool exact_only = false; // block scales outside the scaled-operand GEMM's range (lfamd_scaled_gemm_ok)
 };
 
 struct State {
@@ -110,6 +112,7 @@ void load_module() {
               import(dso, "lfamd_memcpy_h2d", a.h2d, err) && import(dso, "lfamd_memcpy_d2h", a.d2h, err) &&
               import(dso, "lfamd_stream_sync", a.sync, err) && import(dso, "lfamd_packed_size", a.packed_size, err) &&
               import(dso, "lfamd_pack_weights", a.pack_weights, err) &&
+              import(dso, "lfamd_scaled_gemm_ok", a.scaled_ok, err) &&
               import(dso, "lfamd_quantize_rows", a.quantize_rows, err) &&
               import(dso, "lfamd_mul_mat_workspace", a.mul_mat_workspace, err) &&
               import(dso, "lfamd_mul_mat", a.mul_mat, err) &&
@@ -205,6 +208,12 @@ const CachedWeights *get_weights(int type, const void *A, long rows, long cols, 
         g.api.free_(w.d_packed);
         return nullptr;
     }
+    const int in_range = g.api.scaled_ok(type, rows, cols, w.d_packed, nullptr);
+    if (in_range < 0) {
+        g.api.free_(w.d_packed);
+        return nullptr;
+    }
+    w.exact_only = in_range == 0;
     return &(g.cache[A] = w);
 }
 
@@ -261,7 +270,7 @@ bool run_mul_mat(int Atype, const void *A, long m, long kelems, size_t a_row_byt
         if (g.api.h2d(g.c.p, C, cbytes, nullptr) != LFAMD_OK)
             return false;
     if (g.api.mul_mat(Atype, w->d_packed, m, kelems, Btype, g.b.p, b_row_bytes, n, (float *)g.c.p, ldc, g.ws.p, g.ws.cap,
-                      flags_now(), nullptr) != LFAMD_OK)
+                      flags_now() | (w->exact_only ? LFAMD_FLAG_PRECISE : 0u), nullptr) != LFAMD_OK)
         return false;
     if (g.api.d2h(C, g.c.p, cbytes, nullptr) != LFAMD_OK)
         return false;

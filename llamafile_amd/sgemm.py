@@ -58,6 +58,7 @@ class PackedWeights:
     rows: int
     cols: int
     data: torch.Tensor  # uint8, cuda
+    exact_only: bool = False  # Q4_K / Q5_K block scales outside the scaled-operand GEMM's range (lfamd_scaled_gemm_ok)
 
     @property
     def nbytes(self) -> int:
@@ -81,7 +82,14 @@ def upload_weights(t: int, raw, rows: int, cols: int, device="cuda") -> PackedWe
         raise _hip.LfamdError(f"unsupported weight type {T.NAMES.get(t, t)} or bad shape")
     out = torch.empty(max(size, 16), dtype=torch.uint8, device=raw.device)
     _hip.check(L.lfamd_pack_weights(t, rows, cols, _ptr(raw), raw.shape[1], _ptr(out), _stream()), "lfamd_pack_weights")
-    return PackedWeights(t, rows, cols, out[:size] if size else out[:0])
+    W = PackedWeights(t, rows, cols, out[:size] if size else out[:0])
+    if t in (T.Q4_K, T.Q5_K) and rows and cols:
+        # scaled-operand batches need |d| < 64/63 (include/lfamd_hip.h): out-of-range matrices always run exact
+        ok = L.lfamd_scaled_gemm_ok(t, rows, cols, _ptr(out), _stream())
+        if ok < 0:
+            raise _hip.LfamdError("lfamd_scaled_gemm_ok failed")
+        W.exact_only = ok == 0
+    return W
 
 
 def quantize_rows(vec_dot_type: int, x: torch.Tensor) -> torch.Tensor:
@@ -111,6 +119,8 @@ def mul_mat(W: PackedWeights, B: torch.Tensor, Btype: int, n: int | None = None,
     if out is None:
         out = torch.empty((n, ldc), dtype=torch.float32, device=B.device)
     flags = host_variant_flags() if flags is None else flags
+    if getattr(W, "exact_only", False):
+        flags |= _hip.FLAG_PRECISE
     need = L.lfamd_mul_mat_workspace(W.type, W.rows, W.cols, n)
     if need and (workspace is None or workspace.numel() < need):
         workspace = torch.empty(need, dtype=torch.uint8, device=B.device)

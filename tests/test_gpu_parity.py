@@ -117,6 +117,28 @@ def test_loader_wave_gemm_full_grid(gpu, oracle, t, f32in):
         assert err <= tol, (T.NAMES[t], flags, err)
 
 
+@pytest.mark.parametrize("t", [T.Q4_K, T.Q5_K], ids=lambda t: T.NAMES[t])
+def test_out_of_range_scales_run_exact(gpu, oracle, t):
+    """lfamd_scaled_gemm_ok: block scales beyond the scaled-operand body's f16 range (|d| * 63 >= 64) are detected at
+    upload and the matrix then always takes the exact integer-code path; in-range matrices report 1."""
+    from llamafile_amd import synth
+    m, n, k = 1000, 3100, 1024
+    A = synth.random_weights(t, m, k, 5100 + t).copy()
+    blk = T.row_size(t, 256)
+    hdr = A.reshape(m, k // 256, blk)[:, :, :2].view(np.float16)  # d of every super-block
+    assert gpu.upload_weights(t, A, m, k).exact_only is False
+    hdr[17, 2, 0] = np.float16(1.5)
+    x = synth.random_activations(n, k, 5101)
+    B = synth.quantize_activations(T.Q8_K, x)
+    ok, G = oracle.sgemm(t, A, T.Q8_K, B, m, n, k, nth=8)
+    assert ok == 1
+    W = gpu.upload_weights(t, A, m, k)
+    assert W.exact_only is True
+    C = gpu.mul_mat(W, torch.from_numpy(B).cuda(), T.Q8_K)
+    torch.cuda.synchronize()
+    assert rel_err(C.cpu().numpy(), G) <= GEMM_TOL[t]
+
+
 @pytest.mark.parametrize("t", [T.Q4_K, T.Q5_K, T.Q6_K], ids=lambda t: T.NAMES[t])
 def test_mfma_bodies_agree_and_repeat(gpu, t):
     """Same inputs -> the wide body gives identical bits on every run (no atomics in the default K split), and

@@ -17,6 +17,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from llamafile_amd import _hip, ggml_types as T, sgemm, synth  # noqa: E402
 
 
+EXTRA_FLAGS = 0
+
+
 def run(tname, m, k, n, copies, iters, f32in=True, graph=True):
     t = T.BY_NAME[tname]
     L = _hip.lib()
@@ -36,7 +39,7 @@ def run(tname, m, k, n, copies, iters, f32in=True, graph=True):
         bt, brb = vdt, B.stride(0)
     out = torch.empty((n, m), dtype=torch.float32, device="cuda")
     ws = torch.empty(max(16, sgemm.workspace_bytes(t, m, k, n)), dtype=torch.uint8, device="cuda")
-    flags = sgemm.host_variant_flags()
+    flags = sgemm.host_variant_flags() | EXTRA_FLAGS
 
     def launch_all():
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -75,8 +78,10 @@ if __name__ == "__main__":
     p.add_argument("--cases", default="decode")
     p.add_argument("--iters", type=int, default=20)
     p.add_argument("--copies", type=int, default=0)
+    p.add_argument("--flags", type=int, default=0, help="extra LFAMD_FLAG_* bits (8 narrow, 16 wide, 32 plain, 2 precise)")
     p.add_argument("--prequant", action="store_true", help="activations already in vec_dot format")
     a = p.parse_args()
+    EXTRA_FLAGS = a.flags
     sgemm.init(0)
     if a.cases == "decode":
         cases = [("Q4_K", 4096, 4096, 1), ("Q4_K", 1024, 4096, 1), ("Q4_K", 14336, 4096, 1), ("Q4_K", 4096, 14336, 1),
