@@ -34,9 +34,10 @@ hipError_t lfamd_launch_gemv_multi(int, int, const void *const *, const long *, 
 hipError_t lfamd_launch_gemm_q80(const void *, long, long, int, const void *, size_t, long, float *, long, void *, int, int,
                                  hipStream_t);
 size_t lfamd_gemm_q80_workspace(long, long);
+#define LW_MIN_TILES 64 // 128 x 128 tiles from which the 128 x 64 loader-wave body beats the split-K body (measured)
 void lfamd_gemm_wide_mode(int);
 hipError_t lfamd_launch_scaled_ok(int, long, long, const void *, int *, hipStream_t);
-int lfamd_gemm_wide_scaled_ok(int, int, const long *, long, long, int);
+int lfamd_gemm_wide_scaled_ok(int, int);
 hipError_t lfamd_launch_gemm_wide_multi(int, int, const void *const *, const long *, long, const void *, const void *,
                                         const void *, long, long, float *const *, const long *, hipStream_t);
 hipError_t lfamd_launch_gemm_wide(int, const void *, long, long, const void *, const void *, const void *, long, long,
@@ -366,13 +367,15 @@ int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const v
         // 128 x 64 split-K body (gemm_mfma.hip) for smaller grids.  LFAMD_GEMM_BODY=narrow|wide forces one.
         static const char *body = getenv("LFAMD_GEMM_BODY");
         const long tiles128 = ((m + 127) / 128) * (long)(n_pad / 128);
+        // Q4_K / Q5_K on the loader-wave body: scaled operands (one f16 rounding each, ~1e-4 relative) unless the
+        // caller wants the exact integer-code arithmetic (LFAMD_FLAG_PRECISE).  That body has a 128 x 64 tile for
+        // the grids the 128 x 128 tile cannot fill, so it also replaces the split-K body down to LW_MIN_TILES.
+        const int can_scale = !precise && lfamd_gemm_wide_scaled_ok(Atype, plain);
         const bool narrow = (flags & LFAMD_FLAG_GEMM_NARROW) ? true
                             : (flags & LFAMD_FLAG_GEMM_WIDE) ? false
                             : body                           ? body[0] == 'n'
-                                                             : tiles128 < 192;
-        // Q4_K / Q5_K on the loader-wave body: scaled operands (one f16 rounding each, ~1e-4 relative) unless the
-        // caller wants the exact integer-code arithmetic (LFAMD_FLAG_PRECISE)
-        const int scaled = (!narrow && !precise) ? lfamd_gemm_wide_scaled_ok(Atype, 1, &m, k, (long)n_pad, plain) : 0;
+                                                             : (tiles128 < 192 && !(can_scale && tiles128 >= LW_MIN_TILES));
+        const int scaled = !narrow && can_scale;
         lfamd_gemm_wide_mode(plain | (scaled << 1));
         if (Btype == LFAMD_TYPE_F32)
             HIPCHK(lfamd_launch_prep_f32(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, scaled ? 2 : 0, nullptr, s), "prep_f32");
@@ -516,7 +519,7 @@ int lfamd_mul_mat_multi(int Atype, int count, const void *const *d_A, const long
             void *Xh = ws;
             void *d8T = ws + align_up(n_pad * (size_t)k * 2, 256);
             void *Xm = (uint8_t *)d8T + align_up(nb * n_pad * 4, 256);
-            const int scaled = (flags & LFAMD_FLAG_PRECISE) ? 0 : lfamd_gemm_wide_scaled_ok(Atype, count, m, k, (long)n_pad, plain);
+            const int scaled = (flags & LFAMD_FLAG_PRECISE) ? 0 : lfamd_gemm_wide_scaled_ok(Atype, plain);
             lfamd_gemm_wide_mode(plain | (scaled << 1));
             if (Btype == LFAMD_TYPE_F32)
                 HIPCHK(lfamd_launch_prep_f32(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, scaled ? 2 : 0, nullptr, s), "prep_f32");

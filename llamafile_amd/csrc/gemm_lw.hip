@@ -39,11 +39,15 @@ extern "C" int lfamd_debug_lw_stamps(unsigned long long *dst) {
 #define LSTAMP(role)
 #endif
 
-template <int TYPE, bool MOE, bool FAST>
+// NT = token tiles of 32 per work-group: 4 (128 x 128 tile) or, scaled-operand body only, 2 (128 x 64: grids of 96 .. 191
+// tiles of 128 x 128 — attn_output, ffn_down of an 8B model at 512 tokens — fill the 256 CUs with these instead)
+template <int TYPE, bool MOE, bool FAST, int NT>
 __global__ __launch_bounds__(512) void gemm_lw_kernel(const gemm_mats mats, int nb, const _Float16 *__restrict__ Xh,
                                                       const float *__restrict__ d8T, const _Float16 *__restrict__ Xm, long n,
                                                       long n_pad, int n_rb, int n_ct) {
     static_assert(TYPE == LFAMD_TYPE_Q4_K || TYPE == LFAMD_TYPE_Q5_K, "resident Q4_K-family layouts only");
+    static_assert(NT == 4 || (NT == 2 && FAST && !MOE), "the 64-token tile exists for the scaled-operand body only");
+    constexpr int COLS = 32 * NT;
     constexpr bool Q5 = TYPE == LFAMD_TYPE_Q5_K;
     constexpr int TILE = Q5 ? P5K_TILE : P4K_TILE;
     __shared__ __attribute__((aligned(16))) uint8_t lds[LW_STAGES * LW_SLOT + 16];
@@ -83,7 +87,7 @@ __global__ __launch_bounds__(512) void gemm_lw_kernel(const gemm_mats mats, int 
         A = mats.A[mj];
         C = mats.C[mj];
         m = mats.m[mj], ldc = mats.ldc[mj];
-        n0 = (long)ct * WD_COLS;
+        n0 = (long)ct * COLS;
     }
     const long n_row_tiles = (m + 31) / 32;
     const int H = 2 * nb; // half super-blocks
@@ -103,10 +107,10 @@ __global__ __launch_bounds__(512) void gemm_lw_kernel(const gemm_mats mats, int 
         const long rtl = (long)rb * 4 + lw; // the row tile whose weights this wave copies
         const uint8_t *wt0 = A + (size_t)(rtl < n_row_tiles ? rtl : 0) * nb * TILE;
         // activation pieces: piece p = 8 lw + e holds token rows 4p .. 4p+3; lane = (row 4p + (lane >> 4), slot lane & 15)
-        uint32_t xo[8];
+        uint32_t xo[2 * NT];
 #pragma unroll
-        for (int e = 0; e < 8; e++) {
-            const int row = 4 * (8 * lw + e) + (lane >> 4);
+        for (int e = 0; e < 2 * NT; e++) {
+            const int row = 4 * (2 * NT * lw + e) + (lane >> 4);
             xo[e] = (uint32_t)(row * 512 + (((lane & 15) ^ (row & 15)) * 16));
         }
         const uint32_t xmo = (uint32_t)((32 * lw + (lane >> 1)) * 32 + (lane & 1) * 16);
@@ -122,8 +126,8 @@ __global__ __launch_bounds__(512) void gemm_lw_kernel(const gemm_mats mats, int 
             const uint32_t slot = lds0 + (uint32_t)(hb % LW_STAGES) * LW_SLOT;
             const uint8_t *xs = uniform_ptr(xbase + (size_t)b * n_pad * 512 + half * 256);
 #pragma unroll
-            for (int e = 4 * part; e < 4 * part + 4; e++)
-                glds1x16(xs, slot + LW_X + (8 * lw + e) * 1024, xo[e]);
+            for (int e = NT * part; e < NT * part + NT; e++)
+                glds1x16(xs, slot + LW_X + (2 * NT * lw + e) * 1024, xo[e]);
             if constexpr (part == 1) {
                 const uint8_t *tile = uniform_ptr(wt0 + (size_t)b * TILE);
                 const uint8_t *wg0 = uniform_ptr(tile + (2 * half) * 1024), *wg1 = uniform_ptr(tile + (2 * half + 1) * 1024);
@@ -134,8 +138,10 @@ __global__ __launch_bounds__(512) void gemm_lw_kernel(const gemm_mats mats, int 
                     glds1x16(uniform_ptr(tile + P4K_HDR), slot + LW_HDR + lw * 1024, (uint32_t)((lane & 31) * 16));
                     if constexpr (Q5)
                         glds1x16(uniform_ptr(tile + P5K_QH), slot + LW_QH + lw * 1024, (uint32_t)(lane * 16));
-                    glds1x4(uniform_ptr(d8T + (size_t)b * n_pad + n0), slot + LW_D8 + (lw & 1) * 256, (uint32_t)((lw & 1) * 256 + lane * 4));
-                    glds1x16(uniform_ptr(xmbase + (size_t)b * n_pad * 32), slot + LW_XM + lw * 1024, xmo);
+                    if constexpr (!FAST)
+                        glds1x4(uniform_ptr(d8T + (size_t)b * n_pad + n0), slot + LW_D8 + (lw & 1) * 256, (uint32_t)((lw & 1) * 256 + lane * 4));
+                    if (lw < NT) // 32 tokens x 32 B per wave
+                        glds1x16(uniform_ptr(xmbase + (size_t)b * n_pad * 32), slot + LW_XM + lw * 1024, xmo);
                 }
             }
         };
@@ -148,7 +154,7 @@ __global__ __launch_bounds__(512) void gemm_lw_kernel(const gemm_mats mats, int 
         // compute waves poll the counter late in half-step s and fetch their first operands of stage s+1 BEFORE B_s
         // (no LDS round trip without MFMAs in flight at the start of a half-step).
         auto landed = [&]() {
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NT) : "memory"); // only part A of the newest stage in flight
             if (lane == 0)
                 asm volatile("ds_add_u32 %0, %1" ::"v"(flag_addr), "v"(1u) : "memory");
         };
@@ -156,7 +162,7 @@ __global__ __launch_bounds__(512) void gemm_lw_kernel(const gemm_mats mats, int 
         issue(0, H0{}, H1{});
         issue(1, H1{}, H0{});
         issue(1, H1{}, H1{});
-        asm volatile("s_waitcnt vmcnt(10)\n\ts_barrier" ::: "memory"); // stage 0 landed (stage 1 = 10 pieces in flight)
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * NT + 2) : "memory"); // stage 0 landed (stage 1 = 2 NT + 2 pieces in flight)
 #ifdef LW_EXP_NODMA // development: timing without the steady-state DMA (results are garbage)
 #define LW_DMA_IF if (hb == 0)
 #else
@@ -186,9 +192,9 @@ __global__ __launch_bounds__(512) void gemm_lw_kernel(const gemm_mats mats, int 
     const int rw = wave;
     const long rt = (long)rb * 4 + rw;
     const bool active = rt < n_row_tiles;
-    float16_t_ acc[4], tmp[4];
+    float16_t_ acc[NT], tmp[NT];
 #pragma unroll
-    for (int nt = 0; nt < 4; nt++)
+    for (int nt = 0; nt < NT; nt++)
 #pragma unroll
         for (int r = 0; r < 16; r++)
             acc[nt][r] = 0.0f, tmp[nt][r] = 0.0f;
@@ -343,14 +349,21 @@ __global__ __launch_bounds__(512) void gemm_lw_kernel(const gemm_mats mats, int 
         // acc, nothing is scaled per super-block.  The K-step pipeline runs ACROSS the half-step barriers: the first
         // operands of the next stage are fetched during K-steps 6 and 7 of this one (see the loader's protocol).
         u32x4 qa, qb, qan = {0, 0, 0, 0}, qbn = {0, 0, 0, 0}, hdn = {0, 0, 0, 0}, hqn = {0, 0, 0, 0};
-        half8_t F[4][4], fxm[4];
+        half8_t F[4][NT], fxm[NT];
         uint32_t fl = 0;
-        auto read_frags = [&](half8_t(&f)[4], uint32_t slot, int t8) {
+        auto read_frags = [&](half8_t(&f)[NT], uint32_t slot, int t8) {
             const uint32_t a = xoff[t8] + slot;
             dsr16<0>(f[0], a);
             dsr16<8192>(f[1], a);
-            dsr16<16384>(f[2], a);
-            dsr16<24576>(f[3], a);
+            if constexpr (NT == 4) {
+                dsr16<16384>(f[2], a);
+                dsr16<24576>(f[3], a);
+            }
+        };
+        auto pin = [&](half8_t(&f)[NT]) { // the registers of a fragment group are defined from here on (after a counted wait)
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++)
+                asm volatile("" : "+v"(f[nt]));
         };
         auto dq = [&](auto halfc, int t8) -> half8_t { // weight fragment of K-step t8 of a half, from the CURRENT qa/qb/hd/hq
             constexpr int half = decltype(halfc)::value;
@@ -379,27 +392,35 @@ __global__ __launch_bounds__(512) void gemm_lw_kernel(const gemm_mats mats, int 
             using HN = std::integral_constant<int, 1 - half>;
 #pragma unroll
             for (int t8 = 0; t8 < 8; t8++) {
-#define LW_FW(N) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(F[t8 & 3][0]), "+v"(F[t8 & 3][1]), "+v"(F[t8 & 3][2]), "+v"(F[t8 & 3][3]))
+                // counted waits: lgkmcnt(N) = every LDS read older than the N youngest has returned
                 if (t8 < 6) {
                     if (t8 == 4)
                         asm volatile("ds_read_b32 %0, %1" : "=v"(fl) : "v"(flag_addr));
                     read_frags(F[(t8 + 2) & 3], slot, t8 + 2);
                     if (t8 < 4)
-                        LW_FW(8);
+                        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * NT));
                     else
-                        LW_FW(9); // the counter read sits between K-step 5's and K-step 6's fragments
+                        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * NT + 1)); // the counter read sits between K-step 5's and 6's fragments
+                    pin(F[t8 & 3]);
                 } else if (t8 == 6) {
-                    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(F[2][0]), "+v"(F[2][1]), "+v"(F[2][2]), "+v"(F[2][3]), "+v"(fl));
+                    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(fl) : "n"(NT));
+                    pin(F[2]);
                     uint32_t fv = __builtin_amdgcn_readfirstlane(fl);
                     while (fv < need) { // the next stage has not landed yet (rare: the loaders run a stage ahead)
                         asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(fl) : "v"(flag_addr) : "memory");
                         fv = __builtin_amdgcn_readfirstlane(fl);
                     }
-                    if constexpr (half == 1)
-                        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\t"
-                                     "ds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072"
-                                     : "=&v"(fxm[0]), "=&v"(fxm[1]), "=&v"(fxm[2]), "=&v"(fxm[3])
-                                     : "v"(slot_first + xm_off));
+                    if constexpr (half == 1) {
+                        if constexpr (NT == 4)
+                            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\t"
+                                         "ds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072"
+                                         : "=&v"(fxm[0]), "=&v"(fxm[1]), "=&v"(fxm[NT - 2]), "=&v"(fxm[NT - 1])
+                                         : "v"(slot_first + xm_off));
+                        else
+                            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024"
+                                         : "=&v"(fxm[0]), "=&v"(fxm[1])
+                                         : "v"(slot_first + xm_off));
+                    }
                     asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024" : "=&v"(qan), "=&v"(qbn) : "v"(slot_next + wq_off));
                     if constexpr (half == 1) {
                         asm volatile("ds_read_b128 %0, %1" : "=v"(hdn) : "v"(slot_next + hd_off));
@@ -408,29 +429,29 @@ __global__ __launch_bounds__(512) void gemm_lw_kernel(const gemm_mats mats, int 
                     }
                     read_frags(F[0], slot_next, 0);
                 } else {
-                    // younger than K-step 7's fragments: [mins 4] + qa/qb 2 + [header 1 (+ fifth bits 1)] + fragments 4
-                    constexpr int N7 = (half ? 4 : 0) + 2 + (half ? 1 + (Q5 ? 1 : 0) : 0) + 4;
-                    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(F[3][0]), "+v"(F[3][1]), "+v"(F[3][2]), "+v"(F[3][3]) : "n"(N7));
+                    // younger than K-step 7's fragments: [mins NT] + qa/qb 2 + [header 1 (+ fifth bits 1)] + fragments NT
+                    constexpr int N7 = (half ? NT : 0) + 2 + (half ? 1 + (Q5 ? 1 : 0) : 0) + NT;
+                    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N7));
+                    pin(F[3]);
                     read_frags(F[1], slot_next, 1);
                 }
-#undef LW_FW
                 half8_t wn = wf;
                 if (t8 + 1 < 8)
                     wn = dq(halfc, t8 + 1);
 #pragma unroll
-                for (int nt = 0; nt < 4; nt++) // weights are the A operand here: a lane ends up with 4 consecutive ROWS per token
+                for (int nt = 0; nt < NT; nt++) // weights are the A operand here: a lane ends up with 4 consecutive ROWS per token
                     acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, F[t8 & 3][nt], acc[nt], 0, 0, 0);
 #pragma unroll
-                for (int g = 0; g < 4; g++) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); // one MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0); // three VALU in its shadow
+                for (int g = 0; g < NT; g++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, 12 / NT, 0); // its share of the next fragment's VALU
                 }
                 wf = wn;
             }
             // everything older than the two fragment groups of the next stage: its nibbles / header, this super-block's mins
-            asm volatile("s_waitcnt lgkmcnt(8)"
-                         : "+v"(qan), "+v"(qbn), "+v"(hdn), "+v"(hqn), "+v"(fxm[0]), "+v"(fxm[1]), "+v"(fxm[2]), "+v"(fxm[3]));
+            asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(qan), "+v"(qbn), "+v"(hdn), "+v"(hqn) : "n"(2 * NT));
             if constexpr (half == 1) {
+                pin(fxm);
                 uint32_t sc03, sc47, mn03, mn47;
                 q4k_scales_bytes(hd.y, hd.z, hd.w, sc03, sc47, mn03, mn47);
                 const float ndmin = -h2f((uint16_t)(hd.x >> 16));
@@ -443,7 +464,7 @@ __global__ __launch_bounds__(512) void gemm_lw_kernel(const gemm_mats mats, int 
                     wm.p[p] = v;
                 }
 #pragma unroll
-                for (int nt = 0; nt < 4; nt++)
+                for (int nt = 0; nt < NT; nt++)
                     acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wm.v, fxm[nt], acc[nt], 0, 0, 0);
                 hd = hdn, hq = hqn;
             }
@@ -500,7 +521,7 @@ __global__ __launch_bounds__(512) void gemm_lw_kernel(const gemm_mats mats, int 
         if (active) {
             const bool vec = (ldc & 3) == 0 && (m & 3) == 0 && (((uintptr_t)C) & 15) == 0;
 #pragma unroll
-            for (int nt = 0; nt < 4; nt++) {
+            for (int nt = 0; nt < NT; nt++) {
                 const long tok = n0 + nt * 32 + i;
                 if (tok >= n)
                     continue;
@@ -546,18 +567,22 @@ __global__ __launch_bounds__(512) void gemm_lw_kernel(const gemm_mats mats, int 
 }
 
 hipError_t lfamd_lw_go(int Atype, const gemm_mats &mats, int nb, const void *Xh, const void *d8T, const void *Xm, long n, long n_pad,
-                       int n_rb, int n_ct, unsigned n_wg, int moe, int fast, hipStream_t s) {
-#define LW_GO(T, M, F)                                                                                                 \
-    gemm_lw_kernel<T, M, F><<<n_wg, 512, 0, s>>>(mats, nb, (const _Float16 *)Xh, (const float *)d8T, (const _Float16 *)Xm, n, n_pad, \
-                                                 n_rb, n_ct)
+                       int n_rb, int n_ct, unsigned n_wg, int moe, int fast, int nt, hipStream_t s) {
+    if ((nt != 4 && nt != 2) || (nt == 2 && (!fast || moe)))
+        return hipErrorInvalidValue;
+#define LW_GO(T, M, F, N)                                                                                              \
+    gemm_lw_kernel<T, M, F, N><<<n_wg, 512, 0, s>>>(mats, nb, (const _Float16 *)Xh, (const float *)d8T, (const _Float16 *)Xm, n,  \
+                                                    n_pad, n_rb, n_ct)
 #define LW_GO2(T)                                                                                                      \
     do {                                                                                                               \
         if (moe)                                                                                                       \
-            LW_GO(T, true, false);                                                                                     \
+            LW_GO(T, true, false, 4);                                                                                  \
+        else if (fast && nt == 2)                                                                                      \
+            LW_GO(T, false, true, 2);                                                                                  \
         else if (fast)                                                                                                 \
-            LW_GO(T, false, true);                                                                                     \
+            LW_GO(T, false, true, 4);                                                                                  \
         else                                                                                                           \
-            LW_GO(T, false, false);                                                                                    \
+            LW_GO(T, false, false, 4);                                                                                 \
     } while (0)
     if (Atype == LFAMD_TYPE_Q4_K)
         LW_GO2(LFAMD_TYPE_Q4_K);

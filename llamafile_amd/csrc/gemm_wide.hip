@@ -16,11 +16,12 @@ hipError_t lfamd_wide_go_f16(WIDE_ARGS);
 hipError_t lfamd_wide_go_bf16(WIDE_ARGS);
 
 hipError_t lfamd_lw_go(int Atype, const gemm_mats &mats, int nb, const void *Xh, const void *d8T, const void *Xm, long n, long n_pad,
-                       int n_rb, int n_ct, unsigned n_wg, int moe, int fast, hipStream_t s);
+                       int n_rb, int n_ct, unsigned n_wg, int moe, int fast, int nt, hipStream_t s);
 
 // Q4_K / Q5_K without K split run the loader-wave body (gemm_lw.hip) unless the caller asks for the plain one.
 // mode bit 0: plain body; bit 1: the activations were staged SCALED (pack.hip, prep mode 2) for the scaled-operand
 // loader-wave body — only set when lfamd_gemm_wide_scaled_ok() said that body will run.
+#define LW_FULL_GRID 192 // 128 x 128 tiles from which the 256 CUs count as filled (as wide_ksplit)
 static int g_plain_wide = 0, g_scaled = 0;
 extern "C" void lfamd_gemm_wide_mode(int mode) {
     g_plain_wide = mode & 1, g_scaled = (mode >> 1) & 1;
@@ -31,8 +32,17 @@ static bool lw_allowed() {
 }
 
 static hipError_t wide_go(int Atype, WIDE_ARGS) {
-    if ((Atype == LFAMD_TYPE_Q4_K || Atype == LFAMD_TYPE_Q5_K) && ks == 1 && lw_allowed())
-        return lfamd_lw_go(Atype, mats, nb, Xh, d8T, Xm, n, n_pad, n_rb, n_ct, n_wg, moe, moe ? 0 : g_scaled, s);
+    if ((Atype == LFAMD_TYPE_Q4_K || Atype == LFAMD_TYPE_Q5_K) && lw_allowed()) {
+        if (g_scaled && !moe) {
+            // scaled operands: 128 x 128 tiles when they fill the chip, else 128 x 64 (twice the work-groups, no K split)
+            if (n_rb * n_ct >= LW_FULL_GRID)
+                return lfamd_lw_go(Atype, mats, nb, Xh, d8T, Xm, n, n_pad, n_rb, n_ct, (unsigned)(n_rb * n_ct), 0, 1, 4, s);
+            const int n_ct2 = (int)((n + 63) / 64);
+            return lfamd_lw_go(Atype, mats, nb, Xh, d8T, Xm, n, n_pad, n_rb, n_ct2, (unsigned)(n_rb * n_ct2), 0, 1, 2, s);
+        }
+        if (ks == 1)
+            return lfamd_lw_go(Atype, mats, nb, Xh, d8T, Xm, n, n_pad, n_rb, n_ct, n_wg, moe, 0, 4, s);
+    }
     if (g_scaled)
         return hipErrorInvalidValue; // scaled activations reached a body that expects integer codes
     switch (Atype) {
@@ -88,14 +98,9 @@ extern "C" int lfamd_gemm_wide_ksplit(long m, long k, long n_pad) {
 }
 
 // Will a wide launch of these (fused) matrices run the loader-wave body, i.e. may the caller stage scaled activations?
-extern "C" int lfamd_gemm_wide_scaled_ok(int Atype, int count, const long *m, long k, long n_pad, int plain) {
+extern "C" int lfamd_gemm_wide_scaled_ok(int Atype, int plain) {
     static const bool env_off = getenv("LFAMD_GEMM_NO_SCALED") != nullptr, env_plain = getenv("LFAMD_GEMM_NO_LW") != nullptr;
-    if (env_off || env_plain || plain || (Atype != LFAMD_TYPE_Q4_K && Atype != LFAMD_TYPE_Q5_K))
-        return 0;
-    int n_rb = 0;
-    for (int j = 0; j < count; j++)
-        n_rb += (int)((m[j] + 127) / 128);
-    return wide_ksplit(n_rb * (int)(n_pad / WD_COLS), (int)(k / 256)) == 1;
+    return !(env_off || env_plain || plain || (Atype != LFAMD_TYPE_Q4_K && Atype != LFAMD_TYPE_Q5_K));
 }
 
 extern "C" hipError_t lfamd_launch_gemm_wide_multi(int Atype, int count, const void *const *A, const long *m, long k,
@@ -123,7 +128,8 @@ extern "C" hipError_t lfamd_launch_gemm_wide_multi(int Atype, int count, const v
     for (int i = mats.count; i < GEMM_MAX_MATS; i++)
         mats.A[i] = mats.A[0], mats.C[i] = mats.C[0], mats.m[i] = 0, mats.ldc[i] = 0, mats.rb_end[i] = n_rb;
     const int n_ct = (int)(n_pad / WD_COLS);
-    const int ks = wide_ksplit(n_rb * n_ct, nb);
+    const bool scaled_lw = g_scaled && lw_allowed() && (Atype == LFAMD_TYPE_Q4_K || Atype == LFAMD_TYPE_Q5_K);
+    const int ks = scaled_lw ? 1 : wide_ksplit(n_rb * n_ct, nb); // the scaled-operand body never splits K
     const int nbs = (nb + ks - 1) / ks;
     const int n_wg = n_rb * n_ct * ks;
     if (ks > 1) {

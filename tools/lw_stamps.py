@@ -2,7 +2,7 @@
 import ctypes as C, sys, numpy as np, torch
 sys.path.insert(0, ".")
 from llamafile_amd import sgemm, synth, _hip, ggml_types as T
-m, k, n = 14336, 4096, 512
+m, k, n = (int(v) for v in sys.argv[1:4]) if len(sys.argv) > 3 else (14336, 4096, 512)
 sgemm.init(0)
 W = sgemm.upload_weights(T.Q4_K, synth.random_weights_torch(T.Q4_K, m, k, seed=1), m, k)
 x = torch.randn(n, k, device="cuda")
