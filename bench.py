@@ -363,11 +363,11 @@ def main():
     # FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM), stored
     # under profiles/ — counters cannot be read from inside this process
     traffic, traffic_src = None, None
-    tfile = os.path.join(ROOT, "profiles", "r01_v3_pmc_traffic.json")
+    tfile = os.path.join(ROOT, "profiles", "r01_v4_pmc_traffic.json")
     if dom_type == T.Q4_K and world == 1 and os.path.exists(tfile):
         try:
             traffic = json.load(open(tfile))["gemv_q4k"]["hbm_bytes_per_launch"]
-            traffic_src = "profiles/r01_v3_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2)"
+            traffic_src = "profiles/r01_v4_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2)"
         except (KeyError, ValueError):
             pass
     kname = "gemv_kq_kernel<q4k_traits, 1, F32, 16, {1,2}>" if dom_type == T.Q4_K else "gemv_q80_kernel<1, F32, mode>"
@@ -386,9 +386,9 @@ def main():
         tf = fl / (gus * 1e-6) / 1e12
         roofline_gemm = {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(tf / MFMA_F16_PEAK_TFLOPS, 4),
-                         "kernel": "prep_f32 + gemm_kq_kernel<Q4_K> (128x64 split-K body: 128 tiles of 128x128 cannot fill 256 CUs)",
+                         "kernel": "prep_f32 + gemm_lw_kernel<Q4_K, 128x64 tile, scaled operands> (128 tiles of 128x128 cannot fill 256 CUs)",
                          "shape": [o.m, o.k, a.prefill], "avg_launch_us": round(gus, 2)}
-        # the same measurement on the largest Q4_K shape of the model (128x128 body, gemm_wide.hip)
+        # the same measurement on the largest Q4_K shape of the model (128x128 loader-wave body, gemm_lw.hip)
         big = [q for q in runner.layers[0] if q.W.type == T.Q4_K and q.m >= 8192]
         if big:
             q = big[0]
@@ -397,7 +397,7 @@ def main():
             tf = 2.0 * q.m * q.k * a.prefill / (gus * 1e-6) / 1e12
             roofline_gemm["large_shape"] = {"shape": [q.m, q.k, a.prefill], "avg_launch_us": round(gus, 2),
                                             "achieved": round(tf, 1), "frac": round(tf / MFMA_F16_PEAK_TFLOPS, 4),
-                                            "kernel": "prep_f32 + gemm_wide_kernel<Q4_K>"}
+                                            "kernel": "prep_f32 + gemm_lw_kernel<Q4_K, 128x128 tile, scaled operands>"}
 
     if rank != 0:
         if dist_on:
@@ -421,8 +421,9 @@ def main():
         "config": {
             "workload": f"Llama-3-8B Q4_K_M mat-muls (225 GGML_OP_MUL_MAT per pass, f32 activations in, quantisation fused, sibling ops fused at decode), "
                         f"{a.prefill}-token prefill + {a.decode} decode, matmul-only",
-            "numerics": "exact int8 x int4/int6 block dot products with f32 scales (decode: v_dot4_i32_i8; prefill: "
-                        "f16 MFMA on the exact integer codes, f32 accumulate)",
+            "numerics": "decode: exact int8 x int4/int6 block dot products with f32 scales (v_dot4_i32_i8); prefill: f16 MFMA, "
+                        "f32 accumulate - Q4_K on scaled operands f16(d*sc*q) x f16(d8*code) (<= 1e-3 relative, measured "
+                        "~3e-4; exact integer codes with LFAMD_FLAG_PRECISE), Q6_K on integer codes with f32 scales",
             "model": a.model, "prefill_tokens": a.prefill, "decode_tokens": a.decode,
             "parallelism": "single GPU" if world == 1 else f"tp{world} (RCCL all-reduce on attn_output/ffn_down)",
             "hip_graph": use_graph, "weight_bytes_per_gpu": runner.weight_bytes(),

@@ -37,6 +37,8 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             agg["gemm_q4k_narrow"].append(float(r["Counter_Value"]))
         elif "gemm_wide_kernel" in k and "Li12E" in k:
             agg["gemm_q4k_wide"].append(float(r["Counter_Value"]))
+        elif "gemm_lw_kernel" in k and "Li12E" in k:
+            agg["gemm_q4k_lw_" + ("128x64" if "Li2E" in k else "128x128")].append(float(r["Counter_Value"]))
     for k, v in agg.items():
         res[k][ctr + "_KB_avg_per_launch"] = sum(v) / len(v)
         res[k]["launches"] = len(v)
