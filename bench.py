@@ -111,13 +111,14 @@ class Runner:
         return sum(o.W.nbytes for ops in self.layers for o in ops)
 
     def _groups(self, ops):
-        """Consecutive ops of one layer that read the same activations with the same weight type and k:
-        what a backend's graph_compute fuses into one launch (lfamd_mul_mat_multi)."""
+        """Consecutive ops of one layer that read the same activations with the same k: what a backend's graph_compute
+        fuses into one call (lfamd_mul_mat_multi_types: one launch at decode for one type or for the K-quant pair
+        {Q4_K, Q6_K} — attn_q/k/v of a Q4_K_M file; per type for batches)."""
         groups = []
         for o in ops:
             g = groups[-1] if groups else None
-            if g and g[0].spec.input == o.spec.input and g[0].spec.type == o.spec.type and g[0].k == o.k and \
-                    g[0].spec.shard == o.spec.shard and len(g) < 4:
+            if g and g[0].spec.input == o.spec.input and g[0].k == o.k and g[0].spec.shard == o.spec.shard and len(g) < 4 and \
+                    (g[0].spec.type == o.spec.type or {g[0].spec.type, o.spec.type} <= {T.Q4_K, T.Q6_K}):
                 g.append(o)
             else:
                 groups.append([o])
@@ -141,7 +142,8 @@ class Runner:
                 A_arr = (C.c_void_p * cnt)(*[o.W.data.data_ptr() for o in g])
                 C_arr = (C.c_void_p * cnt)(*[t.data_ptr() for t in outs])
                 m_arr = (C.c_long * cnt)(*[o.m for o in g])
-                calls.append((g, x, outs, A_arr, C_arr, m_arr))
+                t_arr = (C.c_int * cnt)(*[o.spec.type for o in g])
+                calls.append((g, x, outs, A_arr, C_arr, m_arr, t_arr))
         b["calls"] = calls
 
     def run_pass(self, n, only_type=None):
@@ -155,14 +157,15 @@ class Runner:
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         ws, wsn = C.c_void_p(b["ws"].data_ptr()), b["ws"].numel()
         launches = nops = 0
-        for g, x, outs, A_arr, C_arr, m_arr in b["calls"]:
+        for g, x, outs, A_arr, C_arr, m_arr, t_arr in b["calls"]:
             o0 = g[0]
-            if only_type is not None and o0.spec.type != only_type:
+            types = {o.spec.type for o in g}
+            if only_type is not None and types != {only_type}:
                 continue
-            rc = L.lfamd_mul_mat_multi(o0.spec.type, len(g), A_arr, m_arr, o0.k, T.F32, C.c_void_p(x.data_ptr()),
-                                       x.stride(0) * 4, n, C_arr, m_arr, ws, wsn, self.flags, stream)
+            rc = L.lfamd_mul_mat_multi_types(len(g), t_arr, A_arr, m_arr, o0.k, T.F32, C.c_void_p(x.data_ptr()),
+                                             x.stride(0) * 4, n, C_arr, m_arr, ws, wsn, self.flags, stream)
             if rc:
-                _hip.check(rc, "mul_mat_multi " + o0.spec.name)
+                _hip.check(rc, "mul_mat_multi_types " + o0.spec.name)
             launches += 1 if n <= 8 else len(g)
             nops += len(g)
             if only_type is None and self.collectives:
@@ -349,13 +352,13 @@ def main():
     # ---- roofline of the dominant kernel: the decode GEMV of the dominant weight type, all its
     # launches of one decode pass, back to back on the stream, timed with HIP events
     dom_type = T.Q4_K if a.model == "llama3-8b-q4_k_m" else T.Q8_0
-    dom_ops = [o for ops in runner.layers for o in ops if o.spec.type == dom_type]
+    dom_ops = [o for ops in runner.layers for g in runner._groups(ops) if {q.spec.type for q in g} == {dom_type} for o in g]
     launches_per_pass, _ = runner.run_pass(1, only_type=dom_type)
     us, n_launch = time_region(lambda: runner.run_pass(1, only_type=dom_type), 10)
     avg_us = us / n_launch
     # algorithmic bytes per launch: weights once + f32 activations (once per launch: sibling
     # ops fused into a launch share them) + f32 outputs
-    groups = [g for ops in runner.layers for g in runner._groups(ops) if g[0].spec.type == dom_type]
+    groups = [g for ops in runner.layers for g in runner._groups(ops) if {o.spec.type for o in g} == {dom_type}]
     alg_bytes = sum(sum(o.m * T.row_size(dom_type, o.k) + o.m * 4 for o in g) + g[0].k * 4 for g in groups)
     avg_bytes = alg_bytes / launches_per_pass
     achieved = avg_bytes / (avg_us * 1e-6) / 1e9

@@ -113,6 +113,13 @@ int lfamd_mul_mat_multi(int Atype, int count, const void *const *d_A_packed, con
                         const void *d_B, size_t b_row_bytes, long n, float *const *d_C, const long *ldc,
                         void *d_workspace, size_t workspace_bytes, unsigned flags, void *stream);
 
+/* The same for sibling nodes whose weight TYPES may differ (attn_q/k = Q4_K or Q5_K with attn_v = Q6_K in the *_K_M
+ * files): at decode (n = 1) those two groups run as ONE launch; any other mix falls back to one lfamd_mul_mat_multi per
+ * run of equal types.  Same numerics as the separate calls (bit-identical outputs). */
+int lfamd_mul_mat_multi_types(int count, const int *Atype, const void *const *d_A_packed, const long *m, long k, int Btype,
+                              const void *d_B, size_t b_row_bytes, long n, float *const *d_C, const long *ldc, void *d_ws,
+                              size_t ws_bytes, unsigned flags, void *stream);
+
 /* ---- GGML_OP_MUL_MAT_ID (mixture of experts) -------------------------------------------------
  * For every (token, thinker): result[token][thinker][:] = W[plan[token][thinker]] x
  * thought[token][thinker % tasks][:]   (tinyblas_cpu_mixmul.inc:39-50).

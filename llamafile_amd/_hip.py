@@ -48,6 +48,7 @@ _SIGS = {
     "lfamd_mul_mat_workspace": (_sz, [_i, _l, _l, _l]),
     "lfamd_mul_mat": (_i, [_i, _vp, _l, _l, _i, _vp, _sz, _l, _vp, _l, _vp, _sz, _u, _vp]),
     "lfamd_mul_mat_multi": (_i, [_i, _i, _vp, _vp, _l, _i, _vp, _sz, _l, _vp, _vp, _vp, _sz, _u, _vp]),
+    "lfamd_mul_mat_multi_types": (_i, [_i, _vp, _vp, _vp, _l, _i, _vp, _sz, _l, _vp, _vp, _vp, _sz, _u, _vp]),
     "lfamd_mul_mat_id_workspace": (_sz, [_i, _l, _l, _i, _l, _i]),
     "lfamd_mul_mat_id": (_i, [_i, _vp, _l, _l, _i, _i, _vp, _sz, _i, _l, _vp, _i, _vp, _vp, _sz, _u, _vp]),
     "lfamd_time_mul_mat": (_i, [_i, _vp, _l, _l, _i, _vp, _sz, _l, _vp, _l, _vp, _sz, _u, _vp, _i, _i,

@@ -35,6 +35,9 @@ hipError_t lfamd_launch_gemm_q80(const void *, long, long, int, const void *, si
                                  hipStream_t);
 size_t lfamd_gemm_q80_workspace(long, long);
 #define LW_MIN_TILES 64 // 128 x 128 tiles from which the 128 x 64 loader-wave body beats the split-K body (measured)
+hipError_t lfamd_launch_gemv_dual(int, int, const void *const *, const long *, float *const *, const long *, int, int,
+                                  const void *const *, const long *, float *const *, const long *, long, int, const void *, size_t,
+                                  hipStream_t);
 void lfamd_gemm_wide_mode(int);
 hipError_t lfamd_launch_scaled_ok(int, long, long, const void *, int *, hipStream_t);
 int lfamd_gemm_wide_scaled_ok(int, int);
@@ -467,6 +470,61 @@ int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const v
         return LFAMD_OK;
     }
     HIPCHK(lfamd_launch_generic(Atype, d_A, m, k, Btype, d_B, b_row_bytes, n, d_C, ldc, s), "generic");
+    return LFAMD_OK;
+}
+
+// Sibling mat-muls on the same activations whose weight types may differ (a backend's graph_compute sees attn_q/k/v as
+// three MUL_MAT nodes with one src1; in a Q4_K_M file q and k are Q4_K, v is Q6_K).  Decode (n = 1) with exactly two
+// K-quant types {Q4_K | Q5_K, Q6_K}: ONE launch (gemv_kq_dual_kernel).  Everything else: one lfamd_mul_mat_multi per
+// run of equal types.
+int lfamd_mul_mat_multi_types(int count, const int *Atype, const void *const *d_A, const long *m, long k, int Btype,
+                              const void *d_B, size_t b_row_bytes, long n, float *const *d_C, const long *ldc, void *d_ws,
+                              size_t ws_bytes, unsigned flags, void *stream) {
+    (void)hipGetLastError();
+    if (count <= 0)
+        return LFAMD_OK;
+    if (!Atype || !d_A || !m || !d_C || !ldc)
+        return fail(LFAMD_ERR_INVALID, "mul_mat_multi_types: null argument%s", "");
+    int ta = -1, tb = -1, na = 0, nb_ = 0;
+    const void *Aa[4], *Ab[4];
+    long ma[4], mb[4], la[4], lb[4];
+    float *Ca[4], *Cb[4];
+    bool dual = n == 1 && count <= 8 && k > 0 && k % 256 == 0 && !(flags & LFAMD_FLAG_FORCE_GENERIC) &&
+                (Btype == LFAMD_TYPE_F32 || Btype == LFAMD_TYPE_Q8_K) && b_row_bytes >= lfamd_row_size(Btype, k);
+    for (int j = 0; j < count && dual; j++) {
+        const int t = Atype[j];
+        if (m[j] <= 0 || ldc[j] < m[j]) {
+            dual = false;
+        } else if (t == LFAMD_TYPE_Q6_K) {
+            if (nb_ == 4)
+                dual = false;
+            else
+                Ab[nb_] = d_A[j], mb[nb_] = m[j], lb[nb_] = ldc[j], Cb[nb_] = d_C[j], nb_++, tb = t;
+        } else if ((t == LFAMD_TYPE_Q4_K || t == LFAMD_TYPE_Q5_K) && (ta < 0 || ta == t)) {
+            if (na == 4)
+                dual = false;
+            else
+                Aa[na] = d_A[j], ma[na] = m[j], la[na] = ldc[j], Ca[na] = d_C[j], na++, ta = t;
+        } else {
+            dual = false;
+        }
+    }
+    if (dual && na > 0 && nb_ > 0) {
+        HIPCHK(lfamd_launch_gemv_dual(ta, na, Aa, ma, Ca, la, tb, nb_, Ab, mb, Cb, lb, k, Btype, d_B, b_row_bytes,
+                                      (hipStream_t)stream),
+               "gemv_dual");
+        return LFAMD_OK;
+    }
+    for (int j0 = 0; j0 < count;) { // runs of equal types
+        int j1 = j0 + 1;
+        while (j1 < count && Atype[j1] == Atype[j0] && j1 - j0 < 4)
+            j1++;
+        int r = lfamd_mul_mat_multi(Atype[j0], j1 - j0, d_A + j0, m + j0, k, Btype, d_B, b_row_bytes, n, d_C + j0, ldc + j0, d_ws,
+                                    ws_bytes, flags, stream);
+        if (r != LFAMD_OK)
+            return r;
+        j0 = j1;
+    }
     return LFAMD_OK;
 }
 

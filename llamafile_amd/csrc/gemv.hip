@@ -11,6 +11,9 @@ hipError_t lfamd_gemv_ids_go_q6k(int, const gemv_mats &, int, long, const void *
 hipError_t lfamd_gemv_go_q80_f32(int, const q80_mats &, long, long, const void *, size_t, long, int, int, hipStream_t);
 hipError_t lfamd_gemv_go_q80_q80(int, const q80_mats &, long, long, const void *, size_t, long, int, int, hipStream_t);
 
+hipError_t lfamd_gemv_dual_go_q4k_q6k(int, const gemv_mats &, int, const gemv_mats &, int, long, const void *, size_t, hipStream_t);
+hipError_t lfamd_gemv_dual_go_q5k_q6k(int, const gemv_mats &, int, const gemv_mats &, int, long, const void *, size_t, hipStream_t);
+
 // LDS budget: keep one launch's activation image under 160 KiB; otherwise split the columns.
 static int max_cols_for(size_t per_col_bytes) {
     size_t cap = 150 * 1024;
@@ -99,6 +102,42 @@ extern "C" hipError_t lfamd_launch_gemv_multi(int Atype, int count, const void *
             e = lfamd_gemv_go_q6k(nc, f, mats, n_ht, k, B, b_row_bytes, col0, s);
     }
     return e;
+}
+
+static int fill_mats(gemv_mats &mats, int count, const void *const *A, const long *m, float *const *C, const long *ldc) {
+    int n_ht = 0;
+    mats.count = 0;
+    mats.ids = nullptr, mats.expert_bytes = 0, mats.experts = 0;
+    for (int i = 0; i < GEMV_MAX_MATS; i++)
+        mats.id_idx[i] = 0;
+    for (int j = 0; j < count; j++) {
+        if (m[j] <= 0)
+            continue;
+        const int i = mats.count++;
+        mats.A[i] = (const uint8_t *)A[j], mats.C[i] = C[j], mats.m[i] = m[j], mats.ldc[i] = ldc[j];
+        n_ht += (int)(((m[j] + 31) / 32) * 2);
+        mats.ht_end[i] = n_ht;
+    }
+    for (int i = mats.count; i < GEMV_MAX_MATS; i++)
+        mats.A[i] = mats.A[0], mats.C[i] = mats.C[0], mats.m[i] = 0, mats.ldc[i] = 0, mats.ht_end[i] = n_ht;
+    return n_ht;
+}
+
+// ONE activation row, two groups of matrices of two K-quant types (type_b = Q6_K, type_a = Q4_K or Q5_K): one launch.
+extern "C" hipError_t lfamd_launch_gemv_dual(int type_a, int count_a, const void *const *A_a, const long *m_a, float *const *C_a,
+                                             const long *ldc_a, int type_b, int count_b, const void *const *A_b, const long *m_b,
+                                             float *const *C_b, const long *ldc_b, long k, int Btype, const void *B,
+                                             size_t b_row_bytes, hipStream_t s) {
+    if (type_b != LFAMD_TYPE_Q6_K || (type_a != LFAMD_TYPE_Q4_K && type_a != LFAMD_TYPE_Q5_K) || count_a <= 0 || count_b <= 0 ||
+        count_a > GEMV_MAX_MATS || count_b > GEMV_MAX_MATS || (size_t)(k / 256) * XBLK > 150 * 1024)
+        return hipErrorInvalidValue;
+    gemv_mats ma, mb;
+    const int n_ht_a = fill_mats(ma, count_a, A_a, m_a, C_a, ldc_a), n_ht_b = fill_mats(mb, count_b, A_b, m_b, C_b, ldc_b);
+    if (ma.count == 0 || mb.count == 0)
+        return hipErrorInvalidValue; // (the caller sends an empty group through the one-type path)
+    const int f = Btype == LFAMD_TYPE_F32 ? 1 : 0;
+    return type_a == LFAMD_TYPE_Q4_K ? lfamd_gemv_dual_go_q4k_q6k(f, ma, n_ht_a, mb, n_ht_b, k, B, b_row_bytes, s)
+                                     : lfamd_gemv_dual_go_q5k_q6k(f, ma, n_ht_a, mb, n_ht_b, k, B, b_row_bytes, s);
 }
 
 // GGML_OP_MUL_MAT_ID for ONE activation row: `count` (<= GEMV_MAX_MATS) outputs C[j] = W[ids[id_idx[j]]] x B, the expert

@@ -468,10 +468,11 @@ extern "C" __attribute__((weak)) int lfamd_debug_gemv_stamps(unsigned long long 
 #define GSTAMP()
 #endif
 
-template <typename TR, int NC, int BT, int NW, int GEMV_CH, bool IDS = false>
-__global__ __launch_bounds__(NW * 64) void gemv_kq_kernel(const gemv_mats mats, int nb, const uint8_t *__restrict__ B,
-                                                          size_t b_row_bytes, long col0, int n_ht) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+// The body of a GEMV work-group: work-group `bid` of `gdim` over the half-tiles of `mats` (the plain kernel passes its
+// block index and grid size; the two-type kernel gives each type its own sub-grid).
+template <typename TR, int NC, int BT, int NW, int GEMV_CH, bool IDS>
+__device__ __forceinline__ void gemv_kq_body(const gemv_mats &mats, int nb, const uint8_t *__restrict__ B, size_t b_row_bytes,
+                                             long col0, int n_ht, const int bid, const int gdim, uint8_t *lds) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i16 = lane & 15, h = (lane >> 4) & 1, gsel = lane >> 5;
     float *red = (float *)(lds + (size_t)NC * nb * XBLK); // [2][NW][NC][16]
@@ -482,7 +483,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_kq_kernel(const gemv_mats mats, 
 
     const int sb_per_wave = (nb + NW - 1) / NW;
     const int cpt = (sb_per_wave + GEMV_CH - 1) / GEMV_CH; // chunks per tile
-    const int ntile = (n_ht - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int ntile = (n_ht - bid + gdim - 1) / gdim;
     const int total = ntile * cpt;
 
     // Loads are issued UNCONDITIONALLY through a bounds-checked buffer descriptor: a branch around a load
@@ -493,7 +494,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_kq_kernel(const gemv_mats mats, 
     const uint32_t rt_bytes = (uint32_t)nb * TR::TILE;
     auto issue = [&](typename TR::chunk &ch, int f) {
         const int tile_i = f / cpt, chunk_i = f - tile_i * cpt;
-        long ht = (long)blockIdx.x + (long)tile_i * gridDim.x;
+        long ht = (long)bid + (long)tile_i * gdim;
         int j = 0;
 #pragma unroll
         for (int jj = 1; jj < GEMV_MAX_MATS; jj++)
@@ -556,7 +557,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_kq_kernel(const gemv_mats mats, 
 #pragma unroll
                 for (int w = 0; w < NW; w++)
                     v += rb[(w * NC + c) * 16 + i];
-                long ht = (long)blockIdx.x + (long)tile_i * gridDim.x;
+                long ht = (long)bid + (long)tile_i * gdim;
                 int j = 0;
 #pragma unroll
                 for (int jj = 1; jj < GEMV_MAX_MATS; jj++)
@@ -614,6 +615,29 @@ __global__ __launch_bounds__(NW * 64) void gemv_kq_kernel(const gemv_mats mats, 
         if (f + 1 < total)
             consume(bufB, f + 1);
     }
+}
+
+template <typename TR, int NC, int BT, int NW, int GEMV_CH, bool IDS = false>
+__global__ __launch_bounds__(NW * 64) void gemv_kq_kernel(const gemv_mats mats, int nb, const uint8_t *__restrict__ B,
+                                                          size_t b_row_bytes, long col0, int n_ht) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    gemv_kq_body<TR, NC, BT, NW, GEMV_CH, IDS>(mats, nb, B, b_row_bytes, col0, n_ht, (int)blockIdx.x, (int)gridDim.x, lds);
+}
+
+// Two weight types in ONE decode launch (sibling mat-muls on the same activations whose types differ: attn_q/k in Q4_K
+// with attn_v in Q6_K in a Q4_K_M file): work-groups [0, grid_a) run type A's body over mats_a, the rest type B's over
+// mats_b.  A work-group is of one type, so it stages the activations once, in the (shared) Q8_K image.
+template <typename TRA, typename TRB, int BT, int NW, int GEMV_CH>
+__global__ __launch_bounds__(NW * 64) void gemv_kq_dual_kernel(const gemv_mats mats_a, const gemv_mats mats_b, int nb,
+                                                               const uint8_t *__restrict__ B, size_t b_row_bytes, int n_ht_a,
+                                                               int n_ht_b, int grid_a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    static_assert(TRA::ACT == TRB::ACT, "both types must share the activation image");
+    if ((int)blockIdx.x < grid_a)
+        gemv_kq_body<TRA, 1, BT, NW, GEMV_CH, false>(mats_a, nb, B, b_row_bytes, 0, n_ht_a, (int)blockIdx.x, grid_a, lds);
+    else
+        gemv_kq_body<TRB, 1, BT, NW, GEMV_CH, false>(mats_b, nb, B, b_row_bytes, 0, n_ht_b, (int)blockIdx.x - grid_a,
+                                                     (int)gridDim.x - grid_a, lds);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -910,6 +934,31 @@ static hipError_t launch_kq(const gemv_mats &mats, int n_ht, long k, const void 
     return hipGetLastError();
 }
 
+template <typename TRA, typename TRB, int BT>
+static hipError_t launch_kq_dual(const gemv_mats &ma, int n_ht_a, const gemv_mats &mb, int n_ht_b, long k, const void *B,
+                                 size_t brb, hipStream_t s) {
+    const int nb = (int)(k / 256);
+    constexpr int NW = 16;
+    const size_t smem = (size_t)nb * XBLK + 2 * NW * 16 * sizeof(float);
+    // one persistent grid shared in proportion to the half-tile counts (cf. launch_kq)
+    const int max_wg = num_cus();
+    const int per_wg = (n_ht_a + n_ht_b + max_wg - 1) / max_wg;
+    const int grid_a = (n_ht_a + per_wg - 1) / per_wg, grid_b = (n_ht_b + per_wg - 1) / per_wg;
+    if (nb <= 16) {
+        auto kernel = gemv_kq_dual_kernel<TRA, TRB, BT, NW, 1>;
+        kernel<<<grid_a + grid_b, NW * 64, smem, s>>>(ma, mb, nb, (const uint8_t *)B, brb, n_ht_a, n_ht_b, grid_a);
+    } else {
+        auto kernel = gemv_kq_dual_kernel<TRA, TRB, BT, NW, 2>;
+        if (smem > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            if (e != hipSuccess)
+                return e;
+        }
+        kernel<<<grid_a + grid_b, NW * 64, smem, s>>>(ma, mb, nb, (const uint8_t *)B, brb, n_ht_a, n_ht_b, grid_a);
+    }
+    return hipGetLastError();
+}
+
 template <typename TR, int BT>
 static hipError_t launch_kq_ids(const gemv_mats &mats, int n_ht, long k, const void *B, size_t brb, hipStream_t s) {
     const int nb = (int)(k / 256);
@@ -1040,6 +1089,12 @@ static hipError_t launch_q80(const q80_mats &mats, long n_total, long k, const v
             DISPATCH_NC(launch_##NAME, QTYPE, nc, mats, n_ht, k, B, brb, col0, s)                                      \
         }                                                                                                              \
         return e;                                                                                                      \
+    }
+#define GEMV_INSTANTIATE_DUAL(NAME, TRA, TRB)                                                                           \
+    hipError_t lfamd_gemv_dual_go_##NAME(int f32in, const gemv_mats &ma, int n_ht_a, const gemv_mats &mb, int n_ht_b, long k, \
+                                         const void *B, size_t brb, hipStream_t s) {                                   \
+        return f32in ? launch_kq_dual<TRA, TRB, LFAMD_TYPE_F32>(ma, n_ht_a, mb, n_ht_b, k, B, brb, s)                  \
+                     : launch_kq_dual<TRA, TRB, LFAMD_TYPE_Q8_K>(ma, n_ht_a, mb, n_ht_b, k, B, brb, s);                \
     }
 #define GEMV_INSTANTIATE_IDS(NAME, TRAITS)                                                                             \
     hipError_t lfamd_gemv_ids_go_##NAME(int f32in, const gemv_mats &mats, int n_ht, long k, const void *B, size_t brb,  \

@@ -134,12 +134,16 @@ def mul_mat(W: PackedWeights, B: torch.Tensor, Btype: int, n: int | None = None,
 
 def mul_mat_multi(Ws: list, B: torch.Tensor, Btype: int, n: int | None = None, flags: int | None = None,
                   workspace: torch.Tensor | None = None) -> list:
-    """Several GGML_OP_MUL_MAT nodes sharing the activations B (same weight type and k): one fused launch
-    where the module can (decode GEMV), else one per matrix.  Returns the list of f32 [n, m_j] outputs."""
+    """Several GGML_OP_MUL_MAT nodes sharing the activations B (same k): one fused launch where the module can
+    (decode GEMV of one type, or of the K-quant pair {Q4_K | Q5_K, Q6_K}; batches of one K-quant type), else one per
+    matrix.  Returns the list of f32 [n, m_j] outputs."""
     L = _hip.lib()
-    assert len(Ws) >= 1 and all(w.type == Ws[0].type and w.cols == Ws[0].cols for w in Ws)
+    assert len(Ws) >= 1 and all(w.cols == Ws[0].cols for w in Ws)
+    mixed = any(w.type != Ws[0].type for w in Ws)
     n = B.shape[0] if n is None else n
     flags = host_variant_flags() if flags is None else flags
+    if any(getattr(w, "exact_only", False) for w in Ws):
+        flags |= _hip.FLAG_PRECISE
     outs = [torch.empty((n, w.rows), dtype=torch.float32, device=B.device) for w in Ws]
     need = max(L.lfamd_mul_mat_workspace(w.type, w.rows, w.cols, n) for w in Ws)
     if need and (workspace is None or workspace.numel() < need):
@@ -151,8 +155,13 @@ def mul_mat_multi(Ws: list, B: torch.Tensor, Btype: int, n: int | None = None, f
     ldc_arr = (C.c_long * cnt)(*[w.rows for w in Ws])
     ws_ptr = _ptr(workspace) if workspace is not None else C.c_void_p(0)
     ws_len = workspace.numel() if workspace is not None else 0
-    rc = L.lfamd_mul_mat_multi(Ws[0].type, cnt, A_arr, m_arr, Ws[0].cols, Btype, _ptr(B), B.stride(0) * B.element_size(), n,
-                               C_arr, ldc_arr, ws_ptr, ws_len, flags, _stream())
+    if mixed:
+        t_arr = (C.c_int * cnt)(*[w.type for w in Ws])
+        rc = L.lfamd_mul_mat_multi_types(cnt, t_arr, A_arr, m_arr, Ws[0].cols, Btype, _ptr(B), B.stride(0) * B.element_size(),
+                                         n, C_arr, ldc_arr, ws_ptr, ws_len, flags, _stream())
+    else:
+        rc = L.lfamd_mul_mat_multi(Ws[0].type, cnt, A_arr, m_arr, Ws[0].cols, Btype, _ptr(B), B.stride(0) * B.element_size(),
+                                   n, C_arr, ldc_arr, ws_ptr, ws_len, flags, _stream())
     _hip.check(rc, "lfamd_mul_mat_multi")
     return outs
 

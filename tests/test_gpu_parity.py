@@ -240,6 +240,35 @@ def test_mul_mat_multi_equals_separate(gpu, t, n):
         assert np.array_equal(f.cpu().numpy().view(np.uint32), sep.cpu().numpy().view(np.uint32))
 
 
+@pytest.mark.parametrize("ta", [T.Q4_K, T.Q5_K], ids=lambda t: T.NAMES[t])
+@pytest.mark.parametrize("k", [1024, 4096, 5120])
+@pytest.mark.parametrize("f32in", [True, False], ids=["f32", "q8k"])
+def test_mul_mat_multi_two_types_one_launch(gpu, ta, k, f32in):
+    """lfamd_mul_mat_multi_types at decode: attn_q/k (Q4_K or Q5_K) and attn_v (Q6_K) on one activation row run as one
+    launch of the two-type GEMV; bit-identical to separate calls, in any node order, ragged row counts, both chunk depths
+    (k <= 4096 / beyond).  Other mixes and batches fall back to per-type calls with the same results."""
+    from llamafile_amd import synth
+    specs = [(ta, 200), (ta, 40), (T.Q6_K, 72), (ta, 7), (T.Q6_K, 130)]
+    Ws = [gpu.upload_weights(t, synth.random_weights(t, m, k, 260 + i), m, k) for i, (t, m) in enumerate(specs)]
+    x = torch.from_numpy(synth.random_activations(3, k, 270)).cuda()
+    for n in (1, 3):
+        B = x[:n].contiguous()
+        if f32in:
+            Bq, bt = B.view(torch.uint8), T.F32
+        else:
+            Bq, bt = gpu.quantize_rows(T.Q8_K, B), T.Q8_K
+        fused = gpu.mul_mat_multi(Ws, Bq, bt, n=n)
+        for W, f in zip(Ws, fused):
+            sep = gpu.mul_mat(W, Bq, bt, n=n)
+            assert np.array_equal(f.cpu().numpy().view(np.uint32), sep.cpu().numpy().view(np.uint32)), (n, T.NAMES[W.type], W.rows)
+    # a third type in the mix: per-type fallback
+    Wx = Ws[:3] + [gpu.upload_weights(T.Q8_0, synth.random_weights(T.Q8_0, 24, k, 299), 24, k)]
+    fused = gpu.mul_mat_multi(Wx, x[:1].contiguous().view(torch.uint8), T.F32, n=1)
+    for W, f in zip(Wx, fused):
+        sep = gpu.mul_mat(W, x[:1].contiguous().view(torch.uint8), T.F32, n=1)
+        assert np.array_equal(f.cpu().numpy().view(np.uint32), sep.cpu().numpy().view(np.uint32))
+
+
 @pytest.mark.parametrize("t", [T.Q4_K, T.Q5_K, T.Q6_K], ids=lambda t: T.NAMES[t])
 def test_mul_mat_multi_gemm_fused_launch(gpu, t):
     """Batches: sibling mat-muls share one activation prep and ONE launch of the 128 x 128 MFMA body over their
