@@ -23,7 +23,7 @@
 #define LW_XM 49664     // 128 x 32 B mins operand                        (first half only)
 #define LW_SLOT 53760
 #define LW_STAGES 3
-#define LW_FLAG (LW_STAGES * LW_SLOT) // landed-stage counter (FAST compute waves read ahead of the barrier)
+#define LW_FLAG (LW_STAGES * LW_SLOT) // landed-stage counter (+1 per loader wave and stage), at +4: released-stage counter (+1 per compute wave and stage)
 
 #if GEMM_DIAG == 4 // development: s_memtime stamps around every barrier of work-group 0 (wave 0 computes, wave 4 loads)
 __device__ unsigned long long g_lw_stamps[2 * 128];
@@ -96,9 +96,23 @@ __global__ __launch_bounds__(512) void gemm_lw_kernel(const gemm_mats mats, int 
     const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), real0 = __builtin_amdgcn_s_memrealtime();
 #endif
     const uint32_t lds0 = lds_addr(lds);
-    const uint32_t flag_addr = lds0 + LW_FLAG;
+    const uint32_t flag_addr = lds0 + LW_FLAG, rel_addr = flag_addr + 4;
     if (threadIdx.x == 0)
-        asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(flag_addr), "v"(0u) : "memory");
+        asm volatile("ds_write_b32 %0, %1\n\tds_write_b32 %0, %1 offset:4\n\ts_waitcnt lgkmcnt(0)" ::"v"(flag_addr), "v"(0u) : "memory");
+    // spin until the counter at `addr` reaches `need` (uniform; the slow path sleeps between polls)
+    auto wait_counter = [&](uint32_t addr, uint32_t need) {
+        uint32_t v;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+        while (__builtin_amdgcn_readfirstlane(v) < need) {
+            __builtin_amdgcn_s_sleep(2);
+            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+        }
+    };
+    // a compute wave is done with a stage: every LDS read of it has returned (reads and this add execute in order)
+    auto release_stage = [&]() {
+        if (lane == 0)
+            asm volatile("ds_add_u32 %0, %1" ::"v"(rel_addr), "v"(1u) : "memory");
+    };
     asm volatile("s_barrier" ::: "memory");
 
     if (wave >= 4) {
@@ -170,19 +184,19 @@ __global__ __launch_bounds__(512) void gemm_lw_kernel(const gemm_mats mats, int 
 #endif
         for (int hb = 0; hb < H; hb += 2) {
             LSTAMP(1);
+            wait_counter(rel_addr, 4u * (uint32_t)hb); // the slot of stage hb+2 was stage hb-1's
             LW_DMA_IF issue(hb + 2, H0{}, H0{});
             landed(); // stage hb+1
             LSTAMP(1);
             LW_DMA_IF issue(hb + 2, H0{}, H1{});
             LSTAMP(1);
-            asm volatile("s_barrier" ::: "memory"); // B_hb
+            wait_counter(rel_addr, 4u * (uint32_t)(hb + 1)); // the slot of stage hb+3 was stage hb's
             LSTAMP(1);
             LW_DMA_IF issue(hb + 3, H1{}, H0{});
             landed(); // stage hb+2
             LSTAMP(1);
             LW_DMA_IF issue(hb + 3, H1{}, H1{});
             LSTAMP(1);
-            asm volatile("s_barrier" ::: "memory"); // B_(hb+1)
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // nothing may land after the work-group has left
         return;
@@ -487,24 +501,26 @@ __global__ __launch_bounds__(512) void gemm_lw_kernel(const gemm_mats mats, int 
             LSTAMP(0);
             fast_half(s0, s1, s0, 4u * (uint32_t)(hb + 1), H0{});
             LSTAMP(0);
-            asm volatile("s_barrier" ::: "memory");
+            release_stage();
             LSTAMP(0);
             fast_half(s1, s2, s0, 4u * (uint32_t)(hb + 2), H1{});
             LSTAMP(0);
-            asm volatile("s_barrier" ::: "memory");
+            release_stage();
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the look-ahead reads of the (clamped) stage past the end
     } else {
     for (int hb = 0; hb < H; hb += 2) {
         const uint32_t s0 = lds0 + (uint32_t)(hb % LW_STAGES) * LW_SLOT, s1 = lds0 + (uint32_t)((hb + 1) % LW_STAGES) * LW_SLOT;
         LSTAMP(0);
+        wait_counter(flag_addr, 4u * (uint32_t)hb); // stage hb landed (stage 0: the barrier above)
         half_step(s0, s0, H0{});
         LSTAMP(0);
-        asm volatile("s_barrier" ::: "memory");
+        release_stage();
+        wait_counter(flag_addr, 4u * (uint32_t)(hb + 1));
         LSTAMP(0);
         half_step(s1, s0, H1{});
         LSTAMP(0);
-        asm volatile("s_barrier" ::: "memory");
+        release_stage();
     }
     }
 
