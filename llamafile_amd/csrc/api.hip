@@ -652,8 +652,8 @@ int lfamd_time_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, co
     HIPCHK(hipEventSynchronize(e1), "hipEventSynchronize");
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, e0, e1), "hipEventElapsedTime");
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
     *avg_us = iters > 0 ? ms * 1000.0f / iters : 0.0f;
     return LFAMD_OK;
 }

@@ -73,7 +73,6 @@ __global__ __launch_bounds__(512) void gemm_kq_kernel(const uint8_t *__restrict_
     const long rt = (long)rb * 4 + rw;
     const bool active = rt < n_row_tiles;
     const long n0 = (long)tt * TOK_TILE;
-    const long k = (long)nb * 256;
     const uint8_t *tile0 = A + (size_t)(active ? rt : 0) * nb * TILE;
     const int nit = (nb - kg + GEMM_KG - 1) / GEMM_KG; // this K-group's super-blocks: kg, kg+2, ...
     const int nit_max = (nb + GEMM_KG - 1) / GEMM_KG;
@@ -304,234 +303,6 @@ __global__ __launch_bounds__(512) void gemm_kq_kernel(const uint8_t *__restrict_
     }
 }
 
-// =====================================================================================================
-// EXPERIMENTAL (LFAMD_GEMM_LDS3=1; default is gemm_kq_kernel above): measured 43.8 us vs 41.0 us at
-// 4096x4096x512 — with one wave per SIMD the ~500 VALU instructions per super-block (dequant, scale constants,
-// AGPR moves, epilogue) are issue-bound at 4 cycles each, so removing the load stalls alone does not pay; kept
-// because the hand-counted LDS-DMA pipeline is the base for the next step (two waves per SIMD).
-// Q4_K, three-stage LDS-DMA pipeline.  EVERY global read of the K loop is a global_load_lds (activation
-// tile, this wave's weight tile, scales), so no register-destination load exists for hipcc to wait on and the
-// waits are hand-counted: s_waitcnt vmcnt(G3_PER_STAGE) leaves the youngest stage in flight across a raw
-// s_barrier (cdna_hip_programming.md §5 "Pipelining across barriers", T3+T4).  Two super-blocks stream while
-// one computes.  4 waves, 128 rows x 64 tokens per work-group, 156.75 KiB of LDS (one work-group per CU).
-//
-//   stage (53 504 B):  X 64 tokens x 512 B (XOR-swizzled chunks) | W 4 waves x 4608 B (packed tile of the
-//                      wave's 32 rows) | d8 64 x f32 | xm 64 tokens x 32 B | 256 B spare
-//   iteration b:  wait stage b (vmcnt) ; barrier ; issue stage b+2 ; compute stage b
-// The barrier both publishes stage b (every wave waited for its own part first) and retires stage b-1,
-// whose slot is the one refilled right after it.
-
-#define G3_X 0
-#define G3_W 32768
-#define G3_D8 (G3_W + 4 * P4K_TILE)
-#define G3_XM (G3_D8 + 256)
-#define G3_SPARE (G3_XM + 2048)
-#define G3_STAGE (G3_SPARE + 256)
-#define G3_PER_STAGE 14 // global_load_lds instructions every wave issues per stage
-
-// LDS-DMA in inline asm (cdna_hip_programming.md §5.7, glds16_asm): hipcc's waitcnt pass makes every ds_read
-// wait vmcnt(0) for a pending __builtin_amdgcn_global_load_lds it cannot prove disjoint (here: always, even
-// with one LDS object per stage), which would drain the pipeline at the top of every compute phase.  Hidden in
-// asm, the DMA is invisible to that pass and ordered only by the hand-counted s_waitcnt + s_barrier below.
-// lds_wave_base must be wave-uniform (an SGPR); M0 is saved/restored inside the same statement.
-__device__ static inline void glds16(const void *gsrc, void *lds_wave_base) {
-    const uint32_t dst = __builtin_amdgcn_readfirstlane(
-        (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)(uint8_t *)lds_wave_base);
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(dst)
-                 : "memory");
-}
-
-__global__ __launch_bounds__(256) void gemm_q4k_lds3_kernel(const uint8_t *__restrict__ A, long m, int nb,
-                                                            const _Float16 *__restrict__ Xh, const float *__restrict__ d8T,
-                                                            const _Float16 *__restrict__ Xm, long n, long n_pad,
-                                                            float *__restrict__ C, long ldc, int n_rb, int n_wg) {
-    // three distinct LDS objects, addressed with compile-time stage numbers (loop unrolled x3): hipcc's waitcnt
-    // pass makes a ds_read wait for every pending LDS-DMA it cannot prove disjoint, i.e. vmcnt(0), if the stage
-    // is picked by a run-time index into one array
-    __shared__ __attribute__((aligned(16))) uint8_t lds0[G3_STAGE];
-    __shared__ __attribute__((aligned(16))) uint8_t lds1[G3_STAGE];
-    __shared__ __attribute__((aligned(16))) uint8_t lds2[G3_STAGE];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int i = lane & 31, h = lane >> 5;
-
-    // XCD-aware tile assignment (see gemm_kq_kernel)
-    const int id = blockIdx.x, q8 = n_wg >> 3, r8 = n_wg & 7, xcd = id & 7;
-    const int Lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3);
-    int tt, rb;
-    tile_of(Lin, n_rb, n_wg / n_rb, rb, tt);
-
-    const long n_row_tiles = (m + 31) / 32;
-    const long rt = (long)rb * 4 + wave;
-    const bool active = rt < n_row_tiles;
-    const long n0 = (long)tt * TOK_TILE;
-    const long k = (long)nb * 256;
-    const uint8_t *wtile0 = A + (size_t)(active ? rt : 0) * nb * P4K_TILE; // inactive waves stream tile 0, unused
-
-    auto issue = [&](int b, uint8_t *st) {
-        // activations: wave w fills rows 16w .. 16w+15 (8 instructions x 2 rows); lane p of a row fetches the
-        // logical chunk p ^ (row & 15) so the image is swizzled although the LDS side is lane-linear
-#pragma unroll
-        for (int e = 0; e < 8; e++) {
-            const int wi = wave * 8 + e;
-            const int nn = 2 * wi + h;
-            glds16((const uint8_t *)Xh + ((size_t)b * n_pad + n0 + nn) * 512 + ((i ^ (nn & 15)) * 16),
-                   st + G3_X + wi * 1024);
-        }
-        // this wave's packed weight tile: 4 x 1 KiB of nibbles + 512 B of headers (upper half-wave idle)
-        const uint8_t *wt = wtile0 + (size_t)b * P4K_TILE;
-        uint8_t *wl = st + G3_W + wave * P4K_TILE;
-#pragma unroll
-        for (int g = 0; g < 4; g++)
-            glds16(wt + g * 1024 + lane * 16, wl + g * 1024);
-        if (lane < 32)
-            glds16(wt + P4K_HDR + lane * 16, wl + P4K_HDR);
-        // scales: one more instruction per wave (wave 0: d8, waves 1-2: the two halves of xm, wave 3: spare)
-        if (wave == 0) {
-            if (lane < 16)
-                glds16((const uint8_t *)(d8T + (size_t)b * n_pad + n0) + lane * 16, st + G3_D8);
-        } else if (wave == 3) {
-            if (lane < 16)
-                glds16((const uint8_t *)(d8T + (size_t)b * n_pad + n0) + lane * 16, st + G3_SPARE);
-        } else {
-            // xm rows are 32 B per (token, super-block), token stride nb*32 B: lane = (token half*32.., 16-B half)
-            const int tok = (wave - 1) * 32 + (lane >> 1);
-            glds16((const uint8_t *)Xm + ((size_t)b * n_pad + n0 + tok) * 32 + (lane & 1) * 16,
-                   st + G3_XM + (wave - 1) * 1024);
-        }
-    };
-
-    float16_t_ acc[2];
-#pragma unroll
-    for (int nt = 0; nt < 2; nt++)
-#pragma unroll
-        for (int r = 0; r < 16; r++)
-            acc[nt][r] = 0.0f;
-
-    // byte offset of this lane's fragment chunk inside a token row, per K-step parity: (c ^ (i & 15)) * 16 with
-    // c = 2t + h; c & 15 takes 16 values -> precomputed once, the rest is an immediate
-    uint32_t xoff[8];
-#pragma unroll
-    for (int u = 0; u < 8; u++)
-        xoff[u] = (uint32_t)(i * XT_ROW_BYTES + ((((2 * u + h) & 15) ^ (i & 15)) * 16));
-    const uint32_t magic = opaque_magic();
-
-    auto compute = [&](const uint8_t *st) {
-        const uint8_t *xb = st + G3_X;
-        const uint8_t *wl = st + G3_W + wave * P4K_TILE;
-        float16_t_ tmp[2];
-#pragma unroll
-        for (int nt = 0; nt < 2; nt++)
-#pragma unroll
-            for (int r = 0; r < 16; r++)
-                tmp[nt][r] = 0.0f;
-        const uint4 hd = *(const uint4 *)(wl + P4K_HDR + i * 16);
-        const float d = h2f((uint16_t)(hd.x & 0xffff)), dmin = h2f((uint16_t)(hd.x >> 16));
-        uint32_t sc03, sc47, mn03, mn47;
-        q4k_scales_bytes(hd.y, hd.z, hd.w, sc03, sc47, mn03, mn47);
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-            const uint4 q4 = *(const uint4 *)(wl + g * 1024 + lane * 16);
-            const uint32_t qw[4] = {q4.x, q4.y, q4.z, q4.w};
-#pragma unroll
-            for (int e2 = 0; e2 < 2; e2++) { // sub-block j = 2g + e2 = K-steps 4g + 2e2, +1
-                const int j = 2 * g + e2;
-                const float scf = (float)(((j < 4 ? sc03 : sc47) >> (8 * (j & 3))) & 0xff);
-                const half2_t S = bcast_h2(scf), O = bcast_h2(-1024.0f * scf);
-                const half2_t S16 = bcast_h2(scf * 0.0625f), O16 = bcast_h2(-64.0f * scf);
-#pragma unroll
-                for (int e = 0; e < 2; e++) {
-                    const int t = 4 * g + 2 * e2 + e;
-                    const half8_t wf = dequant_q4(qw[2 * e2 + e], S, O, S16, O16, magic);
-                    // chunk c = 2t + h: bit 4 of c is an immediate (256 B), the low 4 bits come from xoff
-#pragma unroll
-                    for (int nt = 0; nt < 2; nt++) {
-                        const half8_t xf = *(const half8_t *)(xb + xoff[t & 7] + nt * 32 * XT_ROW_BYTES + ((2 * t) & 16) * 16);
-                        tmp[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xf, wf, tmp[nt], 0, 0, 0);
-                    }
-                }
-            }
-        }
-        // ---- mins: one MFMA per token tile, K = 16 = {lo parts | hi parts} of the 8 pair sums
-        frag_u wm;
-        const float mscale = h ? 64.0f : 1.0f;
-#pragma unroll
-        for (int p = 0; p < 4; p++) {
-            const uint32_t mw = p < 2 ? mn03 : mn47;
-            const float m0 = (float)((mw >> (16 * (p & 1))) & 0xff), m1 = (float)((mw >> (16 * (p & 1) + 8)) & 0xff);
-            half2_t v = {(_Float16)(m0 * mscale), (_Float16)(m1 * mscale)};
-            wm.p[p] = v;
-        }
-#pragma unroll
-        for (int nt = 0; nt < 2; nt++) {
-            const half8_t xm = *(const half8_t *)(st + G3_XM + (nt * 32 + i) * 32 + h * 16);
-            float16_t_ tm;
-#pragma unroll
-            for (int r = 0; r < 16; r++)
-                tm[r] = 0.0f;
-            tm = __builtin_amdgcn_mfma_f32_32x32x16_f16(xm, wm.v, tm, 0, 0, 0);
-#pragma unroll
-            for (int r4 = 0; r4 < 4; r4++) {
-                const float4_t_ d8 = *(const float4_t_ *)(st + G3_D8 + (nt * 32 + 8 * r4 + 4 * h) * 4);
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const int r = 4 * r4 + e;
-                    const float u = fmaf(-dmin, tm[r], d * tmp[nt][r]);
-                    acc[nt][r] = fmaf(u, d8[e], acc[nt][r]);
-                }
-            }
-        }
-    };
-
-    // ---- pipeline (unrolled x3: stage objects are compile-time)
-    auto wait_stage = [&](int b) {
-        // stage b is complete once at most the younger stage's G3_PER_STAGE loads remain (none at the end)
-        if (b + 1 < nb)
-            asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
-        else
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-    };
-    issue(0, lds0);
-    if (nb > 1)
-        issue(1, lds1);
-    for (int b = 0; b < nb; b += 3) {
-        wait_stage(b);
-        if (b + 2 < nb)
-            issue(b + 2, lds2);
-        compute(lds0);
-        if (b + 1 < nb) {
-            wait_stage(b + 1);
-            if (b + 3 < nb)
-                issue(b + 3, lds0);
-            compute(lds1);
-        }
-        if (b + 2 < nb) {
-            wait_stage(b + 2);
-            if (b + 4 < nb)
-                issue(b + 4, lds1);
-            compute(lds2);
-        }
-    }
-
-    // ---- store: reg r of token tile nt is token n0 + 32nt + (r&3) + 8(r>>2) + 4h, weight row 32rt + i
-    if (active) {
-        const long row = rt * 32 + i;
-        if (row < m) {
-#pragma unroll
-            for (int nt = 0; nt < 2; nt++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const long tok = n0 + nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (tok < n)
-                        C[tok * ldc + row] = acc[nt][r];
-                }
-        }
-    }
-}
-
 extern "C" hipError_t lfamd_launch_gemm_kq(int Atype, const void *A, long m, long k, const void *Xh, const void *d8T,
                                            const void *Xm, long n, long n_pad, float *C, long ldc, hipStream_t s) {
     if (m <= 0 || n <= 0)
@@ -540,11 +311,7 @@ extern "C" hipError_t lfamd_launch_gemm_kq(int Atype, const void *A, long m, lon
     long n_row_tiles = (m + 31) / 32;
     const int n_rb = (int)((n_row_tiles + 3) / 4), n_tt = (int)(n_pad / TOK_TILE);
     const int n_wg = n_rb * n_tt;
-    if (Atype == LFAMD_TYPE_Q4_K && getenv("LFAMD_GEMM_LDS3")) { // experimental variant, see the kernel's header
-        gemm_q4k_lds3_kernel<<<n_wg, 256, 0, s>>>((const uint8_t *)A, m, nb, (const _Float16 *)Xh,
-                                                              (const float *)d8T, (const _Float16 *)Xm, n, n_pad, C, ldc, n_rb,
-                                                              n_wg);
-    } else if (Atype == LFAMD_TYPE_Q4_K)
+    if (Atype == LFAMD_TYPE_Q4_K)
         gemm_kq_kernel<LFAMD_TYPE_Q4_K><<<n_wg, 512, 0, s>>>((const uint8_t *)A, m, nb, (const _Float16 *)Xh,
                                                                (const float *)d8T, (const _Float16 *)Xm, n, n_pad, C, ldc,
                                                                n_rb, n_wg);

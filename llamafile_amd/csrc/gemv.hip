@@ -162,7 +162,6 @@ extern "C" hipError_t lfamd_launch_gemv_ids(int Atype, int count, const void *W,
             n_ht += (int)(((m + 31) / 32) * 2);
         mats.ht_end[i] = n_ht;
     }
-    const bool f32in = Btype == LFAMD_TYPE_F32;
     const int f = Btype == LFAMD_TYPE_F32 ? 1 : 0;
     if (Atype == LFAMD_TYPE_Q4_K)
         return lfamd_gemv_ids_go_q4k(f, mats, n_ht, k, B, b_row_bytes, s);

@@ -333,16 +333,6 @@ def test_float_types_mfma_gemm(gpu, oracle, ta, tb, shape):
         assert rel_err(C, O) <= 2e-6
 
 
-def test_experimental_lds3_gemm_variant(gpu, oracle, monkeypatch):
-    """The hand-counted three-stage LDS-DMA Q4_K GEMM (LFAMD_GEMM_LDS3=1) stays correct."""
-    monkeypatch.setenv("LFAMD_GEMM_LDS3", "1")
-    for m, n, k in [(128, 64, 1024), (96, 100, 768), (33, 9, 256), (256, 130, 2048)]:
-        A, B, bt = make_case(T.Q4_K, m, n, k, seed=777)
-        ok, G = oracle.sgemm(T.Q4_K, A, bt, B, m, n, k)
-        C = run_gpu(gpu, T.Q4_K, A, B, bt, m, n, k)
-        assert rel_err(C, G) <= 2e-6, (m, n, k)
-
-
 @pytest.mark.parametrize("t", [T.Q4_K, T.Q5_K, T.Q6_K], ids=lambda t: T.NAMES[t])
 @pytest.mark.parametrize("tokens,tasks", [(1, 1), (1, 2), (3, 1), (2, 2)])
 @pytest.mark.parametrize("f32in", [False, True], ids=["q8k", "f32"])
