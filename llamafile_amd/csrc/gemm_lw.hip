@@ -379,24 +379,26 @@ __global__ __launch_bounds__(512) void gemm_lw_kernel(const gemm_mats mats, int 
             for (int nt = 0; nt < NT; nt++)
                 asm volatile("" : "+v"(f[nt]));
         };
-        auto dq = [&](auto halfc, int t8) -> half8_t { // weight fragment of K-step t8 of a half, from the CURRENT qa/qb/hd/hq
+        // weight fragment of K-step t8 of a half from the nibble words (wa, wb), the row header hdr and the fifth bits hqv
+        auto dq_of = [&](auto halfc, int t8, const u32x4 &wa, const u32x4 &wb, const u32x4 &hdr, const u32x4 &hqv) -> half8_t {
             constexpr int half = decltype(halfc)::value;
             uint32_t sc03, sc47, mn03, mn47;
-            q4k_scales_bytes(hd.y, hd.z, hd.w, sc03, sc47, mn03, mn47);
+            q4k_scales_bytes(hdr.y, hdr.z, hdr.w, sc03, sc47, mn03, mn47);
             const uint32_t scw = half ? sc47 : sc03;
-            const half2_t dh2 = as_half2(__builtin_amdgcn_perm(hd.x, hd.x, 0x01000100u));
+            const half2_t dh2 = as_half2(__builtin_amdgcn_perm(hdr.x, hdr.x, 0x01000100u));
             const q4_consts2 cp = q4_consts_pair_scaled(scw, (t8 & 4) ? 2 : 0, dh2);
             const int hsel = (t8 >> 1) & 1;
             const half2_t S = {cp.S[hsel], cp.S[hsel]}, O = {cp.O[hsel], cp.O[hsel]};
             const half2_t S16 = {cp.S16[hsel], cp.S16[hsel]}, O16 = {cp.O16[hsel], cp.O16[hsel]};
-            const uint32_t qw[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+            const uint32_t qw[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
             if constexpr (Q5) {
-                const uint32_t hq5[4] = {hq.x, hq.y, hq.z, hq.w};
+                const uint32_t hq5[4] = {hqv.x, hqv.y, hqv.z, hqv.w};
                 return dequant_q5(qw[t8], hq5[2 * half + (t8 >> 2)] >> (t8 & 3), S, O, S16, O16, magic);
             } else {
                 return dequant_q4(qw[t8], S, O, S16, O16, magic);
             }
         };
+        auto dq = [&](auto halfc, int t8) -> half8_t { return dq_of(halfc, t8, qa, qb, hd, hq); }; // from the CURRENT operands
         const uint32_t wq_off = (uint32_t)(rw * 2048 + lane * 16) + LW_W, hd_off = (uint32_t)(rw * 1024 + i * 16) + LW_HDR;
         const uint32_t hq_off = (uint32_t)(rw * 1024 + lane * 16) + LW_QH, xm_off = (uint32_t)(i * 32 + h * 16) + LW_XM;
         half8_t wf;
@@ -444,14 +446,20 @@ __global__ __launch_bounds__(512) void gemm_lw_kernel(const gemm_mats mats, int 
                     read_frags(F[0], slot_next, 0);
                 } else {
                     // younger than K-step 7's fragments: [mins NT] + qa/qb 2 + [header 1 (+ fifth bits 1)] + fragments NT
-                    constexpr int N7 = (half ? NT : 0) + 2 + (half ? 1 + (Q5 ? 1 : 0) : 0) + NT;
-                    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N7));
-                    pin(F[3]);
+                    // K-step 6's look-ahead reads are older than the next stage's two fragment groups: wait for them here
+                    // too, so that the next half's first weight fragment is built under this K-step's MFMAs instead of
+                    // between two half-steps
                     read_frags(F[1], slot_next, 1);
+                    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(qan), "+v"(qbn), "+v"(hdn), "+v"(hqn) : "n"(2 * NT));
+                    pin(F[3]);
                 }
                 half8_t wn = wf;
                 if (t8 + 1 < 8)
                     wn = dq(halfc, t8 + 1);
+                else if constexpr (half == 1)
+                    wn = dq_of(HN{}, 0, qan, qbn, hdn, hqn); // next super-block: header fetched in K-step 6
+                else
+                    wn = dq_of(HN{}, 0, qan, qbn, hd, hq);
 #pragma unroll
                 for (int nt = 0; nt < NT; nt++) // weights are the A operand here: a lane ends up with 4 consecutive ROWS per token
                     acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, F[t8 & 3][nt], acc[nt], 0, 0, 0);
@@ -462,9 +470,7 @@ __global__ __launch_bounds__(512) void gemm_lw_kernel(const gemm_mats mats, int 
                 }
                 wf = wn;
             }
-            // everything older than the two fragment groups of the next stage: its nibbles / header, this super-block's mins
-            asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(qan), "+v"(qbn), "+v"(hdn), "+v"(hqn) : "n"(2 * NT));
-            if constexpr (half == 1) {
+            if constexpr (half == 1) { // (the mins fragments were covered by K-step 7's wait)
                 pin(fxm);
                 uint32_t sc03, sc47, mn03, mn47;
                 q4k_scales_bytes(hd.y, hd.z, hd.w, sc03, sc47, mn03, mn47);
@@ -483,7 +489,6 @@ __global__ __launch_bounds__(512) void gemm_lw_kernel(const gemm_mats mats, int 
                 hd = hdn, hq = hqn;
             }
             qa = qan, qb = qbn;
-            wf = dq(HN{}, 0);
         };
 
         // prologue: stage 0
