@@ -544,12 +544,18 @@ __global__ __launch_bounds__(512) void gemm_lw_kernel(const gemm_mats mats, int 
 #pragma unroll
             for (int nt = 0; nt < NT; nt++) {
                 const long tok = n0 + nt * 32 + i;
-                if (tok >= n)
+                long crow = tok; // the row of C this token's outputs go to
+                if constexpr (MOE) {
+                    if (nt * 32 + i >= moe_left)
+                        continue;
+                    crow = (long)mats.moe_slot_row[tok];
+                } else if (tok >= n) {
                     continue;
+                }
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
                     const long row0 = rt * 32 + 8 * g + 4 * h;
-                    float *dst = C + tok * ldc + row0;
+                    float *dst = C + crow * ldc + row0;
                     if (vec) {
                         if (row0 < m)
                             *(float4 *)dst = make_float4(acc[nt][4 * g], acc[nt][4 * g + 1], acc[nt][4 * g + 2], acc[nt][4 * g + 3]);
@@ -596,7 +602,9 @@ hipError_t lfamd_lw_go(int Atype, const gemm_mats &mats, int nb, const void *Xh,
                                                     n_pad, n_rb, n_ct)
 #define LW_GO2(T)                                                                                                      \
     do {                                                                                                               \
-        if (moe)                                                                                                       \
+        if (moe && fast)                                                                                               \
+            LW_GO(T, true, true, 4);                                                                                   \
+        else if (moe)                                                                                                  \
             LW_GO(T, true, false, 4);                                                                                  \
         else if (fast && nt == 2)                                                                                      \
             LW_GO(T, false, true, 2);                                                                                  \

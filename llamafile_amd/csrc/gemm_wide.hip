@@ -40,8 +40,8 @@ static hipError_t wide_go(int Atype, WIDE_ARGS) {
             const int n_ct2 = (int)((n + 63) / 64);
             return lfamd_lw_go(Atype, mats, nb, Xh, d8T, Xm, n, n_pad, n_rb, n_ct2, (unsigned)(n_rb * n_ct2), 0, 1, 2, s);
         }
-        if (ks == 1)
-            return lfamd_lw_go(Atype, mats, nb, Xh, d8T, Xm, n, n_pad, n_rb, n_ct, n_wg, moe, 0, 4, s);
+        if (ks == 1) // exact codes; the grouped MUL_MAT_ID launch also on scaled operands
+            return lfamd_lw_go(Atype, mats, nb, Xh, d8T, Xm, n, n_pad, n_rb, n_ct, n_wg, moe, moe ? g_scaled : 0, 4, s);
     }
     if (g_scaled)
         return hipErrorInvalidValue; // scaled activations reached a body that expects integer codes

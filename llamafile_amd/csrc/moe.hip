@@ -112,6 +112,8 @@ extern "C" hipError_t lfamd_launch_prep_q8k(const void *, size_t, long, long, lo
                                             hipStream_t);
 extern "C" hipError_t lfamd_launch_prep_f32(const void *, size_t, long, long, long, void *, void *, void *, int, const int32_t *,
                                             hipStream_t);
+extern "C" void lfamd_gemm_wide_mode(int);
+extern "C" int lfamd_gemm_wide_scaled_ok(int, int);
 extern "C" hipError_t lfamd_launch_gemm_wide_moe(int, const void *, long, int, long, long, const void *, const void *, const void *,
                                                  long, const int *, const int *, const int *, int, float *, long, hipStream_t);
 
@@ -188,9 +190,14 @@ extern "C" hipError_t lfamd_launch_moe(int type, const void *W, long rows, long 
         hipError_t e2 = hipGetLastError();
         if (e2 != hipSuccess)
             return e2;
+        // Q4_K / Q5_K experts: scaled operands like lfamd_mul_mat's batches, unless LFAMD_FLAG_PRECISE
+        const int plain = (flags & LFAMD_FLAG_GEMM_PLAIN) ? 1 : 0;
+        const int scaled = (flags & LFAMD_FLAG_PRECISE) ? 0 : lfamd_gemm_wide_scaled_ok(type, plain);
+        lfamd_gemm_wide_mode(plain | (scaled << 1));
+        const int pmode = scaled ? 2 : 0;
         e2 = Btype == LFAMD_TYPE_F32
-                 ? lfamd_launch_prep_f32(thought, b_row_bytes, (long)n_pad, (long)n_pad, cols, Xh, d8T, Xm, 0, src_row, s)
-                 : lfamd_launch_prep_q8k(thought, b_row_bytes, (long)n_pad, (long)n_pad, cols, Xh, d8T, Xm, 0, src_row, s);
+                 ? lfamd_launch_prep_f32(thought, b_row_bytes, (long)n_pad, (long)n_pad, cols, Xh, d8T, Xm, pmode, src_row, s)
+                 : lfamd_launch_prep_q8k(thought, b_row_bytes, (long)n_pad, (long)n_pad, cols, Xh, d8T, Xm, pmode, src_row, s);
         if (e2 != hipSuccess)
             return e2;
         const int ct_max = (int)((nr + 127) / 128);

@@ -452,6 +452,10 @@ bool llamafile_mixmul(const struct ggml_compute_params *params, const struct ggm
                     g.api.sync(nullptr))
                     die("expert weight upload failed");
             }
+            const int in_range = g.api.scaled_ok(wt, (long)experts * ((rows + 31) / 32) * 32, cols, nw.d_packed, nullptr);
+            if (in_range < 0)
+                die("expert weight range check failed");
+            nw.exact_only = in_range == 0;
             w = &(g.cache[weights->data] = nw);
         }
     }
@@ -492,7 +496,7 @@ bool llamafile_mixmul(const struct ggml_compute_params *params, const struct ggm
     if (g.api.h2d(g.plan.p, hplan.data(), hplan.size() * 4, nullptr) || g.api.sync(nullptr))
         die("plan upload failed");
     if (g.api.mul_mat_id(wt, w->d_packed, rows, cols, experts, bt, g.b.p, brow, tasks, tokens, (const int32_t *)g.plan.p,
-                         thinkers, (float *)g.c.p, g.ws.p, g.ws.cap, flags_now(), nullptr))
+                         thinkers, (float *)g.c.p, g.ws.p, g.ws.cap, flags_now() | (w->exact_only ? LFAMD_FLAG_PRECISE : 0u), nullptr))
         die("device mul_mat_id failed");
     std::vector<float> hres((size_t)tokens * thinkers * rows);
     if (g.api.d2h(hres.data(), g.c.p, rbytes, nullptr) || g.api.sync(nullptr))

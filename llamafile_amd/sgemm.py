@@ -191,6 +191,9 @@ def llamafile_sgemm(m: int, n: int, k: int, A: PackedWeights, lda: int, B: torch
     return True
 
 
+_moe_scaled_ok: dict = {}
+
+
 def mul_mat_id(Ws: torch.Tensor, wtype: int, rows: int, cols: int, experts: int, thought: torch.Tensor, Btype: int,
                tasks: int, tokens: int, plan: torch.Tensor, thinkers: int, flags: int | None = None,
                prefill: float | None = None) -> torch.Tensor:
@@ -198,6 +201,16 @@ def mul_mat_id(Ws: torch.Tensor, wtype: int, rows: int, cols: int, experts: int,
     [tokens*tasks, row_bytes]; plan int32 [tokens, thinkers].  Returns f32 [tokens, thinkers, rows]."""
     L = _hip.lib()
     flags = host_variant_flags() if flags is None else flags
+    if wtype in (T.Q4_K, T.Q5_K) and tokens > 4:
+        # batches run on scaled operands: check the stack's block scales once (cf. upload_weights)
+        key = (Ws.data_ptr(), Ws.numel(), wtype)
+        if key not in _moe_scaled_ok:
+            ok = L.lfamd_scaled_gemm_ok(wtype, experts * ((rows + 31) // 32) * 32, cols, _ptr(Ws), _stream())
+            if ok < 0:
+                raise _hip.LfamdError("lfamd_scaled_gemm_ok failed")
+            _moe_scaled_ok[key] = ok == 1
+        if not _moe_scaled_ok[key]:
+            flags |= _hip.FLAG_PRECISE
     res = torch.empty((tokens, thinkers, rows), dtype=torch.float32, device=thought.device)
     if prefill is not None:  # tests: rows of out-of-range expert ids must stay untouched
         res.fill_(prefill)

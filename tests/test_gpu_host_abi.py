@@ -133,7 +133,8 @@ def test_llamafile_mixmul(host, oracle, wt, tokens, tasks):
     if wt == T.Q8_0:
         assert np.array_equal(res.view(np.uint32), G.view(np.uint32))
     else:
-        assert rel_err(res, G) <= 2e-6
+        # Q4_K experts in batches (> 4 tokens) run the grouped MFMA launch on scaled operands (1e-3, include/lfamd_hip.h)
+        assert rel_err(res, G) <= (1e-3 if wt == T.Q4_K and tokens > 4 else 2e-6)
 
 
 def test_llamafile_mixmul_iqk_row_mapping(host, oracle):

@@ -443,18 +443,22 @@ def test_mul_mat_id_batches_grouped_on_device(gpu, oracle, t, tokens, tasks, f32
     else:
         thought = torch.from_numpy(xq).cuda()
         bt = T.Q8_K
-    res = gpu.mul_mat_id(packed, t, rows, cols, experts, thought, bt, tasks, tokens, torch.from_numpy(plan).cuda(), thinkers,
-                         prefill=-7.0)
-    torch.cuda.synchronize()
-    res = res.cpu().numpy()
-    tol = GEMM_TOL[t]
-    for ex in range(experts):
-        sel = [(tok, th) for tok in range(tokens) for th in range(thinkers) if plan[tok, th] == ex]
-        if not sel:
-            continue
-        Bx = np.stack([xq[tok * tasks + th % tasks] for tok, th in sel])
-        ok, G = oracle.sgemm(t, Ws[ex], T.Q8_K, Bx, rows, len(sel), cols)
-        assert ok == 1
-        got = np.stack([res[tok, th] for tok, th in sel])
-        assert rel_err(got, G) <= tol, (ex, rel_err(got, G))
-    assert (res[-1, -1] == -7.0).all()
+    from llamafile_amd import _hip
+    golden = {}
+    # batches of Q4_K / Q5_K experts: scaled operands by default, exact integer codes with LFAMD_FLAG_PRECISE
+    for flags, tol in ((0, SCALED_TOL if t in (T.Q4_K, T.Q5_K) and tokens > 4 else GEMM_TOL[t]), (_hip.FLAG_PRECISE, GEMM_TOL[t])):
+        res = gpu.mul_mat_id(packed, t, rows, cols, experts, thought, bt, tasks, tokens, torch.from_numpy(plan).cuda(), thinkers,
+                             flags=gpu.host_variant_flags() | flags, prefill=-7.0)
+        torch.cuda.synchronize()
+        res = res.cpu().numpy()
+        for ex in range(experts):
+            sel = [(tok, th) for tok in range(tokens) for th in range(thinkers) if plan[tok, th] == ex]
+            if not sel:
+                continue
+            if ex not in golden:
+                Bx = np.stack([xq[tok * tasks + th % tasks] for tok, th in sel])
+                ok, golden[ex] = oracle.sgemm(t, Ws[ex], T.Q8_K, Bx, rows, len(sel), cols)
+                assert ok == 1
+            got = np.stack([res[tok, th] for tok, th in sel])
+            assert rel_err(got, golden[ex]) <= tol, (ex, flags, rel_err(got, golden[ex]))
+        assert (res[-1, -1] == -7.0).all()
