@@ -130,7 +130,9 @@ int lfamd_mul_mat_multi_types(int count, const int *Atype, const void *const *d_
  * Decode (tokens <= 4, Q4_K / Q6_K experts): the GEMV kernels read the expert index from d_plan themselves; thinkers
  * sharing their activations (tasks == 1) are one launch.  Batches of Q4_K / Q5_K / Q6_K experts (up to 60 Ki rows): a
  * one-work-group routing kernel groups the rows by expert on the device and ONE launch of the 128x128 MFMA body covers
- * (expert, row block, token tile).  Both are asynchronous and graph-capturable — no host read-back (the reference
+ * (expert, row block, token tile) — Q4_K / Q5_K on scaled operands like lfamd_mul_mat's batches (exact integer codes with
+ * LFAMD_FLAG_PRECISE; lfamd_scaled_gemm_ok over the whole stack: rows = experts * roundup(rows, 32)).  Both are
+ * asynchronous and graph-capturable — no host read-back (the reference
  * synchronises, ggml-cuda.cu.patch:18528-18531) — and accept Btype F32 (quantised on the device).  Rows whose expert id
  * is out of range are left untouched.  Other expert types gather rows per expert after a routing read-back and run one
  * mat-mul per expert. */
