@@ -38,13 +38,13 @@ size_t lfamd_gemm_q80_workspace(long, long);
 hipError_t lfamd_launch_gemv_dual(int, int, const void *const *, const long *, float *const *, const long *, int, int,
                                   const void *const *, const long *, float *const *, const long *, long, int, const void *, size_t,
                                   hipStream_t);
-void lfamd_gemm_wide_mode(int);
 hipError_t lfamd_launch_scaled_ok(int, long, long, const void *, int *, hipStream_t);
 int lfamd_gemm_wide_scaled_ok(int, int);
+// (the wide launchers take `mode`: bit 0 plain body, bit 1 activations staged scaled — gemm_wide.hip)
 hipError_t lfamd_launch_gemm_wide_multi(int, int, const void *const *, const long *, long, const void *, const void *,
-                                        const void *, long, long, float *const *, const long *, hipStream_t);
+                                        const void *, long, long, float *const *, const long *, int, hipStream_t);
 hipError_t lfamd_launch_gemm_wide(int, const void *, long, long, const void *, const void *, const void *, long, long,
-                                  float *, long, hipStream_t);
+                                  float *, long, int, hipStream_t);
 hipError_t lfamd_launch_gemm_kq(int, const void *, long, long, const void *, const void *, const void *, long, long,
                                 float *, long, hipStream_t);
 hipError_t lfamd_launch_quantize(int, const float *, long, long, size_t, void *, size_t, hipStream_t);
@@ -331,7 +331,6 @@ int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const v
                   float *d_C, long ldc, void *d_ws, size_t ws_bytes, unsigned flags, void *stream) {
     (void)hipGetLastError(); // a stale error of an earlier call (e.g. an invalidated stream capture) must not fail this one
     const int plain = (flags & LFAMD_FLAG_GEMM_PLAIN) ? 1 : 0;
-    lfamd_gemm_wide_mode(plain);
     if (!type_known(Atype))
         return fail(LFAMD_ERR_UNSUPPORTED, "mul_mat: unsupported weight type%s", "");
     if (m < 0 || n < 0 || k < 0 || ldc < m || k % lfamd_blck_size(Atype))
@@ -363,7 +362,7 @@ int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const v
         void *Xm = (uint8_t *)d8T + align_up(nb * n_pad * 4, 256);
         if (Atype == LFAMD_TYPE_Q4_0) { // Q8_0-quantised activations, eight scales per 256 (they take the Xm area too)
             HIPCHK(lfamd_launch_prep80(Btype, d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, nullptr, s), "prep80");
-            HIPCHK(lfamd_launch_gemm_wide(Atype, d_A, m, k, Xh, d8T, nullptr, n, (long)n_pad, d_C, ldc, s), "gemm_wide");
+            HIPCHK(lfamd_launch_gemm_wide(Atype, d_A, m, k, Xh, d8T, nullptr, n, (long)n_pad, d_C, ldc, plain, s), "gemm_wide");
             return LFAMD_OK;
         }
         // two bodies: 128 x 128 tiles, K streamed once (gemm_wide.hip) when that grid fills the 256 CUs; the
@@ -379,7 +378,6 @@ int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const v
                             : body                           ? body[0] == 'n'
                                                              : (tiles128 < 192 && !(can_scale && tiles128 >= LW_MIN_TILES));
         const int scaled = !narrow && can_scale;
-        lfamd_gemm_wide_mode(plain | (scaled << 1));
         if (Btype == LFAMD_TYPE_F32)
             HIPCHK(lfamd_launch_prep_f32(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, scaled ? 2 : 0, nullptr, s), "prep_f32");
         else
@@ -387,7 +385,7 @@ int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const v
         if (narrow)
             HIPCHK(lfamd_launch_gemm_kq(Atype, d_A, m, k, Xh, d8T, Xm, n, (long)n_pad, d_C, ldc, s), "gemm_kq");
         else
-            HIPCHK(lfamd_launch_gemm_wide(Atype, d_A, m, k, Xh, d8T, Xm, n, (long)n_pad, d_C, ldc, s), "gemm_wide");
+            HIPCHK(lfamd_launch_gemm_wide(Atype, d_A, m, k, Xh, d8T, Xm, n, (long)n_pad, d_C, ldc, plain | (scaled << 1), s), "gemm_wide");
         return LFAMD_OK;
     }
     if (use_gemm_float(Atype, n, flags, k)) {
@@ -396,7 +394,7 @@ int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const v
             return fail(LFAMD_ERR_WORKSPACE, "mul_mat: workspace too small%s", "");
         size_t n_pad = align_up((size_t)n, 128);
         HIPCHK(lfamd_launch_prep_float(Atype, Btype, d_B, b_row_bytes, n, (long)n_pad, k, d_ws, s), "prep_float");
-        HIPCHK(lfamd_launch_gemm_wide(Atype, d_A, m, k, d_ws, d_ws, d_ws, n, (long)n_pad, d_C, ldc, s), "gemm_wide");
+        HIPCHK(lfamd_launch_gemm_wide(Atype, d_A, m, k, d_ws, d_ws, d_ws, n, (long)n_pad, d_C, ldc, plain, s), "gemm_wide");
         return LFAMD_OK;
     }
     if (use_gemm_canon32(Atype, n, flags, k)) {
@@ -412,7 +410,7 @@ int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const v
         const bool q81 = vdt == LFAMD_TYPE_Q8_1;
         HIPCHK(lfamd_launch_wprep32(Atype, d_A, m, k, img, s), "wprep32");
         HIPCHK(lfamd_launch_prep80(Btype, d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, q81 ? sT : nullptr, s), "prep80");
-        HIPCHK(lfamd_launch_gemm_wide(Atype, img, m, k, Xh, d8T, q81 ? sT : nullptr, n, (long)n_pad, d_C, ldc, s), "gemm_wide");
+        HIPCHK(lfamd_launch_gemm_wide(Atype, img, m, k, Xh, d8T, q81 ? sT : nullptr, n, (long)n_pad, d_C, ldc, plain, s), "gemm_wide");
         return LFAMD_OK;
     }
     if (use_gemm_canon(Atype, n, flags)) {
@@ -434,7 +432,7 @@ int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const v
             HIPCHK(lfamd_launch_prep_f32(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, mins16, nullptr, s), "prep_f32");
         else
             HIPCHK(lfamd_launch_prep_q8k(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, mins16, nullptr, s), "prep_q8k");
-        HIPCHK(lfamd_launch_gemm_wide(Atype, img, m, k, Xh, d8T, Xm, n, (long)n_pad, d_C, ldc, s), "gemm_wide");
+        HIPCHK(lfamd_launch_gemm_wide(Atype, img, m, k, Xh, d8T, Xm, n, (long)n_pad, d_C, ldc, plain, s), "gemm_wide");
         return LFAMD_OK;
     }
     if (use_gemm_q80(Atype, n, flags)) {
@@ -533,7 +531,6 @@ int lfamd_mul_mat_multi(int Atype, int count, const void *const *d_A, const long
                         unsigned flags, void *stream) {
     (void)hipGetLastError(); // a stale error of an earlier call (e.g. an invalidated stream capture) must not fail this one
     const int plain = (flags & LFAMD_FLAG_GEMM_PLAIN) ? 1 : 0;
-    lfamd_gemm_wide_mode(plain);
     if (count <= 0)
         return LFAMD_OK;
     // one fused launch when the GEMV path applies to every matrix; otherwise one mul_mat per matrix
@@ -578,12 +575,11 @@ int lfamd_mul_mat_multi(int Atype, int count, const void *const *d_A, const long
             void *d8T = ws + align_up(n_pad * (size_t)k * 2, 256);
             void *Xm = (uint8_t *)d8T + align_up(nb * n_pad * 4, 256);
             const int scaled = (flags & LFAMD_FLAG_PRECISE) ? 0 : lfamd_gemm_wide_scaled_ok(Atype, plain);
-            lfamd_gemm_wide_mode(plain | (scaled << 1));
-            if (Btype == LFAMD_TYPE_F32)
+                if (Btype == LFAMD_TYPE_F32)
                 HIPCHK(lfamd_launch_prep_f32(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, scaled ? 2 : 0, nullptr, s), "prep_f32");
             else
                 HIPCHK(lfamd_launch_prep_q8k(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, scaled ? 2 : 0, nullptr, s), "prep_q8k");
-            HIPCHK(lfamd_launch_gemm_wide_multi(Atype, count, d_A, m, k, Xh, d8T, Xm, n, (long)n_pad, d_C, ldc, s),
+            HIPCHK(lfamd_launch_gemm_wide_multi(Atype, count, d_A, m, k, Xh, d8T, Xm, n, (long)n_pad, d_C, ldc, plain | (scaled << 1), s),
                    "gemm_wide_multi");
             return LFAMD_OK;
         }
@@ -604,7 +600,6 @@ int lfamd_mul_mat_id(int type, const void *d_W, long rows, long cols, int expert
                      size_t b_row_bytes, int tasks, long tokens, const int32_t *d_plan, int thinkers, float *d_result,
                      void *d_ws, size_t ws_bytes, unsigned flags, void *stream) {
     (void)hipGetLastError(); // a stale error of an earlier call (e.g. an invalidated stream capture) must not fail this one
-    lfamd_gemm_wide_mode((flags & LFAMD_FLAG_GEMM_PLAIN) ? 1 : 0);
     if (!type_known(type))
         return fail(LFAMD_ERR_UNSUPPORTED, "mul_mat_id: unsupported weight type%s", "");
     if (rows < 0 || cols < 0 || cols % lfamd_blck_size(type) || experts <= 0 || tasks <= 0 || thinkers <= 0 ||

@@ -19,20 +19,17 @@ hipError_t lfamd_lw_go(int Atype, const gemm_mats &mats, int nb, const void *Xh,
                        int n_rb, int n_ct, unsigned n_wg, int moe, int fast, int nt, hipStream_t s);
 
 // Q4_K / Q5_K without K split run the loader-wave body (gemm_lw.hip) unless the caller asks for the plain one.
-// mode bit 0: plain body; bit 1: the activations were staged SCALED (pack.hip, prep mode 2) for the scaled-operand
+// `mode` (an argument of every launcher here) bit 0: plain body; bit 1: the activations were staged SCALED (pack.hip, prep mode 2) for the scaled-operand
 // loader-wave body — only set when lfamd_gemm_wide_scaled_ok() said that body will run.
 #define LW_FULL_GRID 192 // 128 x 128 tiles from which the 256 CUs count as filled (as wide_ksplit)
-static int g_plain_wide = 0, g_scaled = 0;
-extern "C" void lfamd_gemm_wide_mode(int mode) {
-    g_plain_wide = mode & 1, g_scaled = (mode >> 1) & 1;
-}
-static bool lw_allowed() {
+static bool lw_allowed(int mode) {
     static const bool env_plain = getenv("LFAMD_GEMM_NO_LW") != nullptr;
-    return !g_plain_wide && !env_plain;
+    return !(mode & 1) && !env_plain;
 }
 
-static hipError_t wide_go(int Atype, WIDE_ARGS) {
-    if ((Atype == LFAMD_TYPE_Q4_K || Atype == LFAMD_TYPE_Q5_K) && lw_allowed()) {
+static hipError_t wide_go(int Atype, int mode, WIDE_ARGS) {
+    const int g_scaled = (mode >> 1) & 1;
+    if ((Atype == LFAMD_TYPE_Q4_K || Atype == LFAMD_TYPE_Q5_K) && lw_allowed(mode)) {
         if (g_scaled && !moe) {
             // scaled operands: 128 x 128 tiles when they fill the chip, else 128 x 64 (twice the work-groups, no K split)
             if (n_rb * n_ct >= LW_FULL_GRID)
@@ -105,7 +102,7 @@ extern "C" int lfamd_gemm_wide_scaled_ok(int Atype, int plain) {
 
 extern "C" hipError_t lfamd_launch_gemm_wide_multi(int Atype, int count, const void *const *A, const long *m, long k,
                                                    const void *Xh, const void *d8T, const void *Xm, long n, long n_pad,
-                                                   float *const *C, const long *ldc, hipStream_t s) {
+                                                   float *const *C, const long *ldc, int mode, hipStream_t s) {
     if (n <= 0 || count <= 0)
         return hipSuccess;
     if (n_pad % WD_COLS || count > GEMM_MAX_MATS)
@@ -128,7 +125,7 @@ extern "C" hipError_t lfamd_launch_gemm_wide_multi(int Atype, int count, const v
     for (int i = mats.count; i < GEMM_MAX_MATS; i++)
         mats.A[i] = mats.A[0], mats.C[i] = mats.C[0], mats.m[i] = 0, mats.ldc[i] = 0, mats.rb_end[i] = n_rb;
     const int n_ct = (int)(n_pad / WD_COLS);
-    const bool scaled_lw = g_scaled && lw_allowed() && (Atype == LFAMD_TYPE_Q4_K || Atype == LFAMD_TYPE_Q5_K);
+    const bool scaled_lw = (mode & 2) && lw_allowed(mode) && (Atype == LFAMD_TYPE_Q4_K || Atype == LFAMD_TYPE_Q5_K);
     const int ks = scaled_lw ? 1 : wide_ksplit(n_rb * n_ct, nb); // the scaled-operand body never splits K
     const int nbs = (nb + ks - 1) / ks;
     const int n_wg = n_rb * n_ct * ks;
@@ -139,12 +136,12 @@ extern "C" hipError_t lfamd_launch_gemm_wide_multi(int Atype, int count, const v
             zero_c_kernel<<<blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks), 256, 0, s>>>(mats.C[i], mats.ldc[i], mats.m[i], n);
         }
     }
-    return wide_go(Atype, mats, nb, Xh, d8T, Xm, n, n_pad, n_rb, n_ct, ks, nbs, (unsigned)n_wg, 0, s);
+    return wide_go(Atype, mode, mats, nb, Xh, d8T, Xm, n, n_pad, n_rb, n_ct, ks, nbs, (unsigned)n_wg, 0, s);
 }
 
 extern "C" hipError_t lfamd_launch_gemm_wide(int Atype, const void *A, long m, long k, const void *Xh, const void *d8T,
-                                             const void *Xm, long n, long n_pad, float *C, long ldc, hipStream_t s) {
-    return lfamd_launch_gemm_wide_multi(Atype, 1, &A, &m, k, Xh, d8T, Xm, n, n_pad, &C, &ldc, s);
+                                             const void *Xm, long n, long n_pad, float *C, long ldc, int mode, hipStream_t s) {
+    return lfamd_launch_gemm_wide_multi(Atype, 1, &A, &m, k, Xh, d8T, Xm, n, n_pad, &C, &ldc, mode, s);
 }
 
 // GGML_OP_MUL_MAT_ID batches: one launch over (expert, row block, token tile); see gemm_mats.  n_pad = slots staged by the
@@ -152,7 +149,7 @@ extern "C" hipError_t lfamd_launch_gemm_wide(int Atype, const void *A, long m, l
 extern "C" hipError_t lfamd_launch_gemm_wide_moe(int Atype, const void *W, long expert_bytes, int experts, long m, long k,
                                                  const void *Xh, const void *d8T, const void *Xm, long n_pad, const int *cnt,
                                                  const int *poff, const int *slot_row, int ct_max, float *C, long ldc,
-                                                 hipStream_t s) {
+                                                 int mode, hipStream_t s) {
     if (m <= 0 || experts <= 0 || ct_max <= 0)
         return hipSuccess;
     const int nb = (int)(k / 256);
@@ -165,5 +162,5 @@ extern "C" hipError_t lfamd_launch_gemm_wide_moe(int Atype, const void *W, long 
     const unsigned n_wg = (unsigned)experts * n_rb * ct_max;
     if (Atype != LFAMD_TYPE_Q4_K && Atype != LFAMD_TYPE_Q5_K && Atype != LFAMD_TYPE_Q6_K)
         return hipErrorInvalidValue;
-    return wide_go(Atype, mats, nb, Xh, d8T, Xm, n_pad, n_pad, n_rb, ct_max, 1, nb, n_wg, 1, s);
+    return wide_go(Atype, mode, mats, nb, Xh, d8T, Xm, n_pad, n_pad, n_rb, ct_max, 1, nb, n_wg, 1, s);
 }

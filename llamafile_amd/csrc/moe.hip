@@ -112,10 +112,9 @@ extern "C" hipError_t lfamd_launch_prep_q8k(const void *, size_t, long, long, lo
                                             hipStream_t);
 extern "C" hipError_t lfamd_launch_prep_f32(const void *, size_t, long, long, long, void *, void *, void *, int, const int32_t *,
                                             hipStream_t);
-extern "C" void lfamd_gemm_wide_mode(int);
 extern "C" int lfamd_gemm_wide_scaled_ok(int, int);
 extern "C" hipError_t lfamd_launch_gemm_wide_moe(int, const void *, long, int, long, long, const void *, const void *, const void *,
-                                                 long, const int *, const int *, const int *, int, float *, long, hipStream_t);
+                                                 long, const int *, const int *, const int *, int, float *, long, int, hipStream_t);
 
 static size_t moe_grouped_ws(long cols, long tokens, int thinkers, int experts) {
     const size_t n_pad = moe_grouped_slots(tokens, thinkers, experts), nb = (size_t)(cols / 256);
@@ -193,7 +192,6 @@ extern "C" hipError_t lfamd_launch_moe(int type, const void *W, long rows, long 
         // Q4_K / Q5_K experts: scaled operands like lfamd_mul_mat's batches, unless LFAMD_FLAG_PRECISE
         const int plain = (flags & LFAMD_FLAG_GEMM_PLAIN) ? 1 : 0;
         const int scaled = (flags & LFAMD_FLAG_PRECISE) ? 0 : lfamd_gemm_wide_scaled_ok(type, plain);
-        lfamd_gemm_wide_mode(plain | (scaled << 1));
         const int pmode = scaled ? 2 : 0;
         e2 = Btype == LFAMD_TYPE_F32
                  ? lfamd_launch_prep_f32(thought, b_row_bytes, (long)n_pad, (long)n_pad, cols, Xh, d8T, Xm, pmode, src_row, s)
@@ -202,7 +200,7 @@ extern "C" hipError_t lfamd_launch_moe(int type, const void *W, long rows, long 
             return e2;
         const int ct_max = (int)((nr + 127) / 128);
         return lfamd_launch_gemm_wide_moe(type, W, (long)expert_bytes, experts, rows, cols, Xh, d8T, Xm, (long)n_pad, cnt, poff,
-                                          slot_row, ct_max, result, rows, s);
+                                          slot_row, ct_max, result, rows, plain | (scaled << 1), s);
     }
     std::vector<int32_t> hplan(nr);
     hipError_t e = hipMemcpyAsync(hplan.data(), plan, nr * 4, hipMemcpyDeviceToHost, s);
