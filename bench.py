@@ -425,8 +425,8 @@ def main():
             "workload": f"Llama-3-8B Q4_K_M mat-muls (225 GGML_OP_MUL_MAT per pass, f32 activations in, quantisation fused, sibling ops fused at decode), "
                         f"{a.prefill}-token prefill + {a.decode} decode, matmul-only",
             "numerics": "decode: exact int8 x int4/int6 block dot products with f32 scales (v_dot4_i32_i8); prefill: f16 MFMA, "
-                        "f32 accumulate - Q4_K on scaled operands f16(d*sc*q) x f16(d8*code) (<= 1e-3 relative, measured "
-                        "~3e-4; exact integer codes with LFAMD_FLAG_PRECISE), Q6_K on integer codes with f32 scales",
+                        "f32 accumulate, Q4_K and Q6_K on scaled operands f16(d*sc*q) x f16(d8*code) (<= 1e-3 relative, measured "
+                        "~3e-4; exact integer codes with LFAMD_FLAG_PRECISE)",
             "model": a.model, "prefill_tokens": a.prefill, "decode_tokens": a.decode,
             "parallelism": "single GPU" if world == 1 else f"tp{world} (RCCL all-reduce on attn_output/ffn_down)",
             "hip_graph": use_graph, "weight_bytes_per_gpu": runner.weight_bytes(),

@@ -74,13 +74,13 @@ size_t lfamd_packed_size(int type, long rows, long cols);
 int lfamd_pack_weights(int type, long rows, long cols, const void *d_raw, size_t raw_row_bytes,
                        void *d_packed, void *stream);
 
-/* Batches (n > 8) of Q4_K / Q5_K run the scaled-operand MFMA body by default: weights as f16(d * sc * q), activations as
+/* Batches (n > 8) of Q4_K / Q5_K / Q6_K run the scaled-operand MFMA body by default: weights as f16(d * sc * q), activations as
  * f16(d8 * code), f32 accumulate — one f16 rounding per operand, relative error ~1e-4 (north star: 1e-3), no scaling per
  * super-block.  Its constants need |d| * 63 < 64 and |dmin| * 63 <= 65504 for every block, which every ggml-quantised
  * model satisfies (d = max|w| / (15 * 63)).  lfamd_scaled_gemm_ok checks a packed matrix once after the upload
  * (synchronises the stream): 1 = in range, 0 = out of range -> pass LFAMD_FLAG_PRECISE with this matrix (exact integer
  * codes, f32 scales; out-of-range scales would otherwise surface as inf / NaN outputs), < 0 = error.  Types other than
- * Q4_K / Q5_K: always 1. */
+ * the K-quants with a resident layout: always 1.  (Q6_K: |d| * 127 * 32 <= 65504.) */
 int lfamd_scaled_gemm_ok(int type, long rows, long cols, const void *d_packed, void *stream);
 
 /* ---- activations --------------------------------------------------------------------------

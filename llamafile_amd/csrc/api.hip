@@ -220,7 +220,7 @@ int lfamd_scaled_gemm_ok(int type, long rows, long cols, const void *d_packed, v
     (void)hipGetLastError();
     if (!type_known(type))
         return fail(LFAMD_ERR_UNSUPPORTED, "scaled_gemm_ok: unsupported ggml type%s", "");
-    if ((type != LFAMD_TYPE_Q4_K && type != LFAMD_TYPE_Q5_K) || rows <= 0 || cols <= 0)
+    if ((type != LFAMD_TYPE_Q4_K && type != LFAMD_TYPE_Q5_K && type != LFAMD_TYPE_Q6_K) || rows <= 0 || cols <= 0)
         return 1;
     if (cols % 256 || !d_packed)
         return fail(LFAMD_ERR_INVALID, "scaled_gemm_ok: bad shape%s", "");

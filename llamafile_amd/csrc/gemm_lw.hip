@@ -45,11 +45,12 @@ template <int TYPE, bool MOE, bool FAST, int NT>
 __global__ __launch_bounds__(512) void gemm_lw_kernel(const gemm_mats mats, int nb, const _Float16 *__restrict__ Xh,
                                                       const float *__restrict__ d8T, const _Float16 *__restrict__ Xm, long n,
                                                       long n_pad, int n_rb, int n_ct) {
-    static_assert(TYPE == LFAMD_TYPE_Q4_K || TYPE == LFAMD_TYPE_Q5_K, "resident Q4_K-family layouts only");
+    static_assert(TYPE == LFAMD_TYPE_Q4_K || TYPE == LFAMD_TYPE_Q5_K || (TYPE == LFAMD_TYPE_Q6_K && FAST && !MOE),
+                  "resident K-quant layouts; Q6_K on the scaled-operand body only");
     static_assert(NT == 4 || (NT == 2 && FAST && !MOE), "the 64-token tile exists for the scaled-operand body only");
     constexpr int COLS = 32 * NT;
-    constexpr bool Q5 = TYPE == LFAMD_TYPE_Q5_K;
-    constexpr int TILE = Q5 ? P5K_TILE : P4K_TILE;
+    constexpr bool Q5 = TYPE == LFAMD_TYPE_Q5_K, Q6 = TYPE == LFAMD_TYPE_Q6_K;
+    constexpr int TILE = Q5 ? P5K_TILE : Q6 ? P6K_TILE : P4K_TILE;
     __shared__ __attribute__((aligned(16))) uint8_t lds[LW_STAGES * LW_SLOT + 16];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 31, h = lane >> 5;
@@ -147,7 +148,13 @@ __global__ __launch_bounds__(512) void gemm_lw_kernel(const gemm_mats mats, int 
                 const uint8_t *wg0 = uniform_ptr(tile + (2 * half) * 1024), *wg1 = uniform_ptr(tile + (2 * half + 1) * 1024);
                 glds1x16(wg0, slot + LW_W + lw * 2048, (uint32_t)(lane * 16));
                 glds1x16(wg1, slot + LW_W + lw * 2048 + 1024, (uint32_t)(lane * 16));
-                if constexpr (half == 0) {
+                if constexpr (Q6) { // upper two bits of this half's codes; with the first half the 16 int8 scales and the f16 d
+                    glds1x16(uniform_ptr(tile + P6K_QH + half * 1024), slot + LW_QH + lw * 1024, (uint32_t)(lane * 16));
+                    if constexpr (half == 0) {
+                        glds1x16(uniform_ptr(tile + P6K_SC), slot + LW_HDR + lw * 1024, (uint32_t)((lane & 31) * 16));
+                        glds1x4(uniform_ptr(tile + P6K_D), slot + LW_XM + lw * 256, (uint32_t)((lane & 15) * 4)); // 64 B, four times
+                    }
+                } else if constexpr (half == 0) {
                     // 512-byte header: the upper half-wave copies the same rows again into the second half of the 1 KiB slot
                     glds1x16(uniform_ptr(tile + P4K_HDR), slot + LW_HDR + lw * 1024, (uint32_t)((lane & 31) * 16));
                     if constexpr (Q5)
@@ -176,7 +183,7 @@ __global__ __launch_bounds__(512) void gemm_lw_kernel(const gemm_mats mats, int 
         issue(0, H0{}, H1{});
         issue(1, H1{}, H0{});
         issue(1, H1{}, H1{});
-        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * NT + 2) : "memory"); // stage 0 landed (stage 1 = 2 NT + 2 pieces in flight)
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * NT + 2 + (Q6 ? 1 : 0)) : "memory"); // stage 0 landed (only stage 1's pieces in flight)
 #ifdef LW_EXP_NODMA // development: timing without the steady-state DMA (results are garbage)
 #define LW_DMA_IF if (hb == 0)
 #else
@@ -380,8 +387,21 @@ __global__ __launch_bounds__(512) void gemm_lw_kernel(const gemm_mats mats, int 
                 asm volatile("" : "+v"(f[nt]));
         };
         // weight fragment of K-step t8 of a half from the nibble words (wa, wb), the row header hdr and the fifth bits hqv
-        auto dq_of = [&](auto halfc, int t8, const u32x4 &wa, const u32x4 &wb, const u32x4 &hdr, const u32x4 &hqv) -> half8_t {
+        // (Q6_K: hdr = the row's 16 int8 scales, hqv = the upper code bits of THIS half, dbits = its f16 d)
+        auto dq_of = [&](auto halfc, int t8, const u32x4 &wa, const u32x4 &wb, const u32x4 &hdr, const u32x4 &hqv,
+                         uint32_t dbits) -> half8_t {
             constexpr int half = decltype(halfc)::value;
+            if constexpr (Q6) { // f16(d * sc) * (code - 32): the K-step is one 16-wide sub-block (cf. gemm_wide_impl.h)
+                const uint32_t qw[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+                const uint32_t scw4[4] = {hdr.x, hdr.y, hdr.z, hdr.w}, hw[4] = {hqv.x, hqv.y, hqv.z, hqv.w};
+                const int tt = 8 * half + t8;
+                const float scf = (float)(int)(int8_t)((scw4[tt >> 2] >> (8 * (tt & 3))) & 0xff);
+                const half2_t S = bcast_h2(scf * h2f((uint16_t)(dbits & 0xffff)));
+                uint32_t H = hw[t8 >> 1];
+                if (t8 & 1)
+                    H >>= 2;
+                return dequant_q6(qw[t8], H, S);
+            }
             uint32_t sc03, sc47, mn03, mn47;
             q4k_scales_bytes(hdr.y, hdr.z, hdr.w, sc03, sc47, mn03, mn47);
             const uint32_t scw = half ? sc47 : sc03;
@@ -398,7 +418,9 @@ __global__ __launch_bounds__(512) void gemm_lw_kernel(const gemm_mats mats, int 
                 return dequant_q4(qw[t8], S, O, S16, O16, magic);
             }
         };
-        auto dq = [&](auto halfc, int t8) -> half8_t { return dq_of(halfc, t8, qa, qb, hd, hq); }; // from the CURRENT operands
+        uint32_t dw6 = 0, dw6n = 0; // Q6_K: the row's f16 d (current / next super-block)
+        auto dq = [&](auto halfc, int t8) -> half8_t { return dq_of(halfc, t8, qa, qb, hd, hq, dw6); }; // from the CURRENT operands
+        const uint32_t d6_off = (uint32_t)(rw * 256 + i * 2) + LW_XM;
         const uint32_t wq_off = (uint32_t)(rw * 2048 + lane * 16) + LW_W, hd_off = (uint32_t)(rw * 1024 + i * 16) + LW_HDR;
         const uint32_t hq_off = (uint32_t)(rw * 1024 + lane * 16) + LW_QH, xm_off = (uint32_t)(i * 32 + h * 16) + LW_XM;
         half8_t wf;
@@ -426,7 +448,7 @@ __global__ __launch_bounds__(512) void gemm_lw_kernel(const gemm_mats mats, int 
                         asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(fl) : "v"(flag_addr) : "memory");
                         fv = __builtin_amdgcn_readfirstlane(fl);
                     }
-                    if constexpr (half == 1) {
+                    if constexpr (half == 1 && !Q6) {
                         if constexpr (NT == 4)
                             asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\t"
                                          "ds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072"
@@ -438,10 +460,14 @@ __global__ __launch_bounds__(512) void gemm_lw_kernel(const gemm_mats mats, int 
                                          : "v"(slot_first + xm_off));
                     }
                     asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024" : "=&v"(qan), "=&v"(qbn) : "v"(slot_next + wq_off));
+                    if constexpr (Q6) // the upper code bits come with every half
+                        asm volatile("ds_read_b128 %0, %1" : "=v"(hqn) : "v"(slot_next + hq_off));
                     if constexpr (half == 1) {
                         asm volatile("ds_read_b128 %0, %1" : "=v"(hdn) : "v"(slot_next + hd_off));
                         if constexpr (Q5)
                             asm volatile("ds_read_b128 %0, %1" : "=v"(hqn) : "v"(slot_next + hq_off));
+                        if constexpr (Q6)
+                            asm volatile("ds_read_u16 %0, %1" : "=v"(dw6n) : "v"(slot_next + d6_off));
                     }
                     read_frags(F[0], slot_next, 0);
                 } else {
@@ -450,16 +476,16 @@ __global__ __launch_bounds__(512) void gemm_lw_kernel(const gemm_mats mats, int 
                     // too, so that the next half's first weight fragment is built under this K-step's MFMAs instead of
                     // between two half-steps
                     read_frags(F[1], slot_next, 1);
-                    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(qan), "+v"(qbn), "+v"(hdn), "+v"(hqn) : "n"(2 * NT));
+                    asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(qan), "+v"(qbn), "+v"(hdn), "+v"(hqn), "+v"(dw6n) : "n"(2 * NT));
                     pin(F[3]);
                 }
                 half8_t wn = wf;
                 if (t8 + 1 < 8)
                     wn = dq(halfc, t8 + 1);
                 else if constexpr (half == 1)
-                    wn = dq_of(HN{}, 0, qan, qbn, hdn, hqn); // next super-block: header fetched in K-step 6
+                    wn = dq_of(HN{}, 0, qan, qbn, hdn, hqn, dw6n); // next super-block: header fetched in K-step 6
                 else
-                    wn = dq_of(HN{}, 0, qan, qbn, hd, hq);
+                    wn = dq_of(HN{}, 0, qan, qbn, hd, Q6 ? hqn : hq, dw6);
 #pragma unroll
                 for (int nt = 0; nt < NT; nt++) // weights are the A operand here: a lane ends up with 4 consecutive ROWS per token
                     acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, F[t8 & 3][nt], acc[nt], 0, 0, 0);
@@ -470,7 +496,11 @@ __global__ __launch_bounds__(512) void gemm_lw_kernel(const gemm_mats mats, int 
                 }
                 wf = wn;
             }
-            if constexpr (half == 1) { // (the mins fragments were covered by K-step 7's wait)
+            if constexpr (Q6)
+                hq = hqn;
+            if constexpr (half == 1 && Q6)
+                hd = hdn, dw6 = dw6n;
+            if constexpr (half == 1 && !Q6) { // (the mins fragments were covered by K-step 7's wait)
                 pin(fxm);
                 uint32_t sc03, sc47, mn03, mn47;
                 q4k_scales_bytes(hd.y, hd.z, hd.w, sc03, sc47, mn03, mn47);
@@ -495,8 +525,10 @@ __global__ __launch_bounds__(512) void gemm_lw_kernel(const gemm_mats mats, int 
         asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:1024\n\tds_read_b128 %2, %4\n\ts_waitcnt lgkmcnt(0)"
                      : "=&v"(qa), "=&v"(qb), "=&v"(hd)
                      : "v"(lds0 + wq_off), "v"(lds0 + hd_off));
-        if constexpr (Q5)
+        if constexpr (Q5 || Q6)
             asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(hq) : "v"(lds0 + hq_off));
+        if constexpr (Q6)
+            asm volatile("ds_read_u16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(dw6) : "v"(lds0 + d6_off));
         read_frags(F[0], lds0, 0);
         read_frags(F[1], lds0, 1);
         wf = dq(H0{}, 0);
@@ -613,12 +645,18 @@ hipError_t lfamd_lw_go(int Atype, const gemm_mats &mats, int nb, const void *Xh,
         else                                                                                                           \
             LW_GO(T, false, false, 4);                                                                                 \
     } while (0)
-    if (Atype == LFAMD_TYPE_Q4_K)
+    if (Atype == LFAMD_TYPE_Q4_K) {
         LW_GO2(LFAMD_TYPE_Q4_K);
-    else if (Atype == LFAMD_TYPE_Q5_K)
+    } else if (Atype == LFAMD_TYPE_Q5_K) {
         LW_GO2(LFAMD_TYPE_Q5_K);
-    else
+    } else if (Atype == LFAMD_TYPE_Q6_K && fast && !moe) { // scaled-operand body only
+        if (nt == 2)
+            LW_GO(LFAMD_TYPE_Q6_K, false, true, 2);
+        else
+            LW_GO(LFAMD_TYPE_Q6_K, false, true, 4);
+    } else {
         return hipErrorInvalidValue;
+    }
 #undef LW_GO2
 #undef LW_GO
     return hipGetLastError();

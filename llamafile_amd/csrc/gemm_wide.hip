@@ -29,7 +29,8 @@ static bool lw_allowed(int mode) {
 
 static hipError_t wide_go(int Atype, int mode, WIDE_ARGS) {
     const int g_scaled = (mode >> 1) & 1;
-    if ((Atype == LFAMD_TYPE_Q4_K || Atype == LFAMD_TYPE_Q5_K) && lw_allowed(mode)) {
+    const bool q45 = Atype == LFAMD_TYPE_Q4_K || Atype == LFAMD_TYPE_Q5_K;
+    if ((q45 || (Atype == LFAMD_TYPE_Q6_K && g_scaled && !moe)) && lw_allowed(mode)) {
         if (g_scaled && !moe) {
             // scaled operands: 128 x 128 tiles when they fill the chip, else 128 x 64 (twice the work-groups, no K split)
             if (n_rb * n_ct >= LW_FULL_GRID)
@@ -37,7 +38,7 @@ static hipError_t wide_go(int Atype, int mode, WIDE_ARGS) {
             const int n_ct2 = (int)((n + 63) / 64);
             return lfamd_lw_go(Atype, mats, nb, Xh, d8T, Xm, n, n_pad, n_rb, n_ct2, (unsigned)(n_rb * n_ct2), 0, 1, 2, s);
         }
-        if (ks == 1) // exact codes; the grouped MUL_MAT_ID launch also on scaled operands
+        if (ks == 1 && q45) // exact codes; the grouped MUL_MAT_ID launch also on scaled operands
             return lfamd_lw_go(Atype, mats, nb, Xh, d8T, Xm, n, n_pad, n_rb, n_ct, n_wg, moe, moe ? g_scaled : 0, 4, s);
     }
     if (g_scaled)
@@ -97,7 +98,8 @@ extern "C" int lfamd_gemm_wide_ksplit(long m, long k, long n_pad) {
 // Will a wide launch of these (fused) matrices run the loader-wave body, i.e. may the caller stage scaled activations?
 extern "C" int lfamd_gemm_wide_scaled_ok(int Atype, int plain) {
     static const bool env_off = getenv("LFAMD_GEMM_NO_SCALED") != nullptr, env_plain = getenv("LFAMD_GEMM_NO_LW") != nullptr;
-    return !(env_off || env_plain || plain || (Atype != LFAMD_TYPE_Q4_K && Atype != LFAMD_TYPE_Q5_K));
+    return !(env_off || env_plain || plain ||
+             (Atype != LFAMD_TYPE_Q4_K && Atype != LFAMD_TYPE_Q5_K && Atype != LFAMD_TYPE_Q6_K));
 }
 
 extern "C" hipError_t lfamd_launch_gemm_wide_multi(int Atype, int count, const void *const *A, const long *m, long k,
@@ -125,7 +127,8 @@ extern "C" hipError_t lfamd_launch_gemm_wide_multi(int Atype, int count, const v
     for (int i = mats.count; i < GEMM_MAX_MATS; i++)
         mats.A[i] = mats.A[0], mats.C[i] = mats.C[0], mats.m[i] = 0, mats.ldc[i] = 0, mats.rb_end[i] = n_rb;
     const int n_ct = (int)(n_pad / WD_COLS);
-    const bool scaled_lw = (mode & 2) && lw_allowed(mode) && (Atype == LFAMD_TYPE_Q4_K || Atype == LFAMD_TYPE_Q5_K);
+    const bool scaled_lw = (mode & 2) && lw_allowed(mode) &&
+                           (Atype == LFAMD_TYPE_Q4_K || Atype == LFAMD_TYPE_Q5_K || Atype == LFAMD_TYPE_Q6_K);
     const int ks = scaled_lw ? 1 : wide_ksplit(n_rb * n_ct, nb); // the scaled-operand body never splits K
     const int nbs = (nb + ks - 1) / ks;
     const int n_wg = n_rb * n_ct * ks;

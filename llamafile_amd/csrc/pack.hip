@@ -659,17 +659,24 @@ hipError_t lfamd_launch_prep_q8k(const void *B, size_t b_row_bytes, long n, long
 }
 
 // ---------------------------------------------------------------------------------------------
-// Range check for the scaled-operand GEMM (gemm_lw.hip FAST): every row header of a P4K / P5K image.
+// Range check for the scaled-operand GEMM (gemm_lw.hip FAST): every row header of a P4K / P5K / P6K image.
 
-__global__ void scaled_ok_kernel(const uint8_t *__restrict__ img, long tiles, int tile_bytes, int *__restrict__ bad) {
+__global__ void scaled_ok_kernel(const uint8_t *__restrict__ img, long tiles, int tile_bytes, int q6, int *__restrict__ bad) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; // (tile, row in tile)
     if (idx >= tiles * 32)
         return;
-    const uint32_t dd = *(const uint32_t *)(img + (size_t)(idx >> 5) * tile_bytes + P4K_HDR + (idx & 31) * 16);
     union {
         uint16_t u;
         _Float16 h;
     } d, dm;
+    const uint8_t *tile = img + (size_t)(idx >> 5) * tile_bytes;
+    if (q6) { // f16(d * sc) * (code - 32): |d| * 127 * 32 must stay inside f16
+        d.u = *(const uint16_t *)(tile + P6K_D + (idx & 31) * 2);
+        if (!(fabsf((float)d.h) * (127.0f * 32.0f) <= 65504.0f))
+            atomicOr(bad, 1);
+        return;
+    }
+    const uint32_t dd = *(const uint32_t *)(tile + P4K_HDR + (idx & 31) * 16);
     d.u = (uint16_t)(dd & 0xffff), dm.u = (uint16_t)(dd >> 16);
     const float fd = fabsf((float)d.h), fm = fabsf((float)dm.h);
     if (!(fd * 63.0f < 64.0f) || !(fm * 63.0f <= 65504.0f)) // also catches NaN / inf
@@ -678,8 +685,9 @@ __global__ void scaled_ok_kernel(const uint8_t *__restrict__ img, long tiles, in
 
 extern "C" hipError_t lfamd_launch_scaled_ok(int type, long rows, long cols, const void *packed, int *d_flag, hipStream_t s) {
     const long tiles = ((rows + 31) / 32) * (cols / 256);
-    const int tile_bytes = type == LFAMD_TYPE_Q5_K ? P5K_TILE : P4K_TILE;
+    const int tile_bytes = type == LFAMD_TYPE_Q5_K ? P5K_TILE : type == LFAMD_TYPE_Q6_K ? P6K_TILE : P4K_TILE;
     const long threads = tiles * 32;
-    scaled_ok_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>((const uint8_t *)packed, tiles, tile_bytes, d_flag);
+    scaled_ok_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>((const uint8_t *)packed, tiles, tile_bytes,
+                                                                       type == LFAMD_TYPE_Q6_K ? 1 : 0, d_flag);
     return hipGetLastError();
 }

@@ -83,7 +83,7 @@ def upload_weights(t: int, raw, rows: int, cols: int, device="cuda") -> PackedWe
     out = torch.empty(max(size, 16), dtype=torch.uint8, device=raw.device)
     _hip.check(L.lfamd_pack_weights(t, rows, cols, _ptr(raw), raw.shape[1], _ptr(out), _stream()), "lfamd_pack_weights")
     W = PackedWeights(t, rows, cols, out[:size] if size else out[:0])
-    if t in (T.Q4_K, T.Q5_K) and rows and cols:
+    if t in (T.Q4_K, T.Q5_K, T.Q6_K) and rows and cols:
         # scaled-operand batches need |d| < 64/63 (include/lfamd_hip.h): out-of-range matrices always run exact
         ok = L.lfamd_scaled_gemm_ok(t, rows, cols, _ptr(out), _stream())
         if ok < 0:

@@ -22,7 +22,7 @@ def gemm_tol(t, body_flags, n):
     from llamafile_amd import _hip
     if n <= 8:
         return DEFAULT_TOL
-    scaled = (t in (T.Q4_K, T.Q5_K) and (body_flags & _hip.FLAG_GEMM_WIDE) and not (body_flags & _hip.FLAG_GEMM_PLAIN)
+    scaled = (t in (T.Q4_K, T.Q5_K, T.Q6_K) and (body_flags & _hip.FLAG_GEMM_WIDE) and not (body_flags & _hip.FLAG_GEMM_PLAIN)
               and not (body_flags & _hip.FLAG_PRECISE))
     return SCALED_TOL if scaled else GEMM_TOL.get(t, DEFAULT_TOL)
 
@@ -96,7 +96,7 @@ def test_mfma_gemm_vs_oracle(gpu, oracle, t, shape, body):
     assert rel_err(C, G) <= gemm_tol(t, flag, n), (T.NAMES[t], shape, body, rel_err(C, G))
 
 
-@pytest.mark.parametrize("t", [T.Q4_K, T.Q5_K], ids=lambda t: T.NAMES[t])
+@pytest.mark.parametrize("t", [T.Q4_K, T.Q5_K, T.Q6_K], ids=lambda t: T.NAMES[t])
 @pytest.mark.parametrize("f32in", [False, True], ids=["q8k", "f32"])
 def test_loader_wave_gemm_full_grid(gpu, oracle, t, f32in):
     """The default route of a grid that fills the chip (>= 192 tiles, K not split): loader-wave body, scaled operands by
@@ -151,7 +151,7 @@ def test_mfma_bodies_agree_and_repeat(gpu, t):
     w2 = run_gpu(gpu, t, A, B, bt, m, n, k, flags=base | _hip.FLAG_GEMM_WIDE)
     nr = run_gpu(gpu, t, A, B, bt, m, n, k, flags=base | _hip.FLAG_GEMM_NARROW)
     assert np.array_equal(w1.view(np.uint32), w2.view(np.uint32))
-    assert rel_err(w1, nr) <= max(2e-6, gemm_tol(t, _hip.FLAG_GEMM_WIDE, n) if t != T.Q6_K else 2e-6)
+    assert rel_err(w1, nr) <= gemm_tol(t, _hip.FLAG_GEMM_WIDE, n)
     # exact integer codes on both tiles: only the f32 summation order differs
     we = run_gpu(gpu, t, A, B, bt, m, n, k, flags=base | _hip.FLAG_GEMM_WIDE | _hip.FLAG_PRECISE)
     assert rel_err(we, nr) <= 2e-6
