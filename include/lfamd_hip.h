@@ -80,7 +80,10 @@ int lfamd_pack_weights(int type, long rows, long cols, const void *d_raw, size_t
  * model satisfies (d = max|w| / (15 * 63)).  lfamd_scaled_gemm_ok checks a packed matrix once after the upload
  * (synchronises the stream): 1 = in range, 0 = out of range -> pass LFAMD_FLAG_PRECISE with this matrix (exact integer
  * codes, f32 scales; out-of-range scales would otherwise surface as inf / NaN outputs), < 0 = error.  Types other than
- * the K-quants with a resident layout: always 1.  (Q6_K: |d| * 127 * 32 <= 65504.) */
+ * the K-quants with a resident layout: always 1.  (Q6_K: |d| * 127 * 32 <= 65504.)
+ * Activation range of that body: the staged f16(d8 * code) saturates at +-65504 and is subnormal below 6e-5, so a token
+ * whose values are all tiny (< ~1e-4) loses relative accuracy and values beyond 65504 clip; LFAMD_FLAG_PRECISE has neither
+ * limit (integer codes, f32 scales).  A per-token power-of-two normalisation is the planned fix. */
 int lfamd_scaled_gemm_ok(int type, long rows, long cols, const void *d_packed, void *stream);
 
 /* ---- activations --------------------------------------------------------------------------
