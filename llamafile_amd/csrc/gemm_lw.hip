@@ -584,18 +584,20 @@ __global__ __launch_bounds__(512) void gemm_lw_kernel(const gemm_mats mats, int 
                 } else if (tok >= n) {
                     continue;
                 }
+                const float ts = d8T[tok]; // 2^e of the token's normalised staging (pack.hip, prep_scaled_kernel): exact
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
                     const long row0 = rt * 32 + 8 * g + 4 * h;
                     float *dst = C + crow * ldc + row0;
                     if (vec) {
                         if (row0 < m)
-                            *(float4 *)dst = make_float4(acc[nt][4 * g], acc[nt][4 * g + 1], acc[nt][4 * g + 2], acc[nt][4 * g + 3]);
+                            *(float4 *)dst = make_float4(acc[nt][4 * g] * ts, acc[nt][4 * g + 1] * ts, acc[nt][4 * g + 2] * ts,
+                                                         acc[nt][4 * g + 3] * ts);
                     } else {
 #pragma unroll
                         for (int e = 0; e < 4; e++)
                             if (row0 + e < m)
-                                dst[e] = acc[nt][4 * g + e];
+                                dst[e] = acc[nt][4 * g + e] * ts;
                     }
                 }
             }

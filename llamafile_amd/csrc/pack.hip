@@ -434,6 +434,152 @@ __global__ __launch_bounds__(64) void prep_f32_kernel(const uint8_t *__restrict_
         d8T[(size_t)b * n_pad + tok] = d;
 }
 
+// SCALED staging with a per-token power-of-two normalisation (mode 2, the scaled-operand GEMM of gemm_lw.hip):
+//   Xh = f16(d8 * code * 2^-e(token)),  Xm[0..7] = f16(d8 * S_j * 2^-e), Xm[8..15] = 0,  tok_scale[token] = 2^e
+// with e chosen so that the token's largest |d8 * 128| lands in [512, 1024): no f16 overflow for huge activations, no
+// subnormals for tiny ones, and — a power of two commutes with the rounding — the same bits as the unnormalised staging
+// wherever that one is in range.  The GEMM multiplies its output column by tok_scale when it stores.
+// One work-group per token: pass 1 finds the largest block scale (|d8| = amax / 128), pass 2 quantises exactly like
+// prep_f32_kernel / prep_q8k_kernel (the second read of the row hits the caches).
+// MAXJ > 0: the wave's super-blocks (b = wave + 16 j, j < MAXJ) are loaded ONCE, all loads in flight together, and both
+// passes run from registers (one memory round trip per token; 16 waves per token keep as many waves in flight as the per-super-block kernels);
+// MAXJ == 0: any nb, the row is read twice (the second time from the caches).
+template <bool F32IN, int MAXJ>
+__global__ __launch_bounds__(1024) void prep_scaled_kernel(const uint8_t *__restrict__ X, size_t row_bytes, long n, long n_pad, int nb,
+                                                          _Float16 *__restrict__ Xh, float *__restrict__ tok_scale,
+                                                          _Float16 *__restrict__ Xm, const int32_t *__restrict__ src_idx) {
+    __shared__ float wmax[16];
+    typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+    constexpr int NJ = MAXJ > 0 ? MAXJ : 1;
+    const long tok = blockIdx.x;
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const long src = src_idx ? (long)src_idx[tok] : (tok < n ? tok : -1);
+    if (src < 0) { // padding slot: zero codes, never stored
+        const half4_t z = {(_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0};
+        for (int b = wave; b < nb; b += 16) {
+            *(half4_t *)(Xh + ((size_t)b * n_pad + tok) * 256 + 4 * lane) = z;
+            if (lane < 16)
+                Xm[((size_t)b * n_pad + tok) * 16 + lane] = (_Float16)0;
+        }
+        if (t == 0)
+            tok_scale[tok] = 0.0f;
+        return;
+    }
+    const uint8_t *row = X + src * row_bytes;
+    // what a lane holds of super-block b: four f32 values, or four codes and the block scale
+    float4 fv[NJ];
+    uint32_t qv[NJ];
+    float dv[NJ];
+    auto load = [&](int b, float4 &f, uint32_t &w, float &d) {
+        if constexpr (F32IN) {
+            f = *(const float4 *)((const float *)row + (size_t)b * 256 + 4 * lane);
+        } else {
+            const lfamd_block_q8_K *y = (const lfamd_block_q8_K *)row + b;
+            w = *(const uint32_t *)((const uint8_t *)y->qs + 4 * lane);
+            d = y->d;
+        }
+    };
+    auto block_amax = [&](const float4 &f, float d) -> float { // |d8| * 128 (lane-local part for f32 input)
+        if constexpr (F32IN)
+            return fmaxf(fmaxf(fabsf(f.x), fabsf(f.y)), fmaxf(fabsf(f.z), fabsf(f.w)));
+        else
+            return fabsf(d) * 128.0f;
+    };
+    float dmax = 0.0f;
+    if constexpr (MAXJ > 0) {
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            fv[j] = make_float4(0.f, 0.f, 0.f, 0.f), qv[j] = 0, dv[j] = 0.0f;
+            if (wave + 16 * j < nb)
+                load(wave + 16 * j, fv[j], qv[j], dv[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; j++)
+            dmax = fmaxf(dmax, block_amax(fv[j], dv[j]));
+    } else {
+        for (int b = wave; b < nb; b += 16) {
+            load(b, fv[0], qv[0], dv[0]);
+            dmax = fmaxf(dmax, block_amax(fv[0], dv[0]));
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        dmax = fmaxf(dmax, __shfl_xor(dmax, off, 64));
+    if (lane == 0)
+        wmax[wave] = dmax;
+    __syncthreads();
+    dmax = wmax[lane & 15]; // (every wave reduces the 16 partial maxima itself)
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1)
+        dmax = fmaxf(dmax, __shfl_xor(dmax, off, 64));
+    const bool ok = dmax > 0.0f && dmax < 3.0e38f; // (zero / non-finite rows: no normalisation)
+    const float scale = ok ? ldexpf(1.0f, 9 - ilogbf(dmax)) : 1.0f;
+    if (t == 0)
+        tok_scale[tok] = ok ? ldexpf(1.0f, ilogbf(dmax) - 9) : 1.0f;
+
+    auto emit = [&](int b, const float4 &f, uint32_t w, float dq) {
+        _Float16 *xo = Xh + ((size_t)b * n_pad + tok) * 256;
+        int q[4] = {0, 0, 0, 0};
+        float d = 0.0f;
+        if constexpr (F32IN) { // quantize_row_q8_K: first index of the largest |x|, iscale = -128 / max, nearest-even, clamp 127
+            const float v[4] = {f.x, f.y, f.z, f.w};
+            float amax = 0.0f, val = 0.0f;
+            int idx = 4 * lane;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const float ax = fabsf(v[e]);
+                if (ax > amax)
+                    amax = ax, val = v[e], idx = 4 * lane + e;
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const float oa = __shfl_xor(amax, off, 64);
+                const int oi = __shfl_xor(idx, off, 64);
+                const float ov = __shfl_xor(val, off, 64);
+                if (oa > amax || (oa == amax && oi < idx))
+                    amax = oa, idx = oi, val = ov;
+            }
+            if (amax != 0.0f) {
+                const float iscale = -128.0f / val;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int c = (int)rintf(iscale * v[e]);
+                    q[e] = c > 127 ? 127 : c;
+                }
+                d = 1.0f / iscale;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                q[e] = (int)(int8_t)(w >> (8 * e));
+            d = dq;
+        }
+        const float xs = d * scale;
+        const half4_t h4 = {sat_f16((float)q[0] * xs), sat_f16((float)q[1] * xs), sat_f16((float)q[2] * xs), sat_f16((float)q[3] * xs)};
+        *(half4_t *)(xo + 4 * lane) = h4;
+        int S = q[0] + q[1] + q[2] + q[3]; // pair sum j = lane / 8 covers codes 32j .. 32j+31
+        S += __shfl_xor(S, 1, 64);
+        S += __shfl_xor(S, 2, 64);
+        S += __shfl_xor(S, 4, 64);
+        if ((lane & 7) == 0) {
+            _Float16 *mo = Xm + ((size_t)b * n_pad + tok) * 16;
+            mo[lane >> 3] = sat_f16((float)S * xs);
+            mo[8 + (lane >> 3)] = (_Float16)0;
+        }
+    };
+    if constexpr (MAXJ > 0) {
+#pragma unroll
+        for (int j = 0; j < NJ; j++)
+            if (wave + 16 * j < nb) // (wave-uniform)
+                emit(wave + 16 * j, fv[j], qv[j], dv[j]);
+    } else {
+        for (int b = wave; b < nb; b += 16) {
+            load(b, fv[0], qv[0], dv[0]);
+            emit(b, fv[0], qv[0], dv[0]);
+        }
+    }
+}
+
 // Activation preparation for the legacy 32-block weight types (Q4_0 ...): Q8_0 quantisation (upstream
 // quantize_row_q8_0: d = amax/127 stored as f16, q = roundf(x/d)) ->
 //   Xh  [nb][n_pad][256] f16 codes (as above);  d8T [nb*8][n_pad] f32 block scales.  One wave per (super-block, token).
@@ -591,14 +737,31 @@ hipError_t lfamd_launch_pack_raw(const void *raw, size_t raw_row_bytes, long row
     return hipGetLastError();
 }
 
+// the register-resident forms up to 16 / 64 super-blocks (k <= 4096 / 16384: 1 / 4 per wave), the looping one beyond
+#define PREP_SCALED_GO(F32IN, SRC, RB)                                                                                 \
+    do {                                                                                                               \
+        if (nb <= 16)                                                                                                  \
+            prep_scaled_kernel<F32IN, 1><<<(unsigned)n_pad, 1024, 0, s>>>((const uint8_t *)SRC, RB, n, n_pad, nb, (_Float16 *)Xh, \
+                                                                         (float *)d8T, (_Float16 *)Xm, src_idx);        \
+        else if (nb <= 64)                                                                                             \
+            prep_scaled_kernel<F32IN, 4><<<(unsigned)n_pad, 1024, 0, s>>>((const uint8_t *)SRC, RB, n, n_pad, nb, (_Float16 *)Xh, \
+                                                                          (float *)d8T, (_Float16 *)Xm, src_idx);       \
+        else                                                                                                           \
+            prep_scaled_kernel<F32IN, 0><<<(unsigned)n_pad, 1024, 0, s>>>((const uint8_t *)SRC, RB, n, n_pad, nb, (_Float16 *)Xh, \
+                                                                         (float *)d8T, (_Float16 *)Xm, src_idx);        \
+    } while (0)
+
 hipError_t lfamd_launch_prep_f32(const void *X, size_t x_row_bytes, long n, long n_pad, long cols, void *Xh, void *d8T,
                                  void *Xm, int mins16, const int32_t *src_idx, hipStream_t s) {
     int nb = (int)(cols / 256);
     long blocks = n_pad * nb;
     if (blocks == 0)
         return hipSuccess;
-    prep_f32_kernel<<<(unsigned)blocks, 64, 0, s>>>((const uint8_t *)X, x_row_bytes, n, n_pad, nb, (_Float16 *)Xh,
-                                                     (float *)d8T, (_Float16 *)Xm, mins16, src_idx);
+    if (mins16 == 2) // scaled staging: d8T receives the per-token output scales [n_pad]
+        PREP_SCALED_GO(true, X, x_row_bytes);
+    else
+        prep_f32_kernel<<<(unsigned)blocks, 64, 0, s>>>((const uint8_t *)X, x_row_bytes, n, n_pad, nb, (_Float16 *)Xh,
+                                                         (float *)d8T, (_Float16 *)Xm, mins16, src_idx);
     return hipGetLastError();
 }
 
@@ -652,8 +815,11 @@ hipError_t lfamd_launch_prep_q8k(const void *B, size_t b_row_bytes, long n, long
     long blocks = n_pad * nb;
     if (blocks == 0)
         return hipSuccess;
-    prep_q8k_kernel<<<(unsigned)blocks, 64, 0, s>>>((const uint8_t *)B, b_row_bytes, n, n_pad, nb, (_Float16 *)Xh,
-                                                     (float *)d8T, (_Float16 *)Xm, mins16, src_idx);
+    if (mins16 == 2)
+        PREP_SCALED_GO(false, B, b_row_bytes);
+    else
+        prep_q8k_kernel<<<(unsigned)blocks, 64, 0, s>>>((const uint8_t *)B, b_row_bytes, n, n_pad, nb, (_Float16 *)Xh,
+                                                         (float *)d8T, (_Float16 *)Xm, mins16, src_idx);
     return hipGetLastError();
 }
 }

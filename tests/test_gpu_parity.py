@@ -117,6 +117,35 @@ def test_loader_wave_gemm_full_grid(gpu, oracle, t, f32in):
         assert err <= tol, (T.NAMES[t], flags, err)
 
 
+@pytest.mark.parametrize("t", [T.Q4_K, T.Q6_K], ids=lambda t: T.NAMES[t])
+@pytest.mark.parametrize("f32in", [False, True], ids=["q8k", "f32"])
+def test_scaled_gemm_activation_range(gpu, oracle, t, f32in):
+    """The scaled-operand body normalises every token by a power of two before the f16 staging (prep_scaled_kernel) and
+    undoes it in the store: tokens of magnitude 1e-7 .. 3e5 (far outside f16's 6e-5 .. 65504), an all-zero token and
+    ordinary ones in one batch all meet the north-star tolerance per token."""
+    from llamafile_amd import synth
+    m, n, k = 1000, 3100, 1024
+    A = synth.random_weights(t, m, k, 6100 + t)
+    x = synth.random_activations(n, k, 6101)
+    mags = np.ones(n, dtype=np.float32)
+    mags[0::5] = 1e-7
+    mags[1::5] = 3e5
+    mags[2::5] = 2e-3
+    x = x * mags[:, None]
+    x[7] = 0.0
+    x[8, 100:] *= 1e-6  # one token whose super-blocks differ by six orders of magnitude
+    B = synth.quantize_activations(T.Q8_K, x)
+    ok, G = oracle.sgemm(t, A, T.Q8_K, B, m, n, k, nth=8)
+    assert ok == 1
+    W = gpu.upload_weights(t, A, m, k)
+    Bd = torch.from_numpy(x).cuda().view(torch.uint8).view(n, k * 4) if f32in else torch.from_numpy(B).cuda()
+    C = gpu.mul_mat(W, Bd, T.F32 if f32in else T.Q8_K).cpu().numpy()
+    assert np.isfinite(C).all()
+    assert (C[7] == 0).all()
+    for j in list(range(0, 40)) + [n - 2, n - 1]:  # per token: each against its own scale
+        assert rel_err(C[j], G[j]) <= SCALED_TOL, (j, mags[j], rel_err(C[j], G[j]))
+
+
 @pytest.mark.parametrize("t", [T.Q4_K, T.Q5_K], ids=lambda t: T.NAMES[t])
 def test_out_of_range_scales_run_exact(gpu, oracle, t):
     """lfamd_scaled_gemm_ok: block scales beyond the scaled-operand body's f16 range (|d| * 63 >= 64) are detected at
