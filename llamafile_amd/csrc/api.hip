@@ -513,6 +513,45 @@ int lfamd_mul_mat_multi_types(int count, const int *Atype, const void *const *d_
                "gemv_dual");
         return LFAMD_OK;
     }
+    // Batches whose nodes are all K-quants with a resident layout (attn_q/k = Q4_K with attn_v = Q6_K at prefill): the
+    // scaled-operand GEMM of every type reads the SAME staged activations, so they are prepared once; then one launch of
+    // the loader-wave body per run of equal types.
+    {
+        bool share = n > 8 && count > 1 && k > 0 && k % 256 == 0 && !(flags & (LFAMD_FLAG_PRECISE | LFAMD_FLAG_FORCE_GENERIC |
+                                                                                LFAMD_FLAG_GEMM_NARROW)) &&
+                     (Btype == LFAMD_TYPE_F32 || Btype == LFAMD_TYPE_Q8_K) && b_row_bytes >= lfamd_row_size(Btype, k);
+        const int plain = (flags & LFAMD_FLAG_GEMM_PLAIN) ? 1 : 0;
+        bool mixed = false;
+        for (int j = 0; j < count && share; j++) {
+            const int t = Atype[j];
+            share = (t == LFAMD_TYPE_Q4_K || t == LFAMD_TYPE_Q5_K || t == LFAMD_TYPE_Q6_K) && lfamd_gemm_wide_scaled_ok(t, plain) &&
+                    m[j] >= 0 && ldc[j] >= m[j];
+            mixed = mixed || t != Atype[0];
+        }
+        const size_t n_pad = align_up((size_t)n, 128), nbk = (size_t)(k / 256);
+        const size_t need = align_up(n_pad * (size_t)k * 2, 256) + align_up(nbk * n_pad * 4, 256) + align_up(n_pad * nbk * 32, 256);
+        if (share && mixed && d_ws && ws_bytes >= need) {
+            hipStream_t s = (hipStream_t)stream;
+            uint8_t *ws = (uint8_t *)d_ws;
+            void *Xh = ws;
+            void *d8T = ws + align_up(n_pad * (size_t)k * 2, 256);
+            void *Xm = (uint8_t *)d8T + align_up(nbk * n_pad * 4, 256);
+            if (Btype == LFAMD_TYPE_F32)
+                HIPCHK(lfamd_launch_prep_f32(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, 2, nullptr, s), "prep_f32");
+            else
+                HIPCHK(lfamd_launch_prep_q8k(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, 2, nullptr, s), "prep_q8k");
+            for (int j0 = 0; j0 < count;) {
+                int j1 = j0 + 1;
+                while (j1 < count && Atype[j1] == Atype[j0] && j1 - j0 < 4)
+                    j1++;
+                HIPCHK(lfamd_launch_gemm_wide_multi(Atype[j0], j1 - j0, d_A + j0, m + j0, k, Xh, d8T, Xm, n, (long)n_pad, d_C + j0,
+                                                    ldc + j0, plain | 2, s),
+                       "gemm_wide_multi");
+                j0 = j1;
+            }
+            return LFAMD_OK;
+        }
+    }
     for (int j0 = 0; j0 < count;) { // runs of equal types
         int j1 = j0 + 1;
         while (j1 < count && Atype[j1] == Atype[j0] && j1 - j0 < 4)

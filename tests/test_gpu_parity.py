@@ -298,6 +298,27 @@ def test_mul_mat_multi_two_types_one_launch(gpu, ta, k, f32in):
         assert np.array_equal(f.cpu().numpy().view(np.uint32), sep.cpu().numpy().view(np.uint32))
 
 
+@pytest.mark.parametrize("ta", [T.Q4_K, T.Q5_K], ids=lambda t: T.NAMES[t])
+@pytest.mark.parametrize("f32in", [True, False], ids=["f32", "q8k"])
+def test_mul_mat_multi_two_types_batch_shares_the_prep(gpu, oracle, ta, f32in):
+    """lfamd_mul_mat_multi_types for a batch: attn_q/k (Q4_K or Q5_K) and attn_v (Q6_K) read ONE staged copy of the
+    activations (scaled operands), each type run is one launch of the loader-wave body; every output against the oracle."""
+    from llamafile_amd import synth
+    k, n = 1024, 150
+    specs = [(ta, 200), (ta, 40), (T.Q6_K, 72)]
+    raws = [synth.random_weights(t, m, k, 360 + i) for i, (t, m) in enumerate(specs)]
+    Ws = [gpu.upload_weights(t, r, m, k) for (t, m), r in zip(specs, raws)]
+    x = synth.random_activations(n, k, 370)
+    B = synth.quantize_activations(T.Q8_K, x)
+    Bd = torch.from_numpy(x).cuda().view(torch.uint8).view(n, k * 4) if f32in else torch.from_numpy(B).cuda()
+    outs = gpu.mul_mat_multi(Ws, Bd, T.F32 if f32in else T.Q8_K, n=n)
+    torch.cuda.synchronize()
+    for (t, m), r, o in zip(specs, raws, outs):
+        ok, G = oracle.sgemm(t, r, T.Q8_K, B, m, n, k, nth=4)
+        assert ok == 1
+        assert rel_err(o.cpu().numpy(), G) <= SCALED_TOL, (T.NAMES[t], m, rel_err(o.cpu().numpy(), G))
+
+
 @pytest.mark.parametrize("t", [T.Q4_K, T.Q5_K, T.Q6_K], ids=lambda t: T.NAMES[t])
 def test_mul_mat_multi_gemm_fused_launch(gpu, t):
     """Batches: sibling mat-muls share one activation prep and ONE launch of the 128 x 128 MFMA body over their
