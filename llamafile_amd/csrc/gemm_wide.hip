@@ -21,7 +21,10 @@ hipError_t lfamd_lw_go(int Atype, const gemm_mats &mats, int nb, const void *Xh,
 // Q4_K / Q5_K without K split run the loader-wave body (gemm_lw.hip) unless the caller asks for the plain one.
 // `mode` (an argument of every launcher here) bit 0: plain body; bit 1: the activations were staged SCALED (pack.hip, prep mode 2) for the scaled-operand
 // loader-wave body — only set when lfamd_gemm_wide_scaled_ok() said that body will run.
-#define LW_FULL_GRID 192 // 128 x 128 tiles from which the 256 CUs count as filled (as wide_ksplit)
+// 128 x 128 tiles from which the scaled-operand body uses them instead of 128 x 64: a 128 x 64 work-group takes ~0.73 of a
+// 128 x 128 one (2720 vs 3680 cycles per super-block), so two rounds of the small tile (129 .. 256 big tiles = 258 .. 512
+// small ones on 256 CUs) lose against one partial round of the big tile; up to 128 big tiles the small tile's single round wins.
+#define LW_FULL_GRID 129
 static bool lw_allowed(int mode) {
     static const bool env_plain = getenv("LFAMD_GEMM_NO_LW") != nullptr;
     return !(mode & 1) && !env_plain;
@@ -33,7 +36,8 @@ static hipError_t wide_go(int Atype, int mode, WIDE_ARGS) {
     if ((q45 || (Atype == LFAMD_TYPE_Q6_K && g_scaled && !moe)) && lw_allowed(mode)) {
         if (g_scaled && !moe) {
             // scaled operands: 128 x 128 tiles when they fill the chip, else 128 x 64 (twice the work-groups, no K split)
-            if (n_rb * n_ct >= LW_FULL_GRID)
+            static const int full_grid = getenv("LFAMD_LW_FULL_GRID") ? atoi(getenv("LFAMD_LW_FULL_GRID")) : LW_FULL_GRID; // (tuning)
+            if (n_rb * n_ct >= full_grid)
                 return lfamd_lw_go(Atype, mats, nb, Xh, d8T, Xm, n, n_pad, n_rb, n_ct, (unsigned)(n_rb * n_ct), 0, 1, 4, s);
             const int n_ct2 = (int)((n + 63) / 64);
             return lfamd_lw_go(Atype, mats, nb, Xh, d8T, Xm, n, n_pad, n_rb, n_ct2, (unsigned)(n_rb * n_ct2), 0, 1, 2, s);
