@@ -34,7 +34,7 @@ hipError_t lfamd_launch_gemv_multi(int, int, const void *const *, const long *, 
 hipError_t lfamd_launch_gemm_q80(const void *, long, long, int, const void *, size_t, long, float *, long, void *, int, int,
                                  hipStream_t);
 size_t lfamd_gemm_q80_workspace(long, long);
-#define LW_MIN_TILES 64 // 128 x 128 tiles from which the 128 x 64 loader-wave body beats the split-K body (measured)
+#define LW_MIN_TILES 1 // the 128 x 64 loader-wave tile beats the split-K body at every grid measured (8 .. 128 tiles: 5-10 %)
 hipError_t lfamd_launch_gemv_dual(int, int, const void *const *, const long *, float *const *, const long *, int, int,
                                   const void *const *, const long *, float *const *, const long *, long, int, const void *, size_t,
                                   hipStream_t);

@@ -69,7 +69,7 @@ def test_llamafile_sgemm_host_pointers(host, oracle, t, n):
     if t == T.Q8_0:
         assert np.array_equal(got.view(np.uint32), G.view(np.uint32))
     else:
-        assert rel_err(got, G) <= (1e-3 if (t == T.Q6_K and n > 8) else 2e-6)
+        assert rel_err(got, G) <= (1e-3 if (t in (T.Q4_K, T.Q5_K, T.Q6_K) and n > 8) else 2e-6)  # batches: scaled f16 operands
     # second call hits the device weight cache
     Cm2 = np.full((n, ldc), np.nan, dtype=np.float32)
     assert host.llamafile_sgemm(m, n, kb, A.ctypes.data, kb, B.ctypes.data, kb, Cm2.ctypes.data, ldc, 0, 1, t, bt, T.F32)
