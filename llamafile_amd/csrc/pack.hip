@@ -531,14 +531,16 @@ __global__ __launch_bounds__(1024) void prep_scaled_kernel(const uint8_t *__rest
                 if (ax > amax)
                     amax = ax, val = v[e], idx = 4 * lane + e;
             }
+            // the block's largest |x| (one value through the butterfly), then the FIRST lane holding it: lanes are in index
+            // order and `val` is already the lane's first such element, so this is quantize_row_q8_K's tie-break
+            float bmax = amax;
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const float oa = __shfl_xor(amax, off, 64);
-                const int oi = __shfl_xor(idx, off, 64);
-                const float ov = __shfl_xor(val, off, 64);
-                if (oa > amax || (oa == amax && oi < idx))
-                    amax = oa, idx = oi, val = ov;
-            }
+            for (int off = 32; off > 0; off >>= 1)
+                bmax = fmaxf(bmax, __shfl_xor(bmax, off, 64));
+            const unsigned long long holders = __ballot(amax == bmax);
+            val = __shfl(val, (int)__ffsll((long long)holders) - 1, 64);
+            amax = bmax;
+            (void)idx;
             if (amax != 0.0f) {
                 const float iscale = -128.0f / val;
 #pragma unroll
