@@ -42,9 +42,10 @@ hipError_t lfamd_launch_scaled_ok(int, long, long, const void *, int *, hipStrea
 int lfamd_gemm_wide_scaled_ok(int, int);
 // (the wide launchers take `mode`: bit 0 plain body, bit 1 activations staged scaled — gemm_wide.hip)
 hipError_t lfamd_launch_gemm_wide_multi(int, int, const void *const *, const long *, long, const void *, const void *,
-                                        const void *, long, long, float *const *, const long *, int, hipStream_t);
+                                        const void *, long, long, float *const *, const long *, int, void *, size_t, hipStream_t);
 hipError_t lfamd_launch_gemm_wide(int, const void *, long, long, const void *, const void *, const void *, long, long,
-                                  float *, long, int, hipStream_t);
+                                  float *, long, int, void *, size_t, hipStream_t);
+size_t lfamd_gemm_lw_ksplit_bytes(long, long);
 hipError_t lfamd_launch_gemm_kq(int, const void *, long, long, const void *, const void *, const void *, long, long,
                                 float *, long, hipStream_t);
 hipError_t lfamd_launch_quantize(int, const float *, long, long, size_t, void *, size_t, hipStream_t);
@@ -309,7 +310,8 @@ size_t lfamd_mul_mat_workspace(int Atype, long m, long k, long n) {
         return align_up((size_t)n * lfamd_row_size(lfamd_vec_dot_type(Atype), k), 256);
     if (use_gemm(Atype, n, 0, k)) {
         size_t n_pad = align_up((size_t)n, 128), nb = (size_t)(k / 256);
-        return align_up(n_pad * (size_t)k * 2, 256) + align_up(nb * n_pad * 4, 256) + align_up(n_pad * nb * 32, 256);
+        return align_up(n_pad * (size_t)k * 2, 256) + align_up(nb * n_pad * 4, 256) + align_up(n_pad * nb * 32, 256) +
+               (Atype == LFAMD_TYPE_Q4_0 ? 0 : lfamd_gemm_lw_ksplit_bytes(m, n)); // partial tiles of a K-split launch
     }
     if (use_gemm_q80(Atype, n, 0))
         return align_up(lfamd_gemm_q80_workspace(k, n), 256);
@@ -362,7 +364,7 @@ int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const v
         void *Xm = (uint8_t *)d8T + align_up(nb * n_pad * 4, 256);
         if (Atype == LFAMD_TYPE_Q4_0) { // Q8_0-quantised activations, eight scales per 256 (they take the Xm area too)
             HIPCHK(lfamd_launch_prep80(Btype, d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, nullptr, s), "prep80");
-            HIPCHK(lfamd_launch_gemm_wide(Atype, d_A, m, k, Xh, d8T, nullptr, n, (long)n_pad, d_C, ldc, plain, s), "gemm_wide");
+            HIPCHK(lfamd_launch_gemm_wide(Atype, d_A, m, k, Xh, d8T, nullptr, n, (long)n_pad, d_C, ldc, plain, nullptr, 0, s), "gemm_wide");
             return LFAMD_OK;
         }
         // two bodies: 128 x 128 tiles, K streamed once (gemm_wide.hip) when that grid fills the 256 CUs; the
@@ -382,10 +384,14 @@ int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const v
             HIPCHK(lfamd_launch_prep_f32(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, scaled ? 2 : 0, nullptr, s), "prep_f32");
         else
             HIPCHK(lfamd_launch_prep_q8k(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, scaled ? 2 : 0, nullptr, s), "prep_q8k");
-        if (narrow)
+        if (narrow) {
             HIPCHK(lfamd_launch_gemm_kq(Atype, d_A, m, k, Xh, d8T, Xm, n, (long)n_pad, d_C, ldc, s), "gemm_kq");
-        else
-            HIPCHK(lfamd_launch_gemm_wide(Atype, d_A, m, k, Xh, d8T, Xm, n, (long)n_pad, d_C, ldc, plain | (scaled << 1), s), "gemm_wide");
+        } else {
+            uint8_t *Pp = (uint8_t *)Xm + align_up(n_pad * nb * 32, 256); // after Xh, d8T, Xm (lfamd_mul_mat_workspace)
+            HIPCHK(lfamd_launch_gemm_wide(Atype, d_A, m, k, Xh, d8T, Xm, n, (long)n_pad, d_C, ldc, plain | (scaled << 1), Pp,
+                                          (size_t)((uint8_t *)d_ws + ws_bytes - Pp), s),
+                   "gemm_wide");
+        }
         return LFAMD_OK;
     }
     if (use_gemm_float(Atype, n, flags, k)) {
@@ -394,7 +400,7 @@ int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const v
             return fail(LFAMD_ERR_WORKSPACE, "mul_mat: workspace too small%s", "");
         size_t n_pad = align_up((size_t)n, 128);
         HIPCHK(lfamd_launch_prep_float(Atype, Btype, d_B, b_row_bytes, n, (long)n_pad, k, d_ws, s), "prep_float");
-        HIPCHK(lfamd_launch_gemm_wide(Atype, d_A, m, k, d_ws, d_ws, d_ws, n, (long)n_pad, d_C, ldc, plain, s), "gemm_wide");
+        HIPCHK(lfamd_launch_gemm_wide(Atype, d_A, m, k, d_ws, d_ws, d_ws, n, (long)n_pad, d_C, ldc, plain, nullptr, 0, s), "gemm_wide");
         return LFAMD_OK;
     }
     if (use_gemm_canon32(Atype, n, flags, k)) {
@@ -410,7 +416,7 @@ int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const v
         const bool q81 = vdt == LFAMD_TYPE_Q8_1;
         HIPCHK(lfamd_launch_wprep32(Atype, d_A, m, k, img, s), "wprep32");
         HIPCHK(lfamd_launch_prep80(Btype, d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, q81 ? sT : nullptr, s), "prep80");
-        HIPCHK(lfamd_launch_gemm_wide(Atype, img, m, k, Xh, d8T, q81 ? sT : nullptr, n, (long)n_pad, d_C, ldc, plain, s), "gemm_wide");
+        HIPCHK(lfamd_launch_gemm_wide(Atype, img, m, k, Xh, d8T, q81 ? sT : nullptr, n, (long)n_pad, d_C, ldc, plain, nullptr, 0, s), "gemm_wide");
         return LFAMD_OK;
     }
     if (use_gemm_canon(Atype, n, flags)) {
@@ -432,7 +438,7 @@ int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const v
             HIPCHK(lfamd_launch_prep_f32(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, mins16, nullptr, s), "prep_f32");
         else
             HIPCHK(lfamd_launch_prep_q8k(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, mins16, nullptr, s), "prep_q8k");
-        HIPCHK(lfamd_launch_gemm_wide(Atype, img, m, k, Xh, d8T, Xm, n, (long)n_pad, d_C, ldc, plain, s), "gemm_wide");
+        HIPCHK(lfamd_launch_gemm_wide(Atype, img, m, k, Xh, d8T, Xm, n, (long)n_pad, d_C, ldc, plain, nullptr, 0, s), "gemm_wide");
         return LFAMD_OK;
     }
     if (use_gemm_q80(Atype, n, flags)) {
@@ -545,7 +551,7 @@ int lfamd_mul_mat_multi_types(int count, const int *Atype, const void *const *d_
                 while (j1 < count && Atype[j1] == Atype[j0] && j1 - j0 < 4)
                     j1++;
                 HIPCHK(lfamd_launch_gemm_wide_multi(Atype[j0], j1 - j0, d_A + j0, m + j0, k, Xh, d8T, Xm, n, (long)n_pad, d_C + j0,
-                                                    ldc + j0, plain | 2, s),
+                                                    ldc + j0, plain | 2, nullptr, 0, s),
                        "gemm_wide_multi");
                 j0 = j1;
             }
@@ -618,7 +624,7 @@ int lfamd_mul_mat_multi(int Atype, int count, const void *const *d_A, const long
                 HIPCHK(lfamd_launch_prep_f32(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, scaled ? 2 : 0, nullptr, s), "prep_f32");
             else
                 HIPCHK(lfamd_launch_prep_q8k(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, scaled ? 2 : 0, nullptr, s), "prep_q8k");
-            HIPCHK(lfamd_launch_gemm_wide_multi(Atype, count, d_A, m, k, Xh, d8T, Xm, n, (long)n_pad, d_C, ldc, plain | (scaled << 1), s),
+            HIPCHK(lfamd_launch_gemm_wide_multi(Atype, count, d_A, m, k, Xh, d8T, Xm, n, (long)n_pad, d_C, ldc, plain | (scaled << 1), nullptr, 0, s),
                    "gemm_wide_multi");
             return LFAMD_OK;
         }

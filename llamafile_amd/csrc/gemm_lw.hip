@@ -44,7 +44,7 @@ extern "C" int lfamd_debug_lw_stamps(unsigned long long *dst) {
 template <int TYPE, bool MOE, bool FAST, int NT>
 __global__ __launch_bounds__(512) void gemm_lw_kernel(const gemm_mats mats, int nb, const _Float16 *__restrict__ Xh,
                                                       const float *__restrict__ d8T, const _Float16 *__restrict__ Xm, long n,
-                                                      long n_pad, int n_rb, int n_ct) {
+                                                      long n_pad, int n_rb, int n_ct, int ks, float *__restrict__ P) {
     static_assert(TYPE == LFAMD_TYPE_Q4_K || TYPE == LFAMD_TYPE_Q5_K || (TYPE == LFAMD_TYPE_Q6_K && FAST && !MOE),
                   "resident K-quant layouts; Q6_K on the scaled-operand body only");
     static_assert(NT == 4 || (NT == 2 && FAST && !MOE), "the 64-token tile exists for the scaled-operand body only");
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(512) void gemm_lw_kernel(const gemm_mats mats, int 
     const int i = lane & 31, h = lane >> 5;
 
     // ---- tile of this work-group (same orders as gemm_wide)
-    int rb, ct, moe_left = 0;
+    int rb, ct, moe_left = 0, kpart = 0;
     const uint8_t *__restrict__ A;
     float *__restrict__ C;
     long m, ldc, n0;
@@ -74,10 +74,13 @@ __global__ __launch_bounds__(512) void gemm_lw_kernel(const gemm_mats mats, int 
         m = mats.m[0], ldc = mats.ldc[0];
         n0 = (long)mats.moe_poff[e] + (long)ct * WD_COLS;
     } else {
-        const int n_wg = n_rb * n_ct;
+        // ks > 1 (scaled-operand body, few-token batches of one matrix): K is cut into ks parts, every (tile, part) is a
+        // work-group that writes its partial tile to P[part][token][row]; lw_ksplit_reduce sums the parts in order
+        const int n_tiles = n_rb * n_ct, n_wg = n_tiles * ks;
         const int id = blockIdx.x, q8 = n_wg >> 3, r8 = n_wg & 7, xcd = id & 7;
         const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3);
-        tile_of(L, n_rb, n_ct, rb, ct);
+        kpart = L / n_tiles;
+        tile_of(L - kpart * n_tiles, n_rb, n_ct, rb, ct);
         int mj = 0;
 #pragma unroll
         for (int jj = 1; jj < GEMM_MAX_MATS; jj++)
@@ -91,7 +94,8 @@ __global__ __launch_bounds__(512) void gemm_lw_kernel(const gemm_mats mats, int 
         n0 = (long)ct * COLS;
     }
     const long n_row_tiles = (m + 31) / 32;
-    const int H = 2 * nb; // half super-blocks
+    const int nbs = (nb + ks - 1) / ks, b_base = kpart * nbs; // this work-group's super-blocks [b_base, b_base + H / 2)
+    const int H = 2 * (b_base + nbs <= nb ? nbs : nb - b_base); // half super-blocks
 #if GEMM_DIAG == 4
     int stamp_n = 0;
     const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), real0 = __builtin_amdgcn_s_memrealtime();
@@ -137,7 +141,7 @@ __global__ __launch_bounds__(512) void gemm_lw_kernel(const gemm_mats mats, int 
         auto issue = [&](int hb, auto halfc, auto partc) {
             constexpr int half = decltype(halfc)::value, part = decltype(partc)::value;
             const int hbc = hb < H ? hb : H - 2 + half;
-            const int b = hbc >> 1;
+            const int b = b_base + (hbc >> 1);
             const uint32_t slot = lds0 + (uint32_t)(hb % LW_STAGES) * LW_SLOT;
             const uint8_t *xs = uniform_ptr(xbase + (size_t)b * n_pad * 512 + half * 256);
 #pragma unroll
@@ -369,7 +373,9 @@ __global__ __launch_bounds__(512) void gemm_lw_kernel(const gemm_mats mats, int 
         // mins one more MFMA per token tile with f16(d8 * S_j) x f16(-dmin * m_j): everything accumulates straight into
         // acc, nothing is scaled per super-block.  The K-step pipeline runs ACROSS the half-step barriers: the first
         // operands of the next stage are fetched during K-steps 6 and 7 of this one (see the loader's protocol).
-        u32x4 qa, qb, qan = {0, 0, 0, 0}, qbn = {0, 0, 0, 0}, hdn = {0, 0, 0, 0}, hqn = {0, 0, 0, 0};
+        u32x4 qa, qb;
+        frag_u wm; // mins weights of the current super-block: f16(-dmin * m_j), zero in the upper K half
+        wm.v = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
         half8_t F[4][NT], fxm[NT];
         uint32_t fl = 0;
         auto read_frags = [&](half8_t(&f)[NT], uint32_t slot, int t8) {
@@ -418,7 +424,7 @@ __global__ __launch_bounds__(512) void gemm_lw_kernel(const gemm_mats mats, int 
                 return dequant_q4(qw[t8], S, O, S16, O16, magic);
             }
         };
-        uint32_t dw6 = 0, dw6n = 0; // Q6_K: the row's f16 d (current / next super-block)
+        uint32_t dw6 = 0; // Q6_K: the row's f16 d
         auto dq = [&](auto halfc, int t8) -> half8_t { return dq_of(halfc, t8, qa, qb, hd, hq, dw6); }; // from the CURRENT operands
         const uint32_t d6_off = (uint32_t)(rw * 256 + i * 2) + LW_XM;
         const uint32_t wq_off = (uint32_t)(rw * 2048 + lane * 16) + LW_W, hd_off = (uint32_t)(rw * 1024 + i * 16) + LW_HDR;
@@ -459,16 +465,6 @@ __global__ __launch_bounds__(512) void gemm_lw_kernel(const gemm_mats mats, int 
                                          : "=&v"(fxm[0]), "=&v"(fxm[1])
                                          : "v"(slot_first + xm_off));
                     }
-                    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024" : "=&v"(qan), "=&v"(qbn) : "v"(slot_next + wq_off));
-                    if constexpr (Q6) // the upper code bits come with every half
-                        asm volatile("ds_read_b128 %0, %1" : "=v"(hqn) : "v"(slot_next + hq_off));
-                    if constexpr (half == 1) {
-                        asm volatile("ds_read_b128 %0, %1" : "=v"(hdn) : "v"(slot_next + hd_off));
-                        if constexpr (Q5)
-                            asm volatile("ds_read_b128 %0, %1" : "=v"(hqn) : "v"(slot_next + hq_off));
-                        if constexpr (Q6)
-                            asm volatile("ds_read_u16 %0, %1" : "=v"(dw6n) : "v"(slot_next + d6_off));
-                    }
                     read_frags(F[0], slot_next, 0);
                 } else {
                     // younger than K-step 7's fragments: [mins NT] + qa/qb 2 + [header 1 (+ fifth bits 1)] + fragments NT
@@ -476,16 +472,44 @@ __global__ __launch_bounds__(512) void gemm_lw_kernel(const gemm_mats mats, int 
                     // too, so that the next half's first weight fragment is built under this K-step's MFMAs instead of
                     // between two half-steps
                     read_frags(F[1], slot_next, 1);
-                    asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(qan), "+v"(qbn), "+v"(hdn), "+v"(hqn), "+v"(dw6n) : "n"(2 * NT));
+                    asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(qa), "+v"(qb), "+v"(hd), "+v"(hq), "+v"(dw6) : "n"(NT));
                     pin(F[3]);
                 }
                 half8_t wn = wf;
                 if (t8 + 1 < 8)
                     wn = dq(halfc, t8 + 1);
-                else if constexpr (half == 1)
-                    wn = dq_of(HN{}, 0, qan, qbn, hdn, hqn, dw6n); // next super-block: header fetched in K-step 6
                 else
-                    wn = dq_of(HN{}, 0, qan, qbn, hd, Q6 ? hqn : hq, dw6);
+                    wn = dq_of(HN{}, 0, qa, qb, hd, hq, dw6); // the next stage's operands (K-step 6's reads, waited for above)
+                if (t8 == 6) {
+                    // The last fragment of this half (K-step 7) is built: qa / qb — and, at the end of a super-block, its
+                    // header words — are dead, so the next stage's are read STRAIGHT INTO THE SAME REGISTERS.  (A second set
+                    // of variables copied over after the wait let hipcc place that register copy BEFORE the wait: an
+                    // intermittent read of data still in flight.)  The mins weights are taken from the header first.
+                    if constexpr (half == 1 && !Q6) {
+                        uint32_t sc03, sc47, mn03, mn47;
+                        q4k_scales_bytes(hd.y, hd.z, hd.w, sc03, sc47, mn03, mn47);
+                        const float ndmin = -h2f((uint16_t)(hd.x >> 16));
+#pragma unroll
+                        for (int p = 0; p < 4; p++) {
+                            const uint32_t mw = p < 2 ? mn03 : mn47;
+                            const float m0 = (float)((mw >> (16 * (p & 1))) & 0xff), m1 = (float)((mw >> (16 * (p & 1) + 8)) & 0xff);
+                            half2_t v = {(_Float16)(h ? 0.0f : m0 * ndmin), (_Float16)(h ? 0.0f : m1 * ndmin)};
+                            wm.p[p] = v;
+                        }
+                        asm volatile("" : "+v"(wm.v)); // (computed before the header registers are reloaded)
+                    }
+                    asm volatile("" : "+v"(wn)); // K-step 7's fragment is complete before its source registers are reloaded
+                    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024" : "=&v"(qa), "=&v"(qb) : "v"(slot_next + wq_off));
+                    if constexpr (Q6) // the upper code bits come with every half
+                        asm volatile("ds_read_b128 %0, %1" : "=v"(hq) : "v"(slot_next + hq_off));
+                    if constexpr (half == 1) {
+                        asm volatile("ds_read_b128 %0, %1" : "=v"(hd) : "v"(slot_next + hd_off));
+                        if constexpr (Q5)
+                            asm volatile("ds_read_b128 %0, %1" : "=v"(hq) : "v"(slot_next + hq_off));
+                        if constexpr (Q6)
+                            asm volatile("ds_read_u16 %0, %1" : "=v"(dw6) : "v"(slot_next + d6_off));
+                    }
+                }
 #pragma unroll
                 for (int nt = 0; nt < NT; nt++) // weights are the A operand here: a lane ends up with 4 consecutive ROWS per token
                     acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, F[t8 & 3][nt], acc[nt], 0, 0, 0);
@@ -496,29 +520,12 @@ __global__ __launch_bounds__(512) void gemm_lw_kernel(const gemm_mats mats, int 
                 }
                 wf = wn;
             }
-            if constexpr (Q6)
-                hq = hqn;
-            if constexpr (half == 1 && Q6)
-                hd = hdn, dw6 = dw6n;
-            if constexpr (half == 1 && !Q6) { // (the mins fragments were covered by K-step 7's wait)
+            if constexpr (half == 1 && !Q6) { // mins of the super-block (its fragments were covered by K-step 7's wait)
                 pin(fxm);
-                uint32_t sc03, sc47, mn03, mn47;
-                q4k_scales_bytes(hd.y, hd.z, hd.w, sc03, sc47, mn03, mn47);
-                const float ndmin = -h2f((uint16_t)(hd.x >> 16));
-                frag_u wm;
-#pragma unroll
-                for (int p = 0; p < 4; p++) {
-                    const uint32_t mw = p < 2 ? mn03 : mn47;
-                    const float m0 = (float)((mw >> (16 * (p & 1))) & 0xff), m1 = (float)((mw >> (16 * (p & 1) + 8)) & 0xff);
-                    half2_t v = {(_Float16)(h ? 0.0f : m0 * ndmin), (_Float16)(h ? 0.0f : m1 * ndmin)};
-                    wm.p[p] = v;
-                }
 #pragma unroll
                 for (int nt = 0; nt < NT; nt++)
                     acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wm.v, fxm[nt], acc[nt], 0, 0, 0);
-                hd = hdn, hq = hqn;
             }
-            qa = qan, qb = qbn;
         };
 
         // prologue: stage 0
@@ -572,6 +579,9 @@ __global__ __launch_bounds__(512) void gemm_lw_kernel(const gemm_mats mats, int 
     // issue-bound: 6.1k cycles of a 62k-cycle work-group with dword stores)
     if constexpr (FAST) {
         if (active) {
+            const bool part = !MOE && ks > 1; // partial tile: rows padded to the row-block grid, no token scale yet
+            if (part)
+                C = P + (size_t)kpart * (size_t)n_pad * (size_t)(n_rb * 128), ldc = (long)n_rb * 128, m = ldc;
             const bool vec = (ldc & 3) == 0 && (m & 3) == 0 && (((uintptr_t)C) & 15) == 0;
 #pragma unroll
             for (int nt = 0; nt < NT; nt++) {
@@ -584,7 +594,7 @@ __global__ __launch_bounds__(512) void gemm_lw_kernel(const gemm_mats mats, int 
                 } else if (tok >= n) {
                     continue;
                 }
-                const float ts = d8T[tok]; // 2^e of the token's normalised staging (pack.hip, prep_scaled_kernel): exact
+                const float ts = part ? 1.0f : d8T[tok]; // 2^e of the token's normalised staging (pack.hip, prep_scaled_kernel): exact
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
                     const long row0 = rt * 32 + 8 * g + 4 * h;
@@ -628,12 +638,12 @@ __global__ __launch_bounds__(512) void gemm_lw_kernel(const gemm_mats mats, int 
 }
 
 hipError_t lfamd_lw_go(int Atype, const gemm_mats &mats, int nb, const void *Xh, const void *d8T, const void *Xm, long n, long n_pad,
-                       int n_rb, int n_ct, unsigned n_wg, int moe, int fast, int nt, hipStream_t s) {
-    if ((nt != 4 && nt != 2) || (nt == 2 && (!fast || moe)))
+                       int n_rb, int n_ct, unsigned n_wg, int moe, int fast, int nt, int ks, float *P, hipStream_t s) {
+    if ((nt != 4 && nt != 2) || (nt == 2 && (!fast || moe)) || ks < 1 || (ks > 1 && (!fast || moe || !P || mats.count != 1)))
         return hipErrorInvalidValue;
 #define LW_GO(T, M, F, N)                                                                                              \
     gemm_lw_kernel<T, M, F, N><<<n_wg, 512, 0, s>>>(mats, nb, (const _Float16 *)Xh, (const float *)d8T, (const _Float16 *)Xm, n,  \
-                                                    n_pad, n_rb, n_ct)
+                                                    n_pad, n_rb, n_ct, ks, P)
 #define LW_GO2(T)                                                                                                      \
     do {                                                                                                               \
         if (moe && fast)                                                                                               \
@@ -661,5 +671,31 @@ hipError_t lfamd_lw_go(int Atype, const gemm_mats &mats, int nb, const void *Xh,
     }
 #undef LW_GO2
 #undef LW_GO
+    return hipGetLastError();
+}
+
+// Sum of the K parts of a split launch (fixed order: deterministic) times the token's output scale -> C.
+__global__ void lw_ksplit_reduce(const float *__restrict__ P, int ks, long n, long n_pad, long ldp, long m, float *__restrict__ C,
+                                 long ldc, const float *__restrict__ tok_scale) {
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x; // (token, row quad)
+    const long quads = ldp / 4, tok = q / quads, r0 = (q - tok * quads) * 4;
+    if (tok >= n || r0 >= m)
+        return;
+    float4 a = *(const float4 *)(P + tok * ldp + r0);
+    for (int kp = 1; kp < ks; kp++) {
+        const float4 b = *(const float4 *)(P + ((size_t)kp * n_pad + tok) * ldp + r0);
+        a.x += b.x, a.y += b.y, a.z += b.z, a.w += b.w;
+    }
+    const float ts = tok_scale[tok];
+    const float v[4] = {a.x * ts, a.y * ts, a.z * ts, a.w * ts};
+    for (int e = 0; e < 4; e++)
+        if (r0 + e < m)
+            C[tok * ldc + r0 + e] = v[e];
+}
+
+hipError_t lfamd_lw_ksplit_reduce(const float *P, int ks, long n, long n_pad, long ldp, long m, float *C, long ldc,
+                                  const float *tok_scale, hipStream_t s) {
+    const long threads = n * (ldp / 4);
+    lw_ksplit_reduce<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>(P, ks, n, n_pad, ldp, m, C, ldc, tok_scale);
     return hipGetLastError();
 }

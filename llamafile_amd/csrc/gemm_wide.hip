@@ -16,7 +16,25 @@ hipError_t lfamd_wide_go_f16(WIDE_ARGS);
 hipError_t lfamd_wide_go_bf16(WIDE_ARGS);
 
 hipError_t lfamd_lw_go(int Atype, const gemm_mats &mats, int nb, const void *Xh, const void *d8T, const void *Xm, long n, long n_pad,
-                       int n_rb, int n_ct, unsigned n_wg, int moe, int fast, int nt, hipStream_t s);
+                       int n_rb, int n_ct, unsigned n_wg, int moe, int fast, int nt, int ks, float *P, hipStream_t s);
+hipError_t lfamd_lw_ksplit_reduce(const float *P, int ks, long n, long n_pad, long ldp, long m, float *C, long ldc,
+                                  const float *tok_scale, hipStream_t s);
+
+// Few-token batches (n <= 128) of one matrix whose 128 x 64 tiles leave most CUs idle: K is cut into up to 8 parts, the
+// partial tiles go to a workspace and are summed by a second kernel (4096 x 4096 x 32: 32 work-groups of 16 serial
+// super-blocks become 256 of 2).
+extern "C" size_t lfamd_gemm_lw_ksplit_bytes(long m, long n) {
+    if (m <= 0 || n <= 8 || n > 128)
+        return 0;
+    const long n_rb = (m + 127) / 128, tiles2 = n_rb * ((n + 63) / 64);
+    return tiles2 > 128 ? 0 : (size_t)8 * 128 * (size_t)n_rb * 128 * sizeof(float);
+}
+static int lw_ksplit(int tiles2, int nb) {
+    int ks = 1;
+    while (ks < 8 && tiles2 * ks * 2 <= 256 && nb / (ks * 2) >= 2)
+        ks *= 2;
+    return ks;
+}
 
 // Q4_K / Q5_K without K split run the loader-wave body (gemm_lw.hip) unless the caller asks for the plain one.
 // `mode` (an argument of every launcher here) bit 0: plain body; bit 1: the activations were staged SCALED (pack.hip, prep mode 2) for the scaled-operand
@@ -30,7 +48,7 @@ static bool lw_allowed(int mode) {
     return !(mode & 1) && !env_plain;
 }
 
-static hipError_t wide_go(int Atype, int mode, WIDE_ARGS) {
+static hipError_t wide_go(int Atype, int mode, float *P, size_t P_bytes, WIDE_ARGS) {
     const int g_scaled = (mode >> 1) & 1;
     const bool q45 = Atype == LFAMD_TYPE_Q4_K || Atype == LFAMD_TYPE_Q5_K;
     if ((q45 || (Atype == LFAMD_TYPE_Q6_K && g_scaled && !moe)) && lw_allowed(mode)) {
@@ -38,12 +56,21 @@ static hipError_t wide_go(int Atype, int mode, WIDE_ARGS) {
             // scaled operands: 128 x 128 tiles when they fill the chip, else 128 x 64 (twice the work-groups, no K split)
             static const int full_grid = getenv("LFAMD_LW_FULL_GRID") ? atoi(getenv("LFAMD_LW_FULL_GRID")) : LW_FULL_GRID; // (tuning)
             if (n_rb * n_ct >= full_grid)
-                return lfamd_lw_go(Atype, mats, nb, Xh, d8T, Xm, n, n_pad, n_rb, n_ct, (unsigned)(n_rb * n_ct), 0, 1, 4, s);
+                return lfamd_lw_go(Atype, mats, nb, Xh, d8T, Xm, n, n_pad, n_rb, n_ct, (unsigned)(n_rb * n_ct), 0, 1, 4, 1, nullptr, s);
             const int n_ct2 = (int)((n + 63) / 64);
-            return lfamd_lw_go(Atype, mats, nb, Xh, d8T, Xm, n, n_pad, n_rb, n_ct2, (unsigned)(n_rb * n_ct2), 0, 1, 2, s);
+            const int ksp = (mats.count == 1 && P && n_pad == 128) ? lw_ksplit(n_rb * n_ct2, nb) : 1;
+            if (ksp > 1 && P_bytes >= (size_t)ksp * 128 * (size_t)n_rb * 128 * sizeof(float)) {
+                hipError_t e = lfamd_lw_go(Atype, mats, nb, Xh, d8T, Xm, n, n_pad, n_rb, n_ct2, (unsigned)(n_rb * n_ct2 * ksp), 0, 1, 2,
+                                           ksp, P, s);
+                if (e != hipSuccess)
+                    return e;
+                return lfamd_lw_ksplit_reduce(P, ksp, n, n_pad, (long)n_rb * 128, mats.m[0], mats.C[0], mats.ldc[0],
+                                              (const float *)d8T, s);
+            }
+            return lfamd_lw_go(Atype, mats, nb, Xh, d8T, Xm, n, n_pad, n_rb, n_ct2, (unsigned)(n_rb * n_ct2), 0, 1, 2, 1, nullptr, s);
         }
         if (ks == 1 && q45) // exact codes; the grouped MUL_MAT_ID launch also on scaled operands
-            return lfamd_lw_go(Atype, mats, nb, Xh, d8T, Xm, n, n_pad, n_rb, n_ct, n_wg, moe, moe ? g_scaled : 0, 4, s);
+            return lfamd_lw_go(Atype, mats, nb, Xh, d8T, Xm, n, n_pad, n_rb, n_ct, n_wg, moe, moe ? g_scaled : 0, 4, 1, nullptr, s);
     }
     if (g_scaled)
         return hipErrorInvalidValue; // scaled activations reached a body that expects integer codes
@@ -108,7 +135,8 @@ extern "C" int lfamd_gemm_wide_scaled_ok(int Atype, int plain) {
 
 extern "C" hipError_t lfamd_launch_gemm_wide_multi(int Atype, int count, const void *const *A, const long *m, long k,
                                                    const void *Xh, const void *d8T, const void *Xm, long n, long n_pad,
-                                                   float *const *C, const long *ldc, int mode, hipStream_t s) {
+                                                   float *const *C, const long *ldc, int mode, void *P, size_t P_bytes,
+                                                   hipStream_t s) {
     if (n <= 0 || count <= 0)
         return hipSuccess;
     if (n_pad % WD_COLS || count > GEMM_MAX_MATS)
@@ -143,12 +171,13 @@ extern "C" hipError_t lfamd_launch_gemm_wide_multi(int Atype, int count, const v
             zero_c_kernel<<<blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks), 256, 0, s>>>(mats.C[i], mats.ldc[i], mats.m[i], n);
         }
     }
-    return wide_go(Atype, mode, mats, nb, Xh, d8T, Xm, n, n_pad, n_rb, n_ct, ks, nbs, (unsigned)n_wg, 0, s);
+    return wide_go(Atype, mode, (float *)P, P_bytes, mats, nb, Xh, d8T, Xm, n, n_pad, n_rb, n_ct, ks, nbs, (unsigned)n_wg, 0, s);
 }
 
 extern "C" hipError_t lfamd_launch_gemm_wide(int Atype, const void *A, long m, long k, const void *Xh, const void *d8T,
-                                             const void *Xm, long n, long n_pad, float *C, long ldc, int mode, hipStream_t s) {
-    return lfamd_launch_gemm_wide_multi(Atype, 1, &A, &m, k, Xh, d8T, Xm, n, n_pad, &C, &ldc, mode, s);
+                                             const void *Xm, long n, long n_pad, float *C, long ldc, int mode, void *P, size_t P_bytes,
+                                             hipStream_t s) {
+    return lfamd_launch_gemm_wide_multi(Atype, 1, &A, &m, k, Xh, d8T, Xm, n, n_pad, &C, &ldc, mode, P, P_bytes, s);
 }
 
 // GGML_OP_MUL_MAT_ID batches: one launch over (expert, row block, token tile); see gemm_mats.  n_pad = slots staged by the
@@ -169,5 +198,5 @@ extern "C" hipError_t lfamd_launch_gemm_wide_moe(int Atype, const void *W, long 
     const unsigned n_wg = (unsigned)experts * n_rb * ct_max;
     if (Atype != LFAMD_TYPE_Q4_K && Atype != LFAMD_TYPE_Q5_K && Atype != LFAMD_TYPE_Q6_K)
         return hipErrorInvalidValue;
-    return wide_go(Atype, mode, mats, nb, Xh, d8T, Xm, n_pad, n_pad, n_rb, ct_max, 1, nb, n_wg, 1, s);
+    return wide_go(Atype, mode, nullptr, 0, mats, nb, Xh, d8T, Xm, n_pad, n_pad, n_rb, ct_max, 1, nb, n_wg, 1, s);
 }

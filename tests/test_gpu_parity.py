@@ -117,6 +117,29 @@ def test_loader_wave_gemm_full_grid(gpu, oracle, t, f32in):
         assert err <= tol, (T.NAMES[t], flags, err)
 
 
+@pytest.mark.parametrize("t", [T.Q4_K, T.Q5_K, T.Q6_K], ids=lambda t: T.NAMES[t])
+@pytest.mark.parametrize("shape", [(4096, 9, 4096), (4096, 32, 4096), (1000, 100, 2048), (2048, 128, 1024), (300, 70, 5 * 256),
+                                   (8192, 64, 2048)], ids=str)
+def test_few_token_batches_k_split(gpu, oracle, t, shape):
+    """Batches of 9 .. 128 tokens on one matrix: the scaled-operand body cuts K into up to 8 parts across work-groups
+    (partial tiles in the workspace, summed in a fixed order by a second kernel) — against the oracle, bit-identical on a
+    rerun, ragged rows / tokens, odd super-block counts, and shapes where the split does not apply."""
+    from llamafile_amd import synth
+    m, n, k = shape
+    A = synth.random_weights(t, m, k, 7100 + t)
+    x = synth.random_activations(n, k, 7101)
+    B = synth.quantize_activations(T.Q8_K, x)
+    ok, G = oracle.sgemm(t, A, T.Q8_K, B, m, n, k, nth=8)
+    assert ok == 1
+    W = gpu.upload_weights(t, A, m, k)
+    Bd = torch.from_numpy(x).cuda().view(torch.uint8).view(n, k * 4)
+    C1 = gpu.mul_mat(W, Bd, T.F32)
+    C2 = gpu.mul_mat(W, Bd, T.F32)
+    torch.cuda.synchronize()
+    assert torch.equal(C1.view(torch.int32), C2.view(torch.int32))
+    assert rel_err(C1.cpu().numpy(), G) <= SCALED_TOL, (T.NAMES[t], shape, rel_err(C1.cpu().numpy(), G))
+
+
 @pytest.mark.parametrize("t", [T.Q4_K, T.Q6_K], ids=lambda t: T.NAMES[t])
 @pytest.mark.parametrize("f32in", [False, True], ids=["q8k", "f32"])
 def test_scaled_gemm_activation_range(gpu, oracle, t, f32in):

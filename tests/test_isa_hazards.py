@@ -1,0 +1,37 @@
+"""CPU: the ISA of the inline-asm GEMM kernels never touches a register a load is still in flight to (tools/isa_hazards.py).
+hipcc cross-compiles gfx950 here; four translation units in parallel, about a minute."""
+import os
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import isa_hazards  # noqa: E402
+
+TUS = ["gemm_lw.hip", "gemm_wide_k4.hip", "gemm_wide_k6.hip", "gemm_mfma.hip"]
+
+
+@pytest.mark.skipif(not os.path.exists(isa_hazards.HIPCC), reason="needs hipcc")
+def test_no_register_is_touched_before_its_load_is_waited_for():
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        results = list(ex.map(lambda f: isa_hazards.check_file(os.path.join(ROOT, "llamafile_amd", "csrc", f)), TUS))
+    for f, res in zip(TUS, results):
+        assert res, f  # kernels were found
+        for kernel, bad in res.items():
+            assert not bad, (f, kernel, bad[:3])
+
+
+def test_checker_flags_a_copy_before_the_wait():
+    asm = """
+_Z4demov: ; @demo
+	ds_read_b128 v[10:13], v2
+	v_mov_b64_e32 v[20:21], v[10:11]
+	s_waitcnt lgkmcnt(0)
+	v_add_u32_e32 v3, v12, v13
+.Lfunc_end0:
+"""
+    assert isa_hazards.check_asm(asm)["_Z4demov"] == ["v_mov_b64_e32 v[20:21], v[10:11]"]
+    ok = asm.replace("v_mov_b64_e32 v[20:21], v[10:11]\n\ts_waitcnt lgkmcnt(0)", "s_waitcnt lgkmcnt(0)\n\tv_mov_b64_e32 v[20:21], v[10:11]")
+    assert isa_hazards.check_asm(ok)["_Z4demov"] == []
