@@ -1,5 +1,5 @@
 """CPU: the ISA of the inline-asm GEMM kernels never touches a register a load is still in flight to (tools/isa_hazards.py).
-hipcc cross-compiles gfx950 here; four translation units in parallel, about a minute."""
+hipcc cross-compiles gfx950 here (device code only, a few seconds per translation unit)."""
 import os
 import sys
 from concurrent.futures import ThreadPoolExecutor
@@ -10,7 +10,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import isa_hazards  # noqa: E402
 
-TUS = ["gemm_lw.hip", "gemm_wide_k4.hip", "gemm_wide_k6.hip", "gemm_mfma.hip"]
+TUS = ["gemm_lw.hip", "gemm_mfma.hip", "gemm_wide_k4.hip", "gemm_wide_k5.hip", "gemm_wide_k6.hip", "gemm_wide_l4.hip",
+       "gemm_wide_l5.hip", "gemm_wide_c16.hip", "gemm_wide_misc.hip"]  # every translation unit with inline-asm loads
 
 
 @pytest.mark.skipif(not os.path.exists(isa_hazards.HIPCC), reason="needs hipcc")
