@@ -1,7 +1,11 @@
-// gemm_lw.hip — prefill GEMM, "loader-wave" body for the resident Q4_K / Q5_K layouts.
+// gemm_lw.hip — prefill GEMM, "loader-wave" body for the resident Q4_K / Q5_K / Q6_K layouts.
 //
-// Same arithmetic as gemm_wide / gemm_mfma (exact integer codes on v_mfma_f32_32x32x16_f16, f32 scales once per
-// super-block; reference mul_mat_qX_K_q8_K_T, iqk_mul_mat.inc:601-643).  What changes is who does what:
+// Two arithmetic forms of the reference's mul_mat_qX_K_q8_K_T (iqk_mul_mat.inc:601-643):
+//   exact  (FAST = false; LFAMD_FLAG_PRECISE, MUL_MAT_ID on request): integer codes on v_mfma_f32_32x32x16_f16, f32 scales
+//          once per super-block, as gemm_wide / gemm_mfma;
+//   scaled (FAST = true; the default for every batch): f16(d * sc * q) x f16(d8 * code * 2^-e(token)), nothing per
+//          super-block, output column times 2^e in the store (<= 1e-3 against the oracle).
+// What changes against the 8-wave bodies is who does what:
 //
 //   * waves 0-3 COMPUTE: 32 weight rows x 128 tokens each (work-group tile 128 x 128).  One dequantised fragment (9-11
 //     VALU instructions) feeds FOUR MFMAs; with the per-super-block scaling that is ~6 VALU per MFMA — the 32 x 64 wave
@@ -12,7 +16,8 @@
 //     operand) is issued by them, two stages ahead, with counted vmcnt.  An LDS-DMA piece blocks its issuer for
 //     100-200 cycles; here that time belongs to a wave with nothing else to do, on a SIMD whose other wave computes.
 //   * stage = HALF a super-block (128 k): 32 KiB of activation codes + 8 KiB of nibbles (+ headers / d8 / mins operand
-//     with the first half), three stages in LDS (157.5 KiB), ONE s_barrier per half super-block.
+//     with the first half), three stages in LDS (157.5 KiB); loaders and compute waves synchronise through two counters
+//     in LDS ("landed" / "released" stages), no work-group barrier inside the K loop.
 #include "gemm_wide_impl.h"
 
 #define LW_X 0          // 128 tokens x 256 B, XOR-swizzled 16-byte chunks
