@@ -402,6 +402,17 @@ def main():
                                             "achieved": round(tf, 1), "frac": round(tf / MFMA_F16_PEAK_TFLOPS, 4),
                                             "kernel": "prep_f32 + gemm_lw_kernel<Q4_K, 128x128 tile, scaled operands>"}
 
+    if roofline_gemm and os.path.exists(tfile):
+        # HBM traffic of the two GEMM tiles: averages over the launches of the profiled bench (each tile serves several
+        # shapes of the model), from the same PMC passes as the GEMV's
+        try:
+            tj = json.load(open(tfile))
+            roofline_gemm["traffic_avg_over_model_launches"] = {
+                "gemm_lw 128x64": tj.get("gemm_q4k_lw_128x64", {}).get("hbm_bytes_per_launch"),
+                "gemm_lw 128x128": tj.get("gemm_q4k_lw_128x128", {}).get("hbm_bytes_per_launch")}
+        except ValueError:
+            pass
+
     if rank != 0:
         if dist_on:
             torch.distributed.destroy_process_group()
