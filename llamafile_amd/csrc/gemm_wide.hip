@@ -48,6 +48,37 @@ static bool lw_allowed(int mode) {
     return !(mode & 1) && !env_plain;
 }
 
+// The first rb_cut row blocks of `mats` / the rest (a matrix straddling the cut is split: weights by row tiles, C by rows).
+static void split_mats(const gemm_mats &mats, int rb_cut, size_t row_tile_bytes, gemm_mats &lo, gemm_mats &hi) {
+    lo = mats, hi = mats;
+    lo.count = hi.count = 0;
+    int lo_end = 0, hi_end = 0;
+    for (int j = 0; j < mats.count; j++) {
+        const int start = j ? mats.rb_end[j - 1] : 0, end = mats.rb_end[j];
+        if (start < rb_cut) { // rows [0, (min(end, rb_cut) - start) * 128) of matrix j
+            const int i = lo.count++;
+            const int rbs = (end < rb_cut ? end : rb_cut) - start;
+            lo.A[i] = mats.A[j], lo.C[i] = mats.C[j], lo.ldc[i] = mats.ldc[j];
+            lo.m[i] = end <= rb_cut ? mats.m[j] : (long)rbs * 128;
+            lo_end += rbs;
+            lo.rb_end[i] = lo_end;
+        }
+        if (end > rb_cut) {
+            const int i = hi.count++;
+            const int skip = start < rb_cut ? rb_cut - start : 0; // row blocks of matrix j that went to `lo`
+            hi.A[i] = mats.A[j] + (size_t)skip * 4 * row_tile_bytes;
+            hi.C[i] = mats.C[j] + (size_t)skip * 128, hi.ldc[i] = mats.ldc[j];
+            hi.m[i] = mats.m[j] - (long)skip * 128;
+            hi_end += end - start - skip;
+            hi.rb_end[i] = hi_end;
+        }
+    }
+    for (int i = lo.count; i < GEMM_MAX_MATS; i++)
+        lo.A[i] = lo.A[0], lo.C[i] = lo.C[0], lo.m[i] = 0, lo.ldc[i] = 0, lo.rb_end[i] = lo_end;
+    for (int i = hi.count; i < GEMM_MAX_MATS; i++)
+        hi.A[i] = hi.A[0], hi.C[i] = hi.C[0], hi.m[i] = 0, hi.ldc[i] = 0, hi.rb_end[i] = hi_end;
+}
+
 static hipError_t wide_go(int Atype, int mode, float *P, size_t P_bytes, WIDE_ARGS) {
     const int g_scaled = (mode >> 1) & 1;
     const bool q45 = Atype == LFAMD_TYPE_Q4_K || Atype == LFAMD_TYPE_Q5_K;
@@ -55,8 +86,25 @@ static hipError_t wide_go(int Atype, int mode, float *P, size_t P_bytes, WIDE_AR
         if (g_scaled && !moe) {
             // scaled operands: 128 x 128 tiles when they fill the chip, else 128 x 64 (twice the work-groups, no K split)
             static const int full_grid = getenv("LFAMD_LW_FULL_GRID") ? atoi(getenv("LFAMD_LW_FULL_GRID")) : LW_FULL_GRID; // (tuning)
-            if (n_rb * n_ct >= full_grid)
+            if (n_rb * n_ct >= full_grid) {
+                // full rounds of 128 x 128 tiles; a last round of at most 128 of them (half the CUs idle) runs as one round of
+                // 128 x 64 tiles instead (0.73 of the time): ffn_gate + ffn_up at 512 tokens = 896 tiles = 3 rounds + 128
+                static const bool no_tail = getenv("LFAMD_LW_NO_TAIL_SPLIT") != nullptr; // (tests compare the two)
+                const int tiles = n_rb * n_ct, rem = tiles % 256;
+                if (!no_tail && tiles > 256 && rem > 0 && rem <= 128 && rem % n_ct == 0) {
+                    const int rb_cut = (tiles - rem) / n_ct;
+                    const size_t tile_bytes = (size_t)nb * (Atype == LFAMD_TYPE_Q5_K ? P5K_TILE : Atype == LFAMD_TYPE_Q6_K ? P6K_TILE : P4K_TILE);
+                    gemm_mats lo, hi;
+                    split_mats(mats, rb_cut, tile_bytes, lo, hi);
+                    hipError_t e = lfamd_lw_go(Atype, lo, nb, Xh, d8T, Xm, n, n_pad, rb_cut, n_ct, (unsigned)(rb_cut * n_ct), 0, 1, 4, 1,
+                                               nullptr, s);
+                    if (e != hipSuccess)
+                        return e;
+                    const int n_ct2 = (int)((n + 63) / 64), rb_hi = n_rb - rb_cut;
+                    return lfamd_lw_go(Atype, hi, nb, Xh, d8T, Xm, n, n_pad, rb_hi, n_ct2, (unsigned)(rb_hi * n_ct2), 0, 1, 2, 1, nullptr, s);
+                }
                 return lfamd_lw_go(Atype, mats, nb, Xh, d8T, Xm, n, n_pad, n_rb, n_ct, (unsigned)(n_rb * n_ct), 0, 1, 4, 1, nullptr, s);
+            }
             const int n_ct2 = (int)((n + 63) / 64);
             const int ksp = (mats.count == 1 && P && n_pad == 128) ? lw_ksplit(n_rb * n_ct2, nb) : 1;
             if (ksp > 1 && P_bytes >= (size_t)ksp * 128 * (size_t)n_rb * 128 * sizeof(float)) {

@@ -87,3 +87,19 @@ def test_prefill_gemm_full_size_properties(gpu, t, m, k):
     # ragged batch: 500 of the 512 rows give the same 500 columns (padding tokens are zero and never stored)
     Cs = gpu.mul_mat(W, xb[:500].contiguous(), T.F32, flags=base)
     assert Cs.shape[0] == 500 and torch.equal(_bits(Cs), _bits(C[:500]))
+
+
+def test_gate_up_fused_launch_tail_split(gpu):
+    """ffn_gate + ffn_up at 512 tokens as ONE call: 896 tiles of 128 x 128 = three full rounds + 128, whose last round runs
+    as 128 x 64 tiles (the second matrix is split at a row-block boundary).  Bit-identical to the two separate calls, which
+    run 128 x 128 tiles only (448 tiles each: no such tail) — i.e. the tile shape does not change a single bit."""
+    from llamafile_amd import synth
+    t, m, k = T.Q4_K, 14336, 4096
+    Ws = [gpu.upload_weights(t, synth.random_weights_torch(t, m, k, 31 + i), m, k) for i in range(2)]
+    x = torch.from_numpy(synth.random_activations(PREFILL, k, 32)).cuda()
+    xb = x.view(torch.uint8).view(PREFILL, k * 4)
+    fused = gpu.mul_mat_multi(Ws, xb, T.F32, n=PREFILL)
+    for W, f in zip(Ws, fused):
+        sep = gpu.mul_mat(W, xb, T.F32)
+        assert torch.isfinite(f).all()
+        assert torch.equal(_bits(f), _bits(sep))
