@@ -118,7 +118,8 @@ int lfamd_mul_mat_multi(int Atype, int count, const void *const *d_A_packed, con
 
 /* The same for sibling nodes whose weight TYPES may differ (attn_q/k = Q4_K or Q5_K with attn_v = Q6_K in the *_K_M
  * files): at decode (n = 1) those two groups run as ONE launch (bit-identical to the separate calls); batches of
- * Q4_K / Q5_K / Q6_K nodes share one staged copy of the activations (scaled-operand body, see above); any other mix falls
+ * Q4_K / Q5_K / Q6_K nodes share one staged copy of the activations (scaled-operand body, see above) and, when the two types'
+ * tiles fill one round of the chip, one launch; any other mix falls
  * back to one lfamd_mul_mat_multi per run of equal types. */
 int lfamd_mul_mat_multi_types(int count, const int *Atype, const void *const *d_A_packed, const long *m, long k, int Btype,
                               const void *d_B, size_t b_row_bytes, long n, float *const *d_C, const long *ldc, void *d_ws,

@@ -46,6 +46,9 @@ hipError_t lfamd_launch_gemm_wide_multi(int, int, const void *const *, const lon
 hipError_t lfamd_launch_gemm_wide(int, const void *, long, long, const void *, const void *, const void *, long, long,
                                   float *, long, int, void *, size_t, hipStream_t);
 size_t lfamd_gemm_lw_ksplit_bytes(long, long);
+hipError_t lfamd_launch_gemm_wide_dual(int, int, const void *const *, const long *, float *const *, const long *, int, int,
+                                       const void *const *, const long *, float *const *, const long *, long, const void *,
+                                       const void *, const void *, long, long, int, hipStream_t);
 hipError_t lfamd_launch_gemm_kq(int, const void *, long, long, const void *, const void *, const void *, long, long,
                                 float *, long, hipStream_t);
 hipError_t lfamd_launch_quantize(int, const float *, long, long, size_t, void *, size_t, hipStream_t);
@@ -546,6 +549,34 @@ int lfamd_mul_mat_multi_types(int count, const int *Atype, const void *const *d_
                 HIPCHK(lfamd_launch_prep_f32(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, 2, nullptr, s), "prep_f32");
             else
                 HIPCHK(lfamd_launch_prep_q8k(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, 2, nullptr, s), "prep_q8k");
+            { // {Q4_K | Q5_K, Q6_K} whose tiles fill more than half the chip in one round: one launch for both types
+                const void *Aa[4], *Ab[4];
+                long ma_[4], mb_[4], la[4], lb[4];
+                float *Ca[4], *Cb[4];
+                int ta = -1, na = 0, nbq = 0;
+                bool two = true;
+                for (int j = 0; j < count && two; j++) {
+                    if (Atype[j] == LFAMD_TYPE_Q6_K) {
+                        two = nbq < 4;
+                        if (two)
+                            Ab[nbq] = d_A[j], mb_[nbq] = m[j], lb[nbq] = ldc[j], Cb[nbq] = d_C[j], nbq++;
+                    } else if (ta < 0 || ta == Atype[j]) {
+                        two = na < 4;
+                        if (two)
+                            Aa[na] = d_A[j], ma_[na] = m[j], la[na] = ldc[j], Ca[na] = d_C[j], na++, ta = Atype[j];
+                    } else {
+                        two = false;
+                    }
+                }
+                if (two && na > 0 && nbq > 0) {
+                    hipError_t e = lfamd_launch_gemm_wide_dual(ta, na, Aa, ma_, Ca, la, LFAMD_TYPE_Q6_K, nbq, Ab, mb_, Cb, lb, k, Xh, d8T,
+                                                               Xm, n, (long)n_pad, plain | 2, s);
+                    if (e == hipSuccess)
+                        return LFAMD_OK;
+                    if (e != hipErrorNotSupported)
+                        HIPCHK(e, "gemm_wide_dual");
+                }
+            }
             for (int j0 = 0; j0 < count;) {
                 int j1 = j0 + 1;
                 while (j1 < count && Atype[j1] == Atype[j0] && j1 - j0 < 4)

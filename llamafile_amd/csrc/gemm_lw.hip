@@ -46,17 +46,19 @@ extern "C" int lfamd_debug_lw_stamps(unsigned long long *dst) {
 
 // NT = token tiles of 32 per work-group: 4 (128 x 128 tile) or, scaled-operand body only, 2 (128 x 64: grids of 96 .. 191
 // tiles of 128 x 128 — attn_output, ffn_down of an 8B model at 512 tokens — fill the 256 CUs with these instead)
+// The work of work-group `bid` of `gdim` (the plain kernel passes its block index and grid size; the two-type kernel gives
+// each type its own sub-grid); `lds` = the work-group's LW_STAGES * LW_SLOT + 16 bytes.
 template <int TYPE, bool MOE, bool FAST, int NT>
-__global__ __launch_bounds__(512) void gemm_lw_kernel(const gemm_mats mats, int nb, const _Float16 *__restrict__ Xh,
-                                                      const float *__restrict__ d8T, const _Float16 *__restrict__ Xm, long n,
-                                                      long n_pad, int n_rb, int n_ct, int ks, float *__restrict__ P) {
+__device__ __forceinline__ void gemm_lw_body(const gemm_mats &mats, int nb, const _Float16 *__restrict__ Xh,
+                                             const float *__restrict__ d8T, const _Float16 *__restrict__ Xm, long n, long n_pad,
+                                             int n_rb, int n_ct, int ks, float *__restrict__ P, const int bid, const int gdim,
+                                             uint8_t *lds) {
     static_assert(TYPE == LFAMD_TYPE_Q4_K || TYPE == LFAMD_TYPE_Q5_K || (TYPE == LFAMD_TYPE_Q6_K && FAST && !MOE),
                   "resident K-quant layouts; Q6_K on the scaled-operand body only");
     static_assert(NT == 4 || (NT == 2 && FAST && !MOE), "the 64-token tile exists for the scaled-operand body only");
     constexpr int COLS = 32 * NT;
     constexpr bool Q5 = TYPE == LFAMD_TYPE_Q5_K, Q6 = TYPE == LFAMD_TYPE_Q6_K;
     constexpr int TILE = Q5 ? P5K_TILE : Q6 ? P6K_TILE : P4K_TILE;
-    __shared__ __attribute__((aligned(16))) uint8_t lds[LW_STAGES * LW_SLOT + 16];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 31, h = lane >> 5;
 
@@ -66,9 +68,9 @@ __global__ __launch_bounds__(512) void gemm_lw_kernel(const gemm_mats mats, int 
     float *__restrict__ C;
     long m, ldc, n0;
     if constexpr (MOE) {
-        const int per_ct = (int)(gridDim.x / mats.moe_ct_max);
-        ct = blockIdx.x / per_ct;
-        const int rem = blockIdx.x - ct * per_ct;
+        const int per_ct = gdim / mats.moe_ct_max;
+        ct = bid / per_ct;
+        const int rem = bid - ct * per_ct;
         const int e = rem / n_rb;
         rb = rem - e * n_rb;
         moe_left = mats.moe_cnt[e] - ct * WD_COLS;
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(512) void gemm_lw_kernel(const gemm_mats mats, int 
         // ks > 1 (scaled-operand body, few-token batches of one matrix): K is cut into ks parts, every (tile, part) is a
         // work-group that writes its partial tile to P[part][token][row]; lw_ksplit_reduce sums the parts in order
         const int n_tiles = n_rb * n_ct, n_wg = n_tiles * ks;
-        const int id = blockIdx.x, q8 = n_wg >> 3, r8 = n_wg & 7, xcd = id & 7;
+        const int id = bid, q8 = n_wg >> 3, r8 = n_wg & 7, xcd = id & 7;
         const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3);
         kpart = L / n_tiles;
         tile_of(L - kpart * n_tiles, n_rb, n_ct, rb, ct);
@@ -640,6 +642,43 @@ __global__ __launch_bounds__(512) void gemm_lw_kernel(const gemm_mats mats, int 
     if (blockIdx.x == 0 && lane == 0 && wave == 0)
         g_lw_stamps[125] = __builtin_amdgcn_s_memtime() - clk0 - g_lw_stamps[126];
 #endif
+}
+
+template <int TYPE, bool MOE, bool FAST, int NT>
+__global__ __launch_bounds__(512) void gemm_lw_kernel(const gemm_mats mats, int nb, const _Float16 *__restrict__ Xh,
+                                                      const float *__restrict__ d8T, const _Float16 *__restrict__ Xm, long n,
+                                                      long n_pad, int n_rb, int n_ct, int ks, float *__restrict__ P) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds[LW_STAGES * LW_SLOT + 16];
+    gemm_lw_body<TYPE, MOE, FAST, NT>(mats, nb, Xh, d8T, Xm, n, n_pad, n_rb, n_ct, ks, P, (int)blockIdx.x, (int)gridDim.x, lds);
+}
+
+// Two weight types in ONE launch of the 128 x 128 scaled-operand body (attn_q/k in Q4_K or Q5_K with attn_v in Q6_K at
+// prefill, cf. gemv_kq_dual_kernel): work-groups [0, grid_a) run type A's body over mats_a, the rest type B's over mats_b.
+template <int TA, int TB>
+__global__ __launch_bounds__(512) void gemm_lw_dual_kernel(const gemm_mats mats_a, const gemm_mats mats_b, int nb,
+                                                           const _Float16 *__restrict__ Xh, const float *__restrict__ d8T,
+                                                           const _Float16 *__restrict__ Xm, long n, long n_pad, int n_rb_a,
+                                                           int n_rb_b, int n_ct, int grid_a) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds[LW_STAGES * LW_SLOT + 16];
+    if ((int)blockIdx.x < grid_a)
+        gemm_lw_body<TA, false, true, 4>(mats_a, nb, Xh, d8T, Xm, n, n_pad, n_rb_a, n_ct, 1, nullptr, (int)blockIdx.x, grid_a, lds);
+    else
+        gemm_lw_body<TB, false, true, 4>(mats_b, nb, Xh, d8T, Xm, n, n_pad, n_rb_b, n_ct, 1, nullptr, (int)blockIdx.x - grid_a,
+                                         (int)gridDim.x - grid_a, lds);
+}
+
+hipError_t lfamd_lw_dual_go(int type_a, const gemm_mats &ma, int n_rb_a, int type_b, const gemm_mats &mb, int n_rb_b, int nb,
+                            const void *Xh, const void *d8T, const void *Xm, long n, long n_pad, int n_ct, hipStream_t s) {
+    if (type_b != LFAMD_TYPE_Q6_K || (type_a != LFAMD_TYPE_Q4_K && type_a != LFAMD_TYPE_Q5_K))
+        return hipErrorInvalidValue;
+    const unsigned grid_a = (unsigned)(n_rb_a * n_ct), grid_b = (unsigned)(n_rb_b * n_ct);
+    if (type_a == LFAMD_TYPE_Q4_K)
+        gemm_lw_dual_kernel<LFAMD_TYPE_Q4_K, LFAMD_TYPE_Q6_K><<<grid_a + grid_b, 512, 0, s>>>(
+            ma, mb, nb, (const _Float16 *)Xh, (const float *)d8T, (const _Float16 *)Xm, n, n_pad, n_rb_a, n_rb_b, n_ct, (int)grid_a);
+    else
+        gemm_lw_dual_kernel<LFAMD_TYPE_Q5_K, LFAMD_TYPE_Q6_K><<<grid_a + grid_b, 512, 0, s>>>(
+            ma, mb, nb, (const _Float16 *)Xh, (const float *)d8T, (const _Float16 *)Xm, n, n_pad, n_rb_a, n_rb_b, n_ct, (int)grid_a);
+    return hipGetLastError();
 }
 
 hipError_t lfamd_lw_go(int Atype, const gemm_mats &mats, int nb, const void *Xh, const void *d8T, const void *Xm, long n, long n_pad,

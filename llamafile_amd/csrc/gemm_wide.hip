@@ -222,6 +222,46 @@ extern "C" hipError_t lfamd_launch_gemm_wide_multi(int Atype, int count, const v
     return wide_go(Atype, mode, (float *)P, P_bytes, mats, nb, Xh, d8T, Xm, n, n_pad, n_rb, n_ct, ks, nbs, (unsigned)n_wg, 0, s);
 }
 
+hipError_t lfamd_lw_dual_go(int type_a, const gemm_mats &ma, int n_rb_a, int type_b, const gemm_mats &mb, int n_rb_b, int nb,
+                            const void *Xh, const void *d8T, const void *Xm, long n, long n_pad, int n_ct, hipStream_t s);
+
+static int fill_gemm_mats(gemm_mats &mats, int count, const void *const *A, const long *m, float *const *C, const long *ldc) {
+    int n_rb = 0;
+    mats.count = 0;
+    mats.moe_cnt = mats.moe_poff = mats.moe_slot_row = nullptr, mats.expert_bytes = 0, mats.moe_ct_max = 0;
+    for (int j = 0; j < count; j++) {
+        if (m[j] <= 0)
+            continue;
+        const int i = mats.count++;
+        mats.A[i] = (const uint8_t *)A[j], mats.C[i] = C[j], mats.m[i] = m[j], mats.ldc[i] = ldc[j];
+        n_rb += (int)((m[j] + 127) / 128);
+        mats.rb_end[i] = n_rb;
+    }
+    for (int i = mats.count; i < GEMM_MAX_MATS; i++)
+        mats.A[i] = mats.A[0], mats.C[i] = mats.C[0], mats.m[i] = 0, mats.ldc[i] = 0, mats.rb_end[i] = n_rb;
+    return n_rb;
+}
+
+// Scaled staged activations, two groups of matrices of two K-quant types (type_b = Q6_K, type_a = Q4_K | Q5_K): ONE launch of
+// the 128 x 128 loader-wave body when the combined grid fills more than half the chip.  Returns hipErrorNotSupported when
+// that launch does not apply (the caller then launches the groups one after the other).
+extern "C" hipError_t lfamd_launch_gemm_wide_dual(int type_a, int count_a, const void *const *A_a, const long *m_a,
+                                                  float *const *C_a, const long *ldc_a, int type_b, int count_b,
+                                                  const void *const *A_b, const long *m_b, float *const *C_b, const long *ldc_b,
+                                                  long k, const void *Xh, const void *d8T, const void *Xm, long n, long n_pad,
+                                                  int mode, hipStream_t s) {
+    static const bool off = getenv("LFAMD_GEMM_NO_DUAL") != nullptr;
+    if (off || !(mode & 2) || !lw_allowed(mode) || type_b != LFAMD_TYPE_Q6_K || (type_a != LFAMD_TYPE_Q4_K && type_a != LFAMD_TYPE_Q5_K) ||
+        count_a <= 0 || count_b <= 0 || count_a > GEMM_MAX_MATS || count_b > GEMM_MAX_MATS || n_pad % WD_COLS)
+        return hipErrorNotSupported;
+    gemm_mats ma, mb;
+    const int n_rb_a = fill_gemm_mats(ma, count_a, A_a, m_a, C_a, ldc_a), n_rb_b = fill_gemm_mats(mb, count_b, A_b, m_b, C_b, ldc_b);
+    const int n_ct = (int)(n_pad / WD_COLS), tiles = (n_rb_a + n_rb_b) * n_ct;
+    if (ma.count == 0 || mb.count == 0 || tiles < LW_FULL_GRID || tiles > 256)
+        return hipErrorNotSupported; // (beyond one round the separate launches with their tail handling do as well)
+    return lfamd_lw_dual_go(type_a, ma, n_rb_a, type_b, mb, n_rb_b, (int)(k / 256), Xh, d8T, Xm, n, n_pad, n_ct, s);
+}
+
 extern "C" hipError_t lfamd_launch_gemm_wide(int Atype, const void *A, long m, long k, const void *Xh, const void *d8T,
                                              const void *Xm, long n, long n_pad, float *C, long ldc, int mode, void *P, size_t P_bytes,
                                              hipStream_t s) {

@@ -103,3 +103,21 @@ def test_gate_up_fused_launch_tail_split(gpu):
         sep = gpu.mul_mat(W, xb, T.F32)
         assert torch.isfinite(f).all()
         assert torch.equal(_bits(f), _bits(sep))
+
+
+@pytest.mark.parametrize("ta", [T.Q4_K, T.Q5_K], ids=lambda t: T.NAMES[t])
+def test_qkv_two_types_one_gemm_launch(gpu, ta):
+    """attn_q / attn_k (Q4_K or Q5_K) and attn_v (Q6_K) at 512 tokens through lfamd_mul_mat_multi_types: 192 tiles of
+    128 x 128 in ONE launch whose work-groups run their own type's body.  Bit-identical to the three separate calls (which run
+    128 x 64 tiles), in the caller's node order q, v, k as well."""
+    from llamafile_amd import synth
+    k = 4096
+    specs = [(ta, 4096), (T.Q6_K, 1024), (ta, 1024)]
+    Ws = [gpu.upload_weights(t, synth.random_weights_torch(t, m, k, 41 + i), m, k) for i, (t, m) in enumerate(specs)]
+    x = torch.from_numpy(synth.random_activations(PREFILL, k, 42)).cuda()
+    xb = x.view(torch.uint8).view(PREFILL, k * 4)
+    fused = gpu.mul_mat_multi(Ws, xb, T.F32, n=PREFILL)
+    for W, f in zip(Ws, fused):
+        sep = gpu.mul_mat(W, xb, T.F32)
+        assert torch.isfinite(f).all()
+        assert torch.equal(_bits(f), _bits(sep)), (T.NAMES[W.type], W.rows)
