@@ -199,14 +199,18 @@ def cpu_baseline(layers, prefill, decode):
         B1 = synth.quantize_activations(vdt, synth.random_activations(1, spec.k, 2))
         Bp = synth.quantize_activations(vdt, synth.random_activations(n_pf, spec.k, 3))
         ora.sgemm_openmp(spec.type, A, vdt, B1, spec.m, 1, spec.k, nth)  # warm
-        t0 = time.perf_counter()
-        reps = 3
-        for _ in range(reps):
+        best = float("inf")  # best of 5 / 2: the box's host cores are shared, single timings scatter by several x
+        for _ in range(5):
+            t0 = time.perf_counter()
             ora.sgemm_openmp(spec.type, A, vdt, B1, spec.m, 1, spec.k, nth)
-        t_dec += (time.perf_counter() - t0) / reps
-        t0 = time.perf_counter()
-        ora.sgemm_openmp(spec.type, A, vdt, Bp, spec.m, n_pf, spec.k, nth)
-        t_pf += time.perf_counter() - t0
+            best = min(best, time.perf_counter() - t0)
+        t_dec += best
+        best = float("inf")
+        for _ in range(2):
+            t0 = time.perf_counter()
+            ora.sgemm_openmp(spec.type, A, vdt, Bp, spec.m, n_pf, spec.k, nth)
+            best = min(best, time.perf_counter() - t0)
+        t_pf += best
     # extrapolate: output.weight costs (its weight bytes / one layer's weight bytes) of a layer pass
     lb = sum(LS.weight_bytes(s) for s in layer)
     scale = n_layers + LS.weight_bytes(layers[-1][0]) / lb
@@ -215,7 +219,7 @@ def cpu_baseline(layers, prefill, decode):
     total = t_prefill + decode * t_decode_token
     return {
         "value": round((prefill + decode) / total, 3), "unit": "tokens/s", "cores": nth, "kind": "port",
-        "sample": f"layer 0 (7 mat-muls) at n=1 x3 and n={n_pf} x1 on {nth} threads, extrapolated x{scale:.2f} layers "
+        "sample": f"layer 0 (7 mat-muls) at n=1 (best of 5) and n={n_pf} (best of 2) on {nth} threads, extrapolated x{scale:.2f} layers "
                   f"and x{prefill / n_pf:.0f} prefill columns; decode {1.0 / t_decode_token:.2f} tok/s, "
                   f"prefill {prefill / t_prefill:.2f} tok/s",
     }
