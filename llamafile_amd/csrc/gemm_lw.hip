@@ -444,15 +444,35 @@ __device__ __forceinline__ void gemm_lw_body(const gemm_mats &mats, int nb, cons
 #pragma unroll
             for (int t8 = 0; t8 < 8; t8++) {
                 // counted waits: lgkmcnt(N) = every LDS read older than the N youngest has returned
+                constexpr int M = (half == 0 && !Q6) ? NT : 0; // mins fragments of this super-block, read in K-step 2 of its first half
                 if (t8 < 6) {
                     if (t8 == 4)
                         asm volatile("ds_read_b32 %0, %1" : "=v"(fl) : "v"(flag_addr));
                     read_frags(F[(t8 + 2) & 3], slot, t8 + 2);
-                    if (t8 < 4)
+                    if (t8 == 2 && M > 0) { // the mins operand came with this (first-half) stage: landed
+                        if constexpr (NT == 4)
+                            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\t"
+                                         "ds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072"
+                                         : "=&v"(fxm[0]), "=&v"(fxm[1]), "=&v"(fxm[NT - 2]), "=&v"(fxm[NT - 1])
+                                         : "v"(slot + xm_off));
+                        else
+                            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024"
+                                         : "=&v"(fxm[0]), "=&v"(fxm[1])
+                                         : "v"(slot + xm_off));
+                    }
+                    // younger than this K-step's fragments: the next two fragment groups, the mins fragments from K-step 2
+                    // until they are older than the group waited for (K-step 5), the counter read of K-step 4
+                    if (t8 < 2)
                         asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * NT));
+                    else if (t8 < 4)
+                        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * NT + M));
+                    else if (t8 == 4)
+                        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * NT + M + 1));
                     else
-                        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * NT + 1)); // the counter read sits between K-step 5's and 6's fragments
+                        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * NT + 1));
                     pin(F[t8 & 3]);
+                    if (t8 == 5 && M > 0)
+                        pin(fxm); // (older than K-step 5's fragments)
                 } else if (t8 == 6) {
                     asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(fl) : "n"(NT));
                     pin(F[2]);
@@ -460,17 +480,6 @@ __device__ __forceinline__ void gemm_lw_body(const gemm_mats &mats, int nb, cons
                     while (fv < need) { // the next stage has not landed yet (rare: the loaders run a stage ahead)
                         asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(fl) : "v"(flag_addr) : "memory");
                         fv = __builtin_amdgcn_readfirstlane(fl);
-                    }
-                    if constexpr (half == 1 && !Q6) {
-                        if constexpr (NT == 4)
-                            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\t"
-                                         "ds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072"
-                                         : "=&v"(fxm[0]), "=&v"(fxm[1]), "=&v"(fxm[NT - 2]), "=&v"(fxm[NT - 1])
-                                         : "v"(slot_first + xm_off));
-                        else
-                            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024"
-                                         : "=&v"(fxm[0]), "=&v"(fxm[1])
-                                         : "v"(slot_first + xm_off));
                     }
                     read_frags(F[0], slot_next, 0);
                 } else {
@@ -482,6 +491,18 @@ __device__ __forceinline__ void gemm_lw_body(const gemm_mats &mats, int nb, cons
                     asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(qa), "+v"(qb), "+v"(hd), "+v"(hq), "+v"(dw6) : "n"(NT));
                     pin(F[3]);
                 }
+                if (t8 == 3 && M > 0) { // mins weights of this super-block: f16(-dmin * m_j), zero in the upper K half
+                    uint32_t sc03, sc47, mn03, mn47;
+                    q4k_scales_bytes(hd.y, hd.z, hd.w, sc03, sc47, mn03, mn47);
+                    const float ndmin = -h2f((uint16_t)(hd.x >> 16));
+#pragma unroll
+                    for (int p = 0; p < 4; p++) {
+                        const uint32_t mw = p < 2 ? mn03 : mn47;
+                        const float m0 = (float)((mw >> (16 * (p & 1))) & 0xff), m1 = (float)((mw >> (16 * (p & 1) + 8)) & 0xff);
+                        half2_t v = {(_Float16)(h ? 0.0f : m0 * ndmin), (_Float16)(h ? 0.0f : m1 * ndmin)};
+                        wm.p[p] = v;
+                    }
+                }
                 half8_t wn = wf;
                 if (t8 + 1 < 8)
                     wn = dq(halfc, t8 + 1);
@@ -492,19 +513,6 @@ __device__ __forceinline__ void gemm_lw_body(const gemm_mats &mats, int nb, cons
                     // header words — are dead, so the next stage's are read STRAIGHT INTO THE SAME REGISTERS.  (A second set
                     // of variables copied over after the wait let hipcc place that register copy BEFORE the wait: an
                     // intermittent read of data still in flight.)  The mins weights are taken from the header first.
-                    if constexpr (half == 1 && !Q6) {
-                        uint32_t sc03, sc47, mn03, mn47;
-                        q4k_scales_bytes(hd.y, hd.z, hd.w, sc03, sc47, mn03, mn47);
-                        const float ndmin = -h2f((uint16_t)(hd.x >> 16));
-#pragma unroll
-                        for (int p = 0; p < 4; p++) {
-                            const uint32_t mw = p < 2 ? mn03 : mn47;
-                            const float m0 = (float)((mw >> (16 * (p & 1))) & 0xff), m1 = (float)((mw >> (16 * (p & 1) + 8)) & 0xff);
-                            half2_t v = {(_Float16)(h ? 0.0f : m0 * ndmin), (_Float16)(h ? 0.0f : m1 * ndmin)};
-                            wm.p[p] = v;
-                        }
-                        asm volatile("" : "+v"(wm.v)); // (computed before the header registers are reloaded)
-                    }
                     asm volatile("" : "+v"(wn)); // K-step 7's fragment is complete before its source registers are reloaded
                     asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024" : "=&v"(qa), "=&v"(qb) : "v"(slot_next + wq_off));
                     if constexpr (Q6) // the upper code bits come with every half
@@ -525,13 +533,13 @@ __device__ __forceinline__ void gemm_lw_body(const gemm_mats &mats, int nb, cons
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
                     __builtin_amdgcn_sched_group_barrier(0x002, 12 / NT, 0); // its share of the next fragment's VALU
                 }
-                wf = wn;
-            }
-            if constexpr (half == 1 && !Q6) { // mins of the super-block (its fragments were covered by K-step 7's wait)
-                pin(fxm);
+                if (t8 == 5 && M > 0) { // the mins: NT more MFMAs among the first half's, straight into the accumulators
 #pragma unroll
-                for (int nt = 0; nt < NT; nt++)
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wm.v, fxm[nt], acc[nt], 0, 0, 0);
+                    for (int nt = 0; nt < NT; nt++)
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wm.v, fxm[nt], acc[nt], 0, 0, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
+                }
+                wf = wn;
             }
         };
 
