@@ -370,11 +370,11 @@ def main():
     # FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM), stored
     # under profiles/ — counters cannot be read from inside this process
     traffic, traffic_src = None, None
-    tfile = os.path.join(ROOT, "profiles", "r01_v11_pmc_traffic.json")
+    tfile = os.path.join(ROOT, "profiles", "r01_v12_pmc_traffic.json")
     if dom_type == T.Q4_K and world == 1 and os.path.exists(tfile):
         try:
             traffic = json.load(open(tfile))["gemv_q4k"]["hbm_bytes_per_launch"]
-            traffic_src = "profiles/r01_v11_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2)"
+            traffic_src = "profiles/r01_v12_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2)"
         except (KeyError, ValueError):
             pass
     kname = "gemv_kq_kernel<q4k_traits, 1, F32, 16, {1,2}>" if dom_type == T.Q4_K else "gemv_q80_kernel<1, F32, mode>"
