@@ -464,8 +464,15 @@ extern "C" __attribute__((weak)) int lfamd_debug_gemv_stamps(unsigned long long 
             g_gemv_stamps[((blockIdx.x ? 1 : 0) * 16 + wave) * 16 + stamp_n++] = __builtin_amdgcn_s_memrealtime(); \
         __builtin_amdgcn_sched_barrier(0);                                                                       \
     } while (0)
+// (diagnostic only: drain the loads first, so the stamp is the arrival time of the item's weights)
+#define GSTAMP_ARRIVAL()                                                                                         \
+    do {                                                                                                         \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                         \
+        GSTAMP();                                                                                                \
+    } while (0)
 #else
 #define GSTAMP()
+#define GSTAMP_ARRIVAL()
 #endif
 
 // The body of a GEMV work-group: work-group `bid` of `gdim` over the half-tiles of `mats` (the plain kernel passes its
@@ -617,11 +624,350 @@ __device__ __forceinline__ void gemv_kq_body(const gemv_mats &mats, int nb, cons
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Decode body (ONE activation row).  What the stamps of the body above showed on 4096 x 4096 (tools/gemv_stamps.py):
+// 0.8 us of dependent kernel-argument rounds before the first load, then 1.4 us in which four of the sixteen waves
+// fetch the row as 64-byte-strided pieces (32 cache-line lookups per wave instruction — more L1 work than the whole
+// weight stream of the CU), quantise it for everybody and release a work-group barrier.  Here instead:
+//   * every kernel argument is read with static indices (one round of s_load, selects instead of indexed reads);
+//   * wave w quantises exactly the super-blocks it will consume (w, w + NW, ...): one coalesced float4 per lane and
+//     block (1 KiB per wave instruction), the block maximum by DPP, the LDS image written with one dword per lane;
+//     a wave only ever reads image blocks it wrote itself (LDS operations of one wave execute in order), so there
+//     is NO work-group barrier before the dots;
+//   * the activation loads go out first and the weight loads right behind them (vmcnt retires in order);
+//   * no integer division: tiles and chunks are walked with cursors.
+// Arithmetic (per-lane dot, wave reduction, fixed-order sum over the waves) is the body above's: results are
+// bit-identical.
+
+template <int CTRL>
+__device__ static inline uint32_t dpp_u32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+}
+template <int CTRL>
+__device__ static inline float dpp_f32(float v) {
+    return __builtin_bit_cast(float, dpp_u32<CTRL>(__builtin_bit_cast(uint32_t, v)));
+}
+#define DPP_XOR1 0xB1        // quad_perm [1,0,3,2]
+#define DPP_XOR2 0x4E        // quad_perm [2,3,0,1]
+#define DPP_HALF_MIRROR 0x141
+#define DPP_MIRROR 0x140
+#define DPP_ROW_SHL4 0x104   // lane i reads lane i + 4 of its row of 16
+
+__device__ static inline float readlane_f32(float v, int l) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+
+// lane l holds codes y = (c[4l] .. c[4l+3]) of one 256-code block: write the code image, the group sums and the pair
+// sums (layout: XBLK above).  Two lanes form an 8-code group.
+__device__ static inline void put_codes_wave(uint8_t *dst, uint32_t y, int lane) {
+    const int hf = lane & 1, grp = lane >> 1;
+    const uint32_t other = dpp_u32<DPP_XOR1>(y);
+    const uint32_t lo = hf ? other : y, hi = hf ? y : other;
+    const uint32_t word = hf ? __builtin_amdgcn_perm(hi, lo, 0x07030602) : __builtin_amdgcn_perm(hi, lo, 0x05010400);
+    const int pos = (grp & 16) | ((grp & 1) << 3) | ((grp & 8) >> 1) | ((grp >> 1) & 3);
+    *(uint32_t *)(dst + 8 * pos + 4 * hf) = word;
+    const int s4 = sdot4(y, 0x01010101u, 0);
+    const int hs = s4 + (int)dpp_u32<DPP_XOR1>((uint32_t)s4);
+    if (hf == 0)
+        *(int16_t *)(dst + XBLK_HB + 2 * pos) = (int16_t)hs;
+    const int hs2 = hs + (int)dpp_u32<DPP_ROW_SHL4>((uint32_t)hs); // group grp + 2 = lane + 4 (the pair's odd K-step)
+    if ((lane & 5) == 0)
+        put_pair(dst, grp, hs2);
+}
+
+// quantize_row_q8_K on one block held as a float4 per lane (element 4 lane + e): first index of the largest |x| gives
+// the sign of iscale = -128/max; codes nearest_int (half-even) clamped at 127; d = 1/iscale.
+__device__ static inline void stage_f32_q8k_wave(uint8_t *dst, const float4 v, int lane) {
+    const float a0 = fabsf(v.x), a1 = fabsf(v.y), a2 = fabsf(v.z), a3 = fabsf(v.w);
+    float am = fmaxf(fmaxf(a0, a1), fmaxf(a2, a3));
+    am = fmaxf(am, dpp_f32<DPP_XOR1>(am));
+    am = fmaxf(am, dpp_f32<DPP_XOR2>(am));
+    am = fmaxf(am, dpp_f32<DPP_HALF_MIRROR>(am));
+    am = fmaxf(am, dpp_f32<DPP_MIRROR>(am));
+    const float amax = fmaxf(fmaxf(readlane_f32(am, 0), readlane_f32(am, 16)), fmaxf(readlane_f32(am, 32), readlane_f32(am, 48)));
+    // (branch-free: an all-zero block goes through the same arithmetic with a harmless divisor and is zeroed by selects)
+    const bool m0 = a0 == amax, m1 = a1 == amax, m2 = a2 == amax, m3 = a3 == amax;
+    const unsigned long long ball = __builtin_amdgcn_ballot_w64(m0 || m1 || m2 || m3);
+    const float cand = m0 ? v.x : (m1 ? v.y : (m2 ? v.z : v.w));
+    const int first = ball ? __builtin_ctzll(ball) : 0;
+    const bool nz = amax != 0.0f;
+    const float val = nz ? readlane_f32(cand, first) : 1.0f;
+    const float iscale = -128.0f / val;
+    int q0 = (int)rintf(iscale * v.x), q1 = (int)rintf(iscale * v.y), q2 = (int)rintf(iscale * v.z), q3 = (int)rintf(iscale * v.w);
+    q0 = q0 > 127 ? 127 : q0, q1 = q1 > 127 ? 127 : q1, q2 = q2 > 127 ? 127 : q2, q3 = q3 > 127 ? 127 : q3;
+    uint32_t y = (uint32_t)(q0 & 0xff) | ((uint32_t)(q1 & 0xff) << 8) | ((uint32_t)(q2 & 0xff) << 16) | ((uint32_t)(q3 & 0xff) << 24);
+    y = nz ? y : 0u;
+    const float d = nz ? 1.0f / iscale : 0.0f;
+    put_codes_wave(dst, y, lane);
+    if (lane == 0)
+        *(float *)(dst + XBLK_D) = d;
+}
+
+// quantize_row_q8_0 on eight 32-blocks held as a float4 per lane (8 lanes per block): d = amax/127 (stored as f16),
+// q = roundf(x / d).
+__device__ static inline void stage_f32_q80_wave(uint8_t *dst, const float4 v, int lane) {
+    float am = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+    am = fmaxf(am, dpp_f32<DPP_XOR1>(am));
+    am = fmaxf(am, dpp_f32<DPP_XOR2>(am));
+    am = fmaxf(am, dpp_f32<DPP_HALF_MIRROR>(am));
+    const float d = am / 127.0f;
+    const float id = d != 0.0f ? 1.0f / d : 0.0f;
+    const int q0 = (int)roundf(v.x * id), q1 = (int)roundf(v.y * id), q2 = (int)roundf(v.z * id), q3 = (int)roundf(v.w * id);
+    const uint32_t y = (uint32_t)(q0 & 0xff) | ((uint32_t)(q1 & 0xff) << 8) | ((uint32_t)(q2 & 0xff) << 16) | ((uint32_t)(q3 & 0xff) << 24);
+    put_codes_wave(dst, y, lane);
+    if ((lane & 7) == 0)
+        *(float *)(dst + XBLK_D + 4 * (lane >> 3)) = h2f(f2h_bits(d));
+}
+
+// one block of already-quantised activations, staged by one wave (lanes 0..31: one 8-code group each)
+template <int ACT>
+__device__ static inline void stage_quantised_wave(uint8_t *dst, const uint8_t *row, int b, int lane) {
+    if (lane < 32) {
+        const int grp = lane;
+        uint32_t y0, y1;
+        if constexpr (ACT == LFAMD_TYPE_Q8_K) {
+            const uint8_t *y = row + (size_t)b * 292;
+            const uint32_t *src = (const uint32_t *)(y + 36 + 8 * grp);
+            y0 = src[0], y1 = src[1];
+            if (grp == 0)
+                *(float *)(dst + XBLK_D) = *(const float *)y;
+        } else {
+            const uint8_t *blk = row + (size_t)(b * 8 + (grp >> 2)) * 34;
+            const uint16_t *src = (const uint16_t *)(blk + 2 + 8 * (grp & 3));
+            y0 = (uint32_t)src[0] | ((uint32_t)src[1] << 16), y1 = (uint32_t)src[2] | ((uint32_t)src[3] << 16);
+            if ((grp & 3) == 0)
+                *(float *)(dst + XBLK_D + 4 * (grp >> 2)) = h2f(*(const uint16_t *)blk);
+        }
+        const int hs = put_group(dst, grp, y0, y1);
+        const int other = (int)dpp_u32<DPP_XOR2>((uint32_t)hs); // group grp ^ 2
+        if ((grp & 2) == 0)
+            put_pair(dst, grp, hs + other);
+    }
+}
+
+// the matrices of a launch as SSA values: every kernel argument is fetched in ONE round of scalar loads at the top of
+// the kernel (the empty asm pins each value in SGPRs there: left alone, hipcc turns a select of two kernel arguments
+// into a load from a selected ADDRESS — a second, dependent round trip of ~0.4 us before the first weight load and
+// another one before the stores)
+struct kq_tab {
+    const uint8_t *A[GEMV_MAX_MATS];
+    float *C[GEMV_MAX_MATS];
+    long m[GEMV_MAX_MATS], ldc[GEMV_MAX_MATS];
+    int e[GEMV_MAX_MATS];
+    int idx[GEMV_MAX_MATS];
+    int cnt;
+};
+
+__device__ __forceinline__ kq_tab kq_table(const gemv_mats &mats) {
+    kq_tab t;
+#pragma unroll
+    for (int i = 0; i < GEMV_MAX_MATS; i++) {
+        t.A[i] = mats.A[i], t.C[i] = mats.C[i], t.m[i] = mats.m[i], t.ldc[i] = mats.ldc[i], t.e[i] = mats.ht_end[i];
+        t.idx[i] = mats.id_idx[i];
+        asm volatile("" : "+s"(t.A[i]), "+s"(t.C[i]), "+s"(t.m[i]), "+s"(t.ldc[i]), "+s"(t.e[i]), "+s"(t.idx[i]));
+    }
+    t.cnt = mats.count;
+    asm volatile("" : "+s"(t.cnt));
+    return t;
+}
+
+struct kq_sel {
+    const uint8_t *A;
+    float *C;
+    long m, ldc;
+    int ht; // half-tile inside the matrix
+    int idx; // id_idx of the matrix (IDS)
+};
+
+__device__ __forceinline__ kq_sel kq_pick(const kq_tab t, int ht) {
+    const bool s1 = t.cnt > 1 && ht >= t.e[0], s2 = t.cnt > 2 && ht >= t.e[1], s3 = t.cnt > 3 && ht >= t.e[2];
+    kq_sel r;
+    r.A = s3 ? t.A[3] : (s2 ? t.A[2] : (s1 ? t.A[1] : t.A[0]));
+    r.C = s3 ? t.C[3] : (s2 ? t.C[2] : (s1 ? t.C[1] : t.C[0]));
+    r.m = s3 ? t.m[3] : (s2 ? t.m[2] : (s1 ? t.m[1] : t.m[0]));
+    r.ldc = s3 ? t.ldc[3] : (s2 ? t.ldc[2] : (s1 ? t.ldc[1] : t.ldc[0]));
+    r.idx = s3 ? t.idx[3] : (s2 ? t.idx[2] : (s1 ? t.idx[1] : t.idx[0]));
+    r.ht = ht - (s3 ? t.e[2] : (s2 ? t.e[1] : (s1 ? t.e[0] : 0)));
+    return r;
+}
+
+struct kq_cursor {
+    int ht, chunk;
+};
+
+// loads are issued UNCONDITIONALLY through bounds-checked descriptors (zero records = nothing to fetch), see above
+template <typename TR, int NW, int GEMV_CH, bool IDS>
+__device__ __forceinline__ void kq_issue(typename TR::chunk &ch, const gemv_mats &mats, const kq_tab tab, const kq_cursor c, const int n_ht,
+                                         const uint32_t rt_bytes, const int wave, const int i16, const int h, const int gsel) {
+    const kq_sel p = kq_pick(tab, c.ht);
+    const uint8_t *A = p.A;
+    bool have = c.ht < n_ht;
+    if constexpr (IDS) { // expert picked on the device: no routing-table read-back, graph-capturable
+        const int ex = mats.ids[p.idx];
+        const bool ok = ex >= 0 && ex < mats.experts;
+        A += (size_t)(ok ? ex : 0) * mats.expert_bytes;
+        have = have && ok;
+    }
+    const int hh = p.ht & 1;
+    const lfamd_rsrc r = make_rsrc(A + (size_t)(p.ht >> 1) * rt_bytes, have ? rt_bytes : 0u);
+    const int slot = h * 32 + hh * 16 + i16, hrow = hh * 16 + i16;
+#pragma unroll
+    for (int s = 0; s < GEMV_CH; s++) {
+        const int b = wave + NW * (c.chunk * GEMV_CH + s); // b >= nb lands past the descriptor: zeros
+        TR::load(ch, s, r, (uint32_t)b * TR::TILE, gsel, slot, hrow);
+    }
+}
+
+template <typename TR, int BT, int NW, int GEMV_CH, bool IDS>
+__device__ __forceinline__ void gemv_kq_body1(const gemv_mats &mats, int nb, const uint8_t *__restrict__ B,
+                                              size_t b_row_bytes, long col0, int n_ht, const int bid, int gdim,
+                                              uint8_t *lds) {
+    asm volatile("" : "+s"(nb), "+s"(B), "+s"(b_row_bytes), "+s"(col0), "+s"(n_ht), "+s"(gdim)); // (one s_load round)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int i16 = lane & 15, h = (lane >> 4) & 1, gsel = lane >> 5;
+    float *red = (float *)(lds + (size_t)nb * XBLK); // [2][NW][16]
+#if GEMV_DIAG
+    int stamp_n = 0;
+#endif
+    GSTAMP();
+    const kq_tab tab = kq_table(mats);
+
+    const int sb_per_wave = (nb + NW - 1) / NW;
+    const int cpt = (sb_per_wave + GEMV_CH - 1) / GEMV_CH; // chunks per tile
+    const uint32_t rt_bytes = (uint32_t)nb * TR::TILE;
+
+    float acc = 0.0f;
+    int par = 0;
+    typename TR::chunk bufA, bufB;
+    kq_cursor ci{bid, 0}, cc{bid, 0};
+#define KQ_ADVANCE(c)                                                                                                  \
+    do {                                                                                                               \
+        if (++(c).chunk == cpt)                                                                                        \
+            (c).chunk = 0, (c).ht += gdim;                                                                             \
+    } while (0)
+#define KQ_ISSUE(buf)                                                                                                  \
+    do {                                                                                                               \
+        kq_issue<TR, NW, GEMV_CH, IDS>(buf, mats, tab, ci, n_ht, rt_bytes, wave, i16, h, gsel);                            \
+        KQ_ADVANCE(ci);                                                                                                \
+    } while (0)
+    // one chunk of this wave against its own image blocks; at the end of a tile: 4 lanes per row (h, gsel), then the
+    // waves through LDS in a fixed order
+#define KQ_CONSUME(buf)                                                                                                \
+    do {                                                                                                               \
+        GSTAMP_ARRIVAL();                                                                                              \
+        _Pragma("unroll") for (int s = 0; s < GEMV_CH; s++) {                                                          \
+            const int b = wave + NW * (cc.chunk * GEMV_CH + s);                                                        \
+            /* a super-block beyond the row was loaded as zeros; its image slot belongs to nobody: discard */          \
+            const float t = TR::dot(buf, s, lds + (size_t)(b < nb ? b : 0) * XBLK, gsel, h);                           \
+            acc += b < nb ? t : 0.0f;                                                                                  \
+        }                                                                                                              \
+        if (cc.chunk == cpt - 1) {                                                                                     \
+            float *rb = red + par * (NW * 16);                                                                         \
+            par ^= 1;                                                                                                  \
+            float v = acc;                                                                                             \
+            v += __shfl_xor(v, 16, 64);                                                                                \
+            v += __shfl_xor(v, 32, 64);                                                                                \
+            if (lane < 16)                                                                                             \
+                rb[wave * 16 + lane] = v;                                                                              \
+            acc = 0.0f;                                                                                                \
+            GSTAMP();                                                                                                  \
+            __syncthreads();                                                                                           \
+            GSTAMP();                                                                                                  \
+            if (threadIdx.x < 16) {                                                                                    \
+                const int i = threadIdx.x;                                                                             \
+                float t = 0.0f;                                                                                        \
+                _Pragma("unroll") for (int w = 0; w < NW; w++) t += rb[w * 16 + i];                                    \
+                const kq_sel p = kq_pick(tab, cc.ht);                                                               \
+                const long row = (long)(p.ht >> 1) * 32 + (p.ht & 1) * 16 + i;                                         \
+                bool ok = true;                                                                                        \
+                if constexpr (IDS) { /* an out-of-range expert id leaves its result row untouched */                   \
+                    const int ex = mats.ids[p.idx];                                                                    \
+                    ok = ex >= 0 && ex < mats.experts;                                                                 \
+                }                                                                                                      \
+                if (row < p.m && ok)                                                                                   \
+                    ((__attribute__((address_space(1))) float *)p.C)[col0 * p.ldc + row] = t; /* (not FLAT) */                                                                     \
+            }                                                                                                          \
+        }                                                                                                              \
+        KQ_ADVANCE(cc);                                                                                                \
+    } while (0)
+
+    const uint8_t *xrow = B + col0 * b_row_bytes;
+    if constexpr (BT == LFAMD_TYPE_F32) {
+        // this wave's blocks, JX at a time; the first JX go out BEFORE the first weight chunk (in-order vmcnt).  The
+        // staging is straight-line code (a block past the row is loaded as zeros through the descriptor and staged
+        // into the wave's dummy slot): with a branch per block hipcc merges its vmcnt bookkeeping at the joins and
+        // makes the second block wait for the WEIGHTS.
+        constexpr int JX = GEMV_CH == 1 ? 1 : 4; // (GEMV_CH == 1 is launched for nb <= NW only)
+        const lfamd_rsrc rx = make_rsrc(xrow, (uint32_t)nb * 1024u);
+        uint8_t *dummy = (uint8_t *)(red + 2 * NW * 16) + (size_t)wave * XBLK;
+        uint4 xv[JX];
+#pragma unroll
+        for (int j = 0; j < JX; j++)
+            xv[j] = buf_ld16(rx, (uint32_t)(wave + NW * j) * 1024u + lane * 16);
+        __builtin_amdgcn_sched_barrier(0); // (the scheduler would put the weight loads first)
+        KQ_ISSUE(bufA);
+        __builtin_amdgcn_sched_barrier(0);
+        GSTAMP();
+#define KQ_STAGE_GROUP(j0)                                                                                             \
+    _Pragma("unroll") for (int j = 0; j < JX; j++) {                                                                   \
+        const int b = wave + NW * ((j0) + j);                                                                          \
+        uint8_t *dst = b < nb ? lds + (size_t)b * XBLK : dummy;                                                        \
+        const float4 f = make_float4(__builtin_bit_cast(float, xv[j].x), __builtin_bit_cast(float, xv[j].y),           \
+                                     __builtin_bit_cast(float, xv[j].z), __builtin_bit_cast(float, xv[j].w));           \
+        if constexpr (TR::ACT == LFAMD_TYPE_Q8_K)                                                                      \
+            stage_f32_q8k_wave(dst, f, lane);                                                                          \
+        else                                                                                                           \
+            stage_f32_q80_wave(dst, f, lane);                                                                          \
+    }
+        KQ_STAGE_GROUP(0) // (peeled: inside the loop below the back edge would hide the weight loads from the wait counts)
+        for (int j0 = JX; j0 < sb_per_wave; j0 += JX) { // rows longer than JX * NW super-blocks
+#pragma unroll
+            for (int j = 0; j < JX; j++)
+                xv[j] = buf_ld16(rx, (uint32_t)(wave + NW * (j0 + j)) * 1024u + lane * 16);
+            KQ_STAGE_GROUP(j0)
+        }
+#undef KQ_STAGE_GROUP
+    } else {
+        KQ_ISSUE(bufA);
+        GSTAMP();
+        for (int b = wave; b < nb; b += NW)
+            stage_quantised_wave<TR::ACT>(lds + (size_t)b * XBLK, xrow, b, lane);
+    }
+    // the image blocks this wave reads are the ones it has just written: program order in the LDS queue is enough;
+    // only the compiler must not move the reads above the (differently typed) writes
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    GSTAMP();
+
+    // pairs of items without a branch inside (a conditionally skipped consume leaves its buffer's loads "pending" at
+    // the loop header for hipcc's wait-count pass, which then drains vmcnt(0) before every issue), then the odd one
+    for (;;) {
+        kq_cursor cn = cc;
+        KQ_ADVANCE(cn);
+        if (cn.ht >= n_ht)
+            break;
+        KQ_ISSUE(bufB);
+        KQ_CONSUME(bufA);
+        GSTAMP();
+        KQ_ISSUE(bufA);
+        KQ_CONSUME(bufB);
+    }
+    if (cc.ht < n_ht)
+        KQ_CONSUME(bufA);
+#undef KQ_ADVANCE
+#undef KQ_ISSUE
+#undef KQ_CONSUME
+}
+
 template <typename TR, int NC, int BT, int NW, int GEMV_CH, bool IDS = false>
 __global__ __launch_bounds__(NW * 64) void gemv_kq_kernel(const gemv_mats mats, int nb, const uint8_t *__restrict__ B,
-                                                          size_t b_row_bytes, long col0, int n_ht) {
+                                                          size_t b_row_bytes, long col0, int n_ht, int gdim) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    gemv_kq_body<TR, NC, BT, NW, GEMV_CH, IDS>(mats, nb, B, b_row_bytes, col0, n_ht, (int)blockIdx.x, (int)gridDim.x, lds);
+    if constexpr (NC == 1)
+        gemv_kq_body1<TR, BT, NW, GEMV_CH, IDS>(mats, nb, B, b_row_bytes, col0, n_ht, (int)blockIdx.x, gdim, lds);
+    else
+        gemv_kq_body<TR, NC, BT, NW, GEMV_CH, IDS>(mats, nb, B, b_row_bytes, col0, n_ht, (int)blockIdx.x, gdim, lds);
 }
 
 // Two weight types in ONE decode launch (sibling mat-muls on the same activations whose types differ: attn_q/k in Q4_K
@@ -630,14 +976,13 @@ __global__ __launch_bounds__(NW * 64) void gemv_kq_kernel(const gemv_mats mats, 
 template <typename TRA, typename TRB, int BT, int NW, int GEMV_CH>
 __global__ __launch_bounds__(NW * 64) void gemv_kq_dual_kernel(const gemv_mats mats_a, const gemv_mats mats_b, int nb,
                                                                const uint8_t *__restrict__ B, size_t b_row_bytes, int n_ht_a,
-                                                               int n_ht_b, int grid_a) {
+                                                               int n_ht_b, int grid_a, int grid_b) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     static_assert(TRA::ACT == TRB::ACT, "both types must share the activation image");
     if ((int)blockIdx.x < grid_a)
-        gemv_kq_body<TRA, 1, BT, NW, GEMV_CH, false>(mats_a, nb, B, b_row_bytes, 0, n_ht_a, (int)blockIdx.x, grid_a, lds);
+        gemv_kq_body1<TRA, BT, NW, GEMV_CH, false>(mats_a, nb, B, b_row_bytes, 0, n_ht_a, (int)blockIdx.x, grid_a, lds);
     else
-        gemv_kq_body<TRB, 1, BT, NW, GEMV_CH, false>(mats_b, nb, B, b_row_bytes, 0, n_ht_b, (int)blockIdx.x - grid_a,
-                                                     (int)gridDim.x - grid_a, lds);
+        gemv_kq_body1<TRB, BT, NW, GEMV_CH, false>(mats_b, nb, B, b_row_bytes, 0, n_ht_b, (int)blockIdx.x - grid_a, grid_b, lds);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -919,7 +1264,7 @@ static int num_cus() {
 template <typename TR, int NC, int BT, int NW, int CH>
 static hipError_t launch_kq(const gemv_mats &mats, int n_ht, long k, const void *B, size_t brb, long col0, hipStream_t s) {
     int nb = (int)(k / 256);
-    size_t smem = (size_t)NC * nb * XBLK + 2 * NW * NC * 16 * sizeof(float);
+    size_t smem = (size_t)NC * nb * XBLK + 2 * NW * NC * 16 * sizeof(float) + (NC == 1 ? (size_t)NW * XBLK : 0); // (+ dummy slots)
     auto kernel = gemv_kq_kernel<TR, NC, BT, NW, CH>;
     if (smem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -930,7 +1275,7 @@ static hipError_t launch_kq(const gemv_mats &mats, int n_ht, long k, const void 
     const int max_wg = (16 / NW) * num_cus();
     const int per_wg = (n_ht + max_wg - 1) / max_wg;
     const int grid = (n_ht + per_wg - 1) / per_wg;
-    kernel<<<grid, NW * 64, smem, s>>>(mats, nb, (const uint8_t *)B, brb, col0, n_ht);
+    kernel<<<grid, NW * 64, smem, s>>>(mats, nb, (const uint8_t *)B, brb, col0, n_ht, grid);
     return hipGetLastError();
 }
 
@@ -939,14 +1284,14 @@ static hipError_t launch_kq_dual(const gemv_mats &ma, int n_ht_a, const gemv_mat
                                  size_t brb, hipStream_t s) {
     const int nb = (int)(k / 256);
     constexpr int NW = 16;
-    const size_t smem = (size_t)nb * XBLK + 2 * NW * 16 * sizeof(float);
+    const size_t smem = (size_t)nb * XBLK + 2 * NW * 16 * sizeof(float) + (size_t)NW * XBLK; // (+ dummy slots)
     // one persistent grid shared in proportion to the half-tile counts (cf. launch_kq)
     const int max_wg = num_cus();
     const int per_wg = (n_ht_a + n_ht_b + max_wg - 1) / max_wg;
     const int grid_a = (n_ht_a + per_wg - 1) / per_wg, grid_b = (n_ht_b + per_wg - 1) / per_wg;
     if (nb <= 16) {
         auto kernel = gemv_kq_dual_kernel<TRA, TRB, BT, NW, 1>;
-        kernel<<<grid_a + grid_b, NW * 64, smem, s>>>(ma, mb, nb, (const uint8_t *)B, brb, n_ht_a, n_ht_b, grid_a);
+        kernel<<<grid_a + grid_b, NW * 64, smem, s>>>(ma, mb, nb, (const uint8_t *)B, brb, n_ht_a, n_ht_b, grid_a, grid_b);
     } else {
         auto kernel = gemv_kq_dual_kernel<TRA, TRB, BT, NW, 2>;
         if (smem > 64 * 1024) {
@@ -954,7 +1299,7 @@ static hipError_t launch_kq_dual(const gemv_mats &ma, int n_ht_a, const gemv_mat
             if (e != hipSuccess)
                 return e;
         }
-        kernel<<<grid_a + grid_b, NW * 64, smem, s>>>(ma, mb, nb, (const uint8_t *)B, brb, n_ht_a, n_ht_b, grid_a);
+        kernel<<<grid_a + grid_b, NW * 64, smem, s>>>(ma, mb, nb, (const uint8_t *)B, brb, n_ht_a, n_ht_b, grid_a, grid_b);
     }
     return hipGetLastError();
 }
@@ -963,13 +1308,13 @@ template <typename TR, int BT>
 static hipError_t launch_kq_ids(const gemv_mats &mats, int n_ht, long k, const void *B, size_t brb, hipStream_t s) {
     const int nb = (int)(k / 256);
     constexpr int NW = 16;
-    const size_t smem = (size_t)nb * XBLK + 2 * NW * 16 * sizeof(float);
+    const size_t smem = (size_t)nb * XBLK + 2 * NW * 16 * sizeof(float) + (size_t)NW * XBLK; // (+ dummy slots)
     const int max_wg = num_cus();
     const int per_wg = (n_ht + max_wg - 1) / max_wg;
     const int grid = (n_ht + per_wg - 1) / per_wg;
     if (nb <= 16) {
         auto kernel = gemv_kq_kernel<TR, 1, BT, NW, 1, true>;
-        kernel<<<grid, NW * 64, smem, s>>>(mats, nb, (const uint8_t *)B, brb, 0, n_ht);
+        kernel<<<grid, NW * 64, smem, s>>>(mats, nb, (const uint8_t *)B, brb, 0, n_ht, grid);
     } else {
         auto kernel = gemv_kq_kernel<TR, 1, BT, NW, 2, true>;
         if (smem > 64 * 1024) {
@@ -977,7 +1322,7 @@ static hipError_t launch_kq_ids(const gemv_mats &mats, int n_ht, long k, const v
             if (e != hipSuccess)
                 return e;
         }
-        kernel<<<grid, NW * 64, smem, s>>>(mats, nb, (const uint8_t *)B, brb, 0, n_ht);
+        kernel<<<grid, NW * 64, smem, s>>>(mats, nb, (const uint8_t *)B, brb, 0, n_ht, grid);
     }
     return hipGetLastError();
 }

@@ -16,7 +16,7 @@ print("rc", _hip.lib().lfamd_debug_gemv_stamps(buf))
 a = np.array(buf[:512], dtype=np.int64).reshape(2, 16, 16)
 t0 = a[a > 0].min()
 for g in (0, 1):
-    for w in (0, 1):
+    for w in range(16):
         t = a[g, w]
         t = t[t > 0]
         print("wg", g, "wave", w, "ticks(10ns) since first stamp:", (t - t0).tolist())
