@@ -720,6 +720,81 @@ __device__ static inline void stage_f32_q80_wave(uint8_t *dst, const float4 v, i
         *(float *)(dst + XBLK_D + 4 * (lane >> 3)) = h2f(f2h_bits(d));
 }
 
+// Two blocks per pass (deep rows: a wave owns several super-blocks): lane l holds the EIGHT values 8 (l & 31) + e of
+// block (l >> 5) — one whole 8-code group — so the fixed part of the quantiser (DPP maximum, the two IEEE divisions, the
+// image addressing) is paid once per two blocks: ~70 VALU per block instead of ~120.  `dst` is this lane's block image.
+__device__ static inline void stage_f32_q8k_wave2(uint8_t *dst, const float4 va, const float4 vb, int lane) {
+    const float v[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
+    float a[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++)
+        a[e] = fabsf(v[e]);
+    float am = fmaxf(fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])), fmaxf(fmaxf(a[4], a[5]), fmaxf(a[6], a[7])));
+    am = fmaxf(am, dpp_f32<DPP_XOR1>(am));
+    am = fmaxf(am, dpp_f32<DPP_XOR2>(am));
+    am = fmaxf(am, dpp_f32<DPP_HALF_MIRROR>(am));
+    am = fmaxf(am, dpp_f32<DPP_MIRROR>(am));
+    const bool hi = lane >= 32;
+    const float amax_lo = fmaxf(readlane_f32(am, 0), readlane_f32(am, 16)), amax_hi = fmaxf(readlane_f32(am, 32), readlane_f32(am, 48));
+    const float amax = hi ? amax_hi : amax_lo;
+    bool any = false;
+    float cand = v[7];
+#pragma unroll
+    for (int e = 7; e >= 0; e--) { // the FIRST element that reaches the maximum wins
+        const bool me = a[e] == amax;
+        cand = me ? v[e] : cand;
+        any = any || me;
+    }
+    const unsigned long long ball = __builtin_amdgcn_ballot_w64(any);
+    const uint32_t blo = (uint32_t)ball, bhi = (uint32_t)(ball >> 32);
+    const int first_lo = blo ? __builtin_ctz(blo) : 0, first_hi = 32 + (bhi ? __builtin_ctz(bhi) : 0);
+    const float val_lo = readlane_f32(cand, first_lo), val_hi = readlane_f32(cand, first_hi);
+    const bool nz = amax != 0.0f;
+    const float val = nz ? (hi ? val_hi : val_lo) : 1.0f;
+    const float iscale = -128.0f / val;
+    uint32_t y[2] = {0, 0};
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        int q = (int)rintf(iscale * v[e]);
+        q = q > 127 ? 127 : q;
+        y[e >> 2] |= (uint32_t)(q & 0xff) << (8 * (e & 3));
+    }
+    const uint32_t y0 = nz ? y[0] : 0u, y1 = nz ? y[1] : 0u;
+    const float d = nz ? 1.0f / iscale : 0.0f;
+    const int grp = lane & 31;
+    const int hs = put_group(dst, grp, y0, y1);
+    const int other = (int)dpp_u32<DPP_XOR2>((uint32_t)hs); // group grp ^ 2
+    if ((grp & 2) == 0)
+        put_pair(dst, grp, hs + other);
+    if (grp == 0)
+        *(float *)(dst + XBLK_D) = d;
+}
+
+__device__ static inline void stage_f32_q80_wave2(uint8_t *dst, const float4 va, const float4 vb, int lane) {
+    const float v[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
+    float am = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 8; e++)
+        am = fmaxf(am, fabsf(v[e]));
+    am = fmaxf(am, dpp_f32<DPP_XOR1>(am)); // four lanes per 32-block
+    am = fmaxf(am, dpp_f32<DPP_XOR2>(am));
+    const float d = am / 127.0f;
+    const float id = d != 0.0f ? 1.0f / d : 0.0f;
+    uint32_t y[2] = {0, 0};
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const int q = (int)roundf(v[e] * id);
+        y[e >> 2] |= (uint32_t)(q & 0xff) << (8 * (e & 3));
+    }
+    const int grp = lane & 31;
+    const int hs = put_group(dst, grp, y[0], y[1]);
+    const int other = (int)dpp_u32<DPP_XOR2>((uint32_t)hs);
+    if ((grp & 2) == 0)
+        put_pair(dst, grp, hs + other);
+    if ((grp & 3) == 0)
+        *(float *)(dst + XBLK_D + 4 * (grp >> 2)) = h2f(f2h_bits(d));
+}
+
 // one block of already-quantised activations, staged by one wave (lanes 0..31: one 8-code group each)
 template <int ACT>
 __device__ static inline void stage_quantised_wave(uint8_t *dst, const uint8_t *row, int b, int lane) {
@@ -832,6 +907,26 @@ __device__ __forceinline__ void gemv_kq_body1(const gemv_mats &mats, int nb, con
     int stamp_n = 0;
 #endif
     GSTAMP();
+    // the activation loads need only the leading (preloaded) kernel arguments: they go out before the rest of the
+    // arguments has even arrived (-amdgpu-kernarg-preload-count, Makefile)
+    // GEMV_CH == 1 (launched for nb <= NW only): ONE block per wave, a float4 per lane.  Deeper rows: FOUR blocks per
+    // group as two passes of two (lane l: eight values of block (l >> 5) of the pass), four loads per lane.
+    constexpr int JX = GEMV_CH == 1 ? 1 : 4;
+    const uint8_t *xrow = B + col0 * b_row_bytes;
+    const lfamd_rsrc rx = make_rsrc(xrow, (uint32_t)nb * 1024u);
+    uint4 xv[JX];
+    auto x_off = [&](int j0, int j) __attribute__((always_inline)) { // byte offset of load j of the group starting at block slot j0
+        if constexpr (JX == 1)
+            return (uint32_t)(wave + NW * j0) * 1024u + (uint32_t)lane * 16u;
+        else
+            return (uint32_t)(wave + NW * (j0 + 2 * (j >> 1) + (lane >> 5))) * 1024u + (uint32_t)(lane & 31) * 32u + 16u * (j & 1);
+    };
+    if constexpr (BT == LFAMD_TYPE_F32) {
+#pragma unroll
+        for (int j = 0; j < JX; j++)
+            xv[j] = buf_ld16(rx, x_off(0, j));
+        __builtin_amdgcn_sched_barrier(0); // (the scheduler would put the weight loads first)
+    }
     const kq_tab tab = kq_table(mats);
 
     const int sb_per_wave = (nb + NW - 1) / NW;
@@ -847,6 +942,9 @@ __device__ __forceinline__ void gemv_kq_body1(const gemv_mats &mats, int nb, con
         if (++(c).chunk == cpt)                                                                                        \
             (c).chunk = 0, (c).ht += gdim;                                                                             \
     } while (0)
+    // (measured and rejected: s_setprio 3 around the load issue, and a work-group barrier between every wave's activation
+    // loads and the first weight loads — the youngest waves of a k = 14336 row still issue 1.5-3 us after the oldest, the
+    // CU's vector-memory queue is simply full — both 2-7 % slower on every decode shape)
 #define KQ_ISSUE(buf)                                                                                                  \
     do {                                                                                                               \
         kq_issue<TR, NW, GEMV_CH, IDS>(buf, mats, tab, ci, n_ht, rt_bytes, wave, i16, h, gsel);                            \
@@ -893,41 +991,43 @@ __device__ __forceinline__ void gemv_kq_body1(const gemv_mats &mats, int nb, con
         KQ_ADVANCE(cc);                                                                                                \
     } while (0)
 
-    const uint8_t *xrow = B + col0 * b_row_bytes;
     if constexpr (BT == LFAMD_TYPE_F32) {
-        // this wave's blocks, JX at a time; the first JX go out BEFORE the first weight chunk (in-order vmcnt).  The
+        // this wave's blocks, JX at a time; the first JX went out BEFORE the first weight chunk (in-order vmcnt).  The
         // staging is straight-line code (a block past the row is loaded as zeros through the descriptor and staged
         // into the wave's dummy slot): with a branch per block hipcc merges its vmcnt bookkeeping at the joins and
         // makes the second block wait for the WEIGHTS.
-        constexpr int JX = GEMV_CH == 1 ? 1 : 4; // (GEMV_CH == 1 is launched for nb <= NW only)
-        const lfamd_rsrc rx = make_rsrc(xrow, (uint32_t)nb * 1024u);
         uint8_t *dummy = (uint8_t *)(red + 2 * NW * 16) + (size_t)wave * XBLK;
-        uint4 xv[JX];
-#pragma unroll
-        for (int j = 0; j < JX; j++)
-            xv[j] = buf_ld16(rx, (uint32_t)(wave + NW * j) * 1024u + lane * 16);
-        __builtin_amdgcn_sched_barrier(0); // (the scheduler would put the weight loads first)
         KQ_ISSUE(bufA);
         __builtin_amdgcn_sched_barrier(0);
         GSTAMP();
+#define KQ_F4(u) make_float4(__builtin_bit_cast(float, (u).x), __builtin_bit_cast(float, (u).y), __builtin_bit_cast(float, (u).z), \
+                           __builtin_bit_cast(float, (u).w))
 #define KQ_STAGE_GROUP(j0)                                                                                             \
-    _Pragma("unroll") for (int j = 0; j < JX; j++) {                                                                   \
-        const int b = wave + NW * ((j0) + j);                                                                          \
+    if constexpr (JX == 1) {                                                                                           \
+        const int b = wave + NW * (j0);                                                                                \
         uint8_t *dst = b < nb ? lds + (size_t)b * XBLK : dummy;                                                        \
-        const float4 f = make_float4(__builtin_bit_cast(float, xv[j].x), __builtin_bit_cast(float, xv[j].y),           \
-                                     __builtin_bit_cast(float, xv[j].z), __builtin_bit_cast(float, xv[j].w));           \
         if constexpr (TR::ACT == LFAMD_TYPE_Q8_K)                                                                      \
-            stage_f32_q8k_wave(dst, f, lane);                                                                          \
+            stage_f32_q8k_wave(dst, KQ_F4(xv[0]), lane);                                                               \
         else                                                                                                           \
-            stage_f32_q80_wave(dst, f, lane);                                                                          \
+            stage_f32_q80_wave(dst, KQ_F4(xv[0]), lane);                                                               \
+    } else {                                                                                                           \
+        _Pragma("unroll") for (int ps = 0; ps < 2; ps++) {                                                             \
+            const int b = wave + NW * ((j0) + 2 * ps + (lane >> 5));                                                   \
+            uint8_t *dst = b < nb ? lds + (size_t)b * XBLK : dummy;                                                    \
+            if constexpr (TR::ACT == LFAMD_TYPE_Q8_K)                                                                  \
+                stage_f32_q8k_wave2(dst, KQ_F4(xv[2 * ps]), KQ_F4(xv[2 * ps + 1]), lane);                              \
+            else                                                                                                       \
+                stage_f32_q80_wave2(dst, KQ_F4(xv[2 * ps]), KQ_F4(xv[2 * ps + 1]), lane);                              \
+        }                                                                                                              \
     }
         KQ_STAGE_GROUP(0) // (peeled: inside the loop below the back edge would hide the weight loads from the wait counts)
         for (int j0 = JX; j0 < sb_per_wave; j0 += JX) { // rows longer than JX * NW super-blocks
 #pragma unroll
             for (int j = 0; j < JX; j++)
-                xv[j] = buf_ld16(rx, (uint32_t)(wave + NW * (j0 + j)) * 1024u + lane * 16);
+                xv[j] = buf_ld16(rx, x_off(j0, j));
             KQ_STAGE_GROUP(j0)
         }
+#undef KQ_F4
 #undef KQ_STAGE_GROUP
     } else {
         KQ_ISSUE(bufA);
@@ -961,8 +1061,8 @@ __device__ __forceinline__ void gemv_kq_body1(const gemv_mats &mats, int nb, con
 }
 
 template <typename TR, int NC, int BT, int NW, int GEMV_CH, bool IDS = false>
-__global__ __launch_bounds__(NW * 64) void gemv_kq_kernel(const gemv_mats mats, int nb, const uint8_t *__restrict__ B,
-                                                          size_t b_row_bytes, long col0, int n_ht, int gdim) {
+__global__ __launch_bounds__(NW * 64) void gemv_kq_kernel(const uint8_t *__restrict__ B, size_t b_row_bytes, long col0, int nb,
+                                                          int n_ht, int gdim, const gemv_mats mats) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     if constexpr (NC == 1)
         gemv_kq_body1<TR, BT, NW, GEMV_CH, IDS>(mats, nb, B, b_row_bytes, col0, n_ht, (int)blockIdx.x, gdim, lds);
@@ -974,9 +1074,9 @@ __global__ __launch_bounds__(NW * 64) void gemv_kq_kernel(const gemv_mats mats, 
 // with attn_v in Q6_K in a Q4_K_M file): work-groups [0, grid_a) run type A's body over mats_a, the rest type B's over
 // mats_b.  A work-group is of one type, so it stages the activations once, in the (shared) Q8_K image.
 template <typename TRA, typename TRB, int BT, int NW, int GEMV_CH>
-__global__ __launch_bounds__(NW * 64) void gemv_kq_dual_kernel(const gemv_mats mats_a, const gemv_mats mats_b, int nb,
-                                                               const uint8_t *__restrict__ B, size_t b_row_bytes, int n_ht_a,
-                                                               int n_ht_b, int grid_a, int grid_b) {
+__global__ __launch_bounds__(NW * 64) void gemv_kq_dual_kernel(const uint8_t *__restrict__ B, size_t b_row_bytes, int nb, int n_ht_a,
+                                                               int n_ht_b, int grid_a, int grid_b, const gemv_mats mats_a,
+                                                               const gemv_mats mats_b) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     static_assert(TRA::ACT == TRB::ACT, "both types must share the activation image");
     if ((int)blockIdx.x < grid_a)
@@ -1275,7 +1375,7 @@ static hipError_t launch_kq(const gemv_mats &mats, int n_ht, long k, const void 
     const int max_wg = (16 / NW) * num_cus();
     const int per_wg = (n_ht + max_wg - 1) / max_wg;
     const int grid = (n_ht + per_wg - 1) / per_wg;
-    kernel<<<grid, NW * 64, smem, s>>>(mats, nb, (const uint8_t *)B, brb, col0, n_ht, grid);
+    kernel<<<grid, NW * 64, smem, s>>>((const uint8_t *)B, brb, col0, nb, n_ht, grid, mats);
     return hipGetLastError();
 }
 
@@ -1291,7 +1391,7 @@ static hipError_t launch_kq_dual(const gemv_mats &ma, int n_ht_a, const gemv_mat
     const int grid_a = (n_ht_a + per_wg - 1) / per_wg, grid_b = (n_ht_b + per_wg - 1) / per_wg;
     if (nb <= 16) {
         auto kernel = gemv_kq_dual_kernel<TRA, TRB, BT, NW, 1>;
-        kernel<<<grid_a + grid_b, NW * 64, smem, s>>>(ma, mb, nb, (const uint8_t *)B, brb, n_ht_a, n_ht_b, grid_a, grid_b);
+        kernel<<<grid_a + grid_b, NW * 64, smem, s>>>((const uint8_t *)B, brb, nb, n_ht_a, n_ht_b, grid_a, grid_b, ma, mb);
     } else {
         auto kernel = gemv_kq_dual_kernel<TRA, TRB, BT, NW, 2>;
         if (smem > 64 * 1024) {
@@ -1299,7 +1399,7 @@ static hipError_t launch_kq_dual(const gemv_mats &ma, int n_ht_a, const gemv_mat
             if (e != hipSuccess)
                 return e;
         }
-        kernel<<<grid_a + grid_b, NW * 64, smem, s>>>(ma, mb, nb, (const uint8_t *)B, brb, n_ht_a, n_ht_b, grid_a, grid_b);
+        kernel<<<grid_a + grid_b, NW * 64, smem, s>>>((const uint8_t *)B, brb, nb, n_ht_a, n_ht_b, grid_a, grid_b, ma, mb);
     }
     return hipGetLastError();
 }
@@ -1314,7 +1414,7 @@ static hipError_t launch_kq_ids(const gemv_mats &mats, int n_ht, long k, const v
     const int grid = (n_ht + per_wg - 1) / per_wg;
     if (nb <= 16) {
         auto kernel = gemv_kq_kernel<TR, 1, BT, NW, 1, true>;
-        kernel<<<grid, NW * 64, smem, s>>>(mats, nb, (const uint8_t *)B, brb, 0, n_ht, grid);
+        kernel<<<grid, NW * 64, smem, s>>>((const uint8_t *)B, brb, 0, nb, n_ht, grid, mats);
     } else {
         auto kernel = gemv_kq_kernel<TR, 1, BT, NW, 2, true>;
         if (smem > 64 * 1024) {
@@ -1322,7 +1422,7 @@ static hipError_t launch_kq_ids(const gemv_mats &mats, int n_ht, long k, const v
             if (e != hipSuccess)
                 return e;
         }
-        kernel<<<grid, NW * 64, smem, s>>>(mats, nb, (const uint8_t *)B, brb, 0, n_ht, grid);
+        kernel<<<grid, NW * 64, smem, s>>>((const uint8_t *)B, brb, 0, nb, n_ht, grid, mats);
     }
     return hipGetLastError();
 }
