@@ -894,6 +894,19 @@ __device__ __forceinline__ void kq_issue(typename TR::chunk &ch, const gemv_mats
     }
 }
 
+// v[l] + v[l ^ 16] + v[l ^ 32] + v[l ^ 48] in every lane, with gfx950's row / half-wave swaps (two VALU instead of two
+// ds_bpermute round trips through the LDS at the end of every tile)
+__device__ static inline float kq_sum_rows(float v) {
+    // (inline asm: with __builtin_amdgcn_permlane16_swap hipcc 7.2 loses the instruction's SECOND result in this kernel
+    // and adds the first to itself — tests/test_golden.py caught it; s_nop 1 = the VALU-write -> permlane-read hazard)
+    float x = v, y = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y)); // rows (r0,r0,r2,r2) and (r1,r1,r3,r3)
+    float p = x + y, q;
+    q = p;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(p), "+v"(q)); // halves (lo,lo) and (hi,hi)
+    return p + q;
+}
+
 template <typename TR, int BT, int NW, int GEMV_CH, bool IDS>
 __device__ __forceinline__ void gemv_kq_body1(const gemv_mats &mats, int nb, const uint8_t *__restrict__ B,
                                               size_t b_row_bytes, long col0, int n_ht, const int bid, int gdim,
@@ -964,9 +977,7 @@ __device__ __forceinline__ void gemv_kq_body1(const gemv_mats &mats, int nb, con
         if (cc.chunk == cpt - 1) {                                                                                     \
             float *rb = red + par * (NW * 16);                                                                         \
             par ^= 1;                                                                                                  \
-            float v = acc;                                                                                             \
-            v += __shfl_xor(v, 16, 64);                                                                                \
-            v += __shfl_xor(v, 32, 64);                                                                                \
+            float v = kq_sum_rows(acc); /* lanes i16, i16 + 16, i16 + 32, i16 + 48 */                                  \
             if (lane < 16)                                                                                             \
                 rb[wave * 16 + lane] = v;                                                                              \
             acc = 0.0f;                                                                                                \
