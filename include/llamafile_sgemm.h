@@ -97,8 +97,16 @@ bool iqk_mul_mat_moe(long Nx, long Ny, long ne00, int ne11, int typeA, const voi
 /* 1 if the HIP module is loaded and a gfx950 device initialised, else 0 (+ reason via _error). */
 int llamafile_sgemm_amd_available(void);
 const char *llamafile_sgemm_amd_error(void);
-/* Weights are cached on the device keyed by host address + shape + a content fingerprint
- * (mmap'd GGUF tensors are immutable).  Drop one tensor / everything (e.g. before unmapping a model). */
+/* Device copies of weights are kept across calls ONLY for host bytes that cannot change behind the library's back:
+ * ranges registered here (the host promises the bytes stay put until it unregisters them), and addresses inside a
+ * mapping without write permission (an mmap'd GGUF file; read from /proc/self/maps).  Any other `A` — ggml also enters
+ * llamafile_sgemm with the mutable KV cache as `A` for KQ / KQV — is uploaded and packed on every call.  The kept
+ * copies are evicted least-recently-used within a byte budget (default 200 GiB). */
+void llamafile_sgemm_amd_register_weights(const void *p, size_t bytes);
+void llamafile_sgemm_amd_unregister_weights(const void *p); /* also frees the device copies inside the range */
+void llamafile_sgemm_amd_set_cache_budget(size_t bytes);
+size_t llamafile_sgemm_amd_cached_bytes(void);
+/* Drop one tensor's device copy / everything (e.g. before unmapping a model). */
 void llamafile_sgemm_amd_forget(const void *A);
 void llamafile_sgemm_amd_reset(void);
 /* FLAG_precise of the reference (--precise): Kahan summation in the Q8_0/Q4_0 kernels. */

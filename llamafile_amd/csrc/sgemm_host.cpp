@@ -18,6 +18,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+#include <list>
+#include <map>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -56,10 +59,19 @@ struct CachedWeights {
     int type;
     long rows, cols;
     size_t row_bytes;
-    uint64_t fingerprint;
     void *d_packed;
     size_t bytes;
     bool exact_only = false; // block scales outside the scaled-operand GEMM's range (lfamd_scaled_gemm_ok)
+    std::list<const void *>::iterator lru;
+};
+
+// Which host bytes may be kept on the device across calls?  Only bytes the host cannot change behind our back:
+//   * ranges the host registered with llamafile_sgemm_amd_register_weights (it promises they stay put), and
+//   * addresses inside a mapping WITHOUT write permission (an mmap'd GGUF: llama.cpp maps model files PROT_READ),
+//     read from /proc/self/maps (re-read when an address is not covered by the snapshot).
+// Everything else — ggml calls llamafile_sgemm with the KV cache as `A` for KQ / KQV — is uploaded on every call.
+struct Range {
+    uintptr_t lo, hi;
 };
 
 struct State {
@@ -69,9 +81,16 @@ struct State {
     HipApi api;
     std::mutex mu;
     std::unordered_map<const void *, CachedWeights> cache;
-    DevBuf raw, b, c, ws, plan, x;
+    std::list<const void *> lru; // front = most recently used
+    size_t cache_bytes = 0, cache_budget = (size_t)200 << 30;
+    std::map<uintptr_t, uintptr_t> registered; // lo -> hi
+    std::vector<Range> ro_maps;                // read-only mappings of /proc/self/maps, sorted
+    DevBuf raw, b, c, ws, plan, x, a_scratch;
+    std::vector<uint8_t> h_gather; // host staging reused across MoE calls
+    std::vector<float> h_out;
+    std::vector<int32_t> h_plan;
     unsigned flags = 0;
-    int precise = 0;
+    std::atomic<int> precise{0};
 } g;
 
 template <typename T>
@@ -165,56 +184,122 @@ bool reserve(DevBuf &b, size_t bytes) {
     return true;
 }
 
-uint64_t fingerprint(const void *p, size_t bytes) { // cheap: 3 x 64 bytes, FNV-1a
-    uint64_t h = 1469598103934665603ull;
-    const uint8_t *b = (const uint8_t *)p;
-    auto mix = [&](size_t off, size_t len) {
-        for (size_t i = 0; i < len && off + i < bytes; i++) {
-            h ^= b[off + i];
-            h *= 1099511628211ull;
-        }
-    };
-    mix(0, 64);
-    mix(bytes / 2, 64);
-    mix(bytes > 64 ? bytes - 64 : 0, 64);
-    return h ^ bytes;
-}
-
 unsigned flags_now() {
-    return g.flags | (g.precise ? LFAMD_FLAG_PRECISE : 0u);
+    return g.flags | (g.precise.load(std::memory_order_relaxed) ? LFAMD_FLAG_PRECISE : 0u);
 }
 
-// device copy of a weight matrix (rows x cols of `type`, host rows `row_bytes` apart), cached
-const CachedWeights *get_weights(int type, const void *A, long rows, long cols, size_t row_bytes) {
-    size_t total = (size_t)rows * row_bytes;
-    uint64_t fp = fingerprint(A, total);
+void read_ro_maps() {
+    g.ro_maps.clear();
+    FILE *f = fopen("/proc/self/maps", "r");
+    if (!f)
+        return;
+    char line[512];
+    while (fgets(line, sizeof line, f)) {
+        unsigned long lo, hi;
+        char perms[8];
+        if (sscanf(line, "%lx-%lx %7s", &lo, &hi, perms) == 3 && perms[0] == 'r' && perms[1] == '-')
+            g.ro_maps.push_back({(uintptr_t)lo, (uintptr_t)hi});
+    }
+    fclose(f);
+}
+
+bool in_ro_map(uintptr_t lo, uintptr_t hi) {
+    // adjacent read-only mappings of one file may be split: walk them
+    uintptr_t at = lo;
+    for (const Range &r : g.ro_maps) {
+        if (r.lo <= at && at < r.hi) {
+            at = r.hi;
+            if (at >= hi)
+                return true;
+        }
+    }
+    return false;
+}
+
+// may [p, p + bytes) be cached on the device?  Caller holds g.mu.
+bool is_immutable(const void *p, size_t bytes) {
+    const uintptr_t lo = (uintptr_t)p, hi = lo + bytes;
+    auto it = g.registered.upper_bound(lo);
+    if (it != g.registered.begin()) {
+        --it;
+        if (it->first <= lo && hi <= it->second)
+            return true;
+    }
+    if (in_ro_map(lo, hi))
+        return true;
+    read_ro_maps(); // the snapshot may predate the mapping
+    return in_ro_map(lo, hi);
+}
+
+void drop(std::unordered_map<const void *, CachedWeights>::iterator it) {
+    g.api.free_(it->second.d_packed);
+    g.cache_bytes -= it->second.bytes;
+    g.lru.erase(it->second.lru);
+    g.cache.erase(it);
+}
+
+// upload + pack `rows` x `cols` of `type` from host rows `row_bytes` apart into d_packed
+bool upload_packed(int type, const void *A, long rows, long cols, size_t row_bytes, void *d_packed, bool *exact_only) {
+    const size_t total = (size_t)rows * row_bytes;
+    if (!reserve(g.raw, total) || g.api.h2d(g.raw.p, A, total, nullptr) != LFAMD_OK)
+        return false;
+    if (g.api.pack_weights(type, rows, cols, g.raw.p, row_bytes, d_packed, nullptr) != LFAMD_OK)
+        return false;
+    const int in_range = g.api.scaled_ok(type, rows, cols, d_packed, nullptr); // (synchronises the stream)
+    if (in_range < 0)
+        return false;
+    *exact_only = in_range == 0;
+    return true;
+}
+
+// Device copy of a weight matrix (rows x cols of `type`, host rows `row_bytes` apart).  Immutable host bytes are packed
+// once and kept (LRU within a byte budget, LFAMD_CACHE_BYTES); anything else is packed into a scratch buffer per call.
+struct DevWeights {
+    const void *d_packed;
+    bool exact_only;
+};
+
+bool get_weights(int type, const void *A, long rows, long cols, size_t row_bytes, DevWeights *out) {
+    const size_t total = (size_t)rows * row_bytes;
+    const size_t packed = g.api.packed_size(type, rows, cols);
+    if (!is_immutable(A, total)) {
+        auto stale = g.cache.find(A); // (a range that was unregistered or remapped writable since)
+        if (stale != g.cache.end())
+            drop(stale);
+        bool eo = false;
+        if (!reserve(g.a_scratch, packed) || !upload_packed(type, A, rows, cols, row_bytes, g.a_scratch.p, &eo))
+            return false;
+        *out = {g.a_scratch.p, eo};
+        return true;
+    }
     auto it = g.cache.find(A);
     if (it != g.cache.end()) {
         CachedWeights &w = it->second;
-        if (w.type == type && w.rows == rows && w.cols == cols && w.row_bytes == row_bytes && w.fingerprint == fp)
-            return &w;
-        g.api.free_(w.d_packed);
-        g.cache.erase(it);
+        if (w.type == type && w.rows == rows && w.cols == cols && w.row_bytes == row_bytes) {
+            g.lru.splice(g.lru.begin(), g.lru, w.lru);
+            *out = {w.d_packed, w.exact_only};
+            return true;
+        }
+        drop(it); // same address, another view of it
     }
-    if (!reserve(g.raw, total))
-        return nullptr;
-    if (g.api.h2d(g.raw.p, A, total, nullptr) != LFAMD_OK)
-        return nullptr;
-    CachedWeights w{type, rows, cols, row_bytes, fp, nullptr, g.api.packed_size(type, rows, cols)};
-    if (g.api.malloc_(&w.d_packed, w.bytes) != LFAMD_OK)
-        return nullptr;
-    if (g.api.pack_weights(type, rows, cols, g.raw.p, row_bytes, w.d_packed, nullptr) != LFAMD_OK ||
-        g.api.sync(nullptr) != LFAMD_OK) {
-        g.api.free_(w.d_packed);
-        return nullptr;
+    while (!g.lru.empty() && g.cache_bytes + packed > g.cache_budget)
+        drop(g.cache.find(g.lru.back()));
+    CachedWeights w{type, rows, cols, row_bytes, nullptr, packed};
+    while (g.api.malloc_(&w.d_packed, w.bytes) != LFAMD_OK) { // device full: evict and retry
+        if (g.lru.empty())
+            return false;
+        drop(g.cache.find(g.lru.back()));
     }
-    const int in_range = g.api.scaled_ok(type, rows, cols, w.d_packed, nullptr);
-    if (in_range < 0) {
+    if (!upload_packed(type, A, rows, cols, row_bytes, w.d_packed, &w.exact_only)) {
         g.api.free_(w.d_packed);
-        return nullptr;
+        return false;
     }
-    w.exact_only = in_range == 0;
-    return &(g.cache[A] = w);
+    g.lru.push_front(A);
+    w.lru = g.lru.begin();
+    g.cache_bytes += w.bytes;
+    const CachedWeights &kept = (g.cache[A] = w);
+    *out = {kept.d_packed, kept.exact_only};
+    return true;
 }
 
 bool is_quant(int t) {
@@ -256,8 +341,8 @@ bool run_mul_mat(int Atype, const void *A, long m, long kelems, size_t a_row_byt
                  size_t b_row_bytes, long n, float *C, long ldc) {
     if (m == 0 || n == 0)
         return true;
-    const CachedWeights *w = get_weights(Atype, A, m, kelems, a_row_bytes);
-    if (!w)
+    DevWeights w;
+    if (!get_weights(Atype, A, m, kelems, a_row_bytes, &w))
         return false;
     // C spans (n-1)*ldc + m floats (the last column is not padded to ldc)
     size_t bbytes = (size_t)n * b_row_bytes, cbytes = ((size_t)(n - 1) * (size_t)ldc + (size_t)m) * 4;
@@ -269,8 +354,8 @@ bool run_mul_mat(int Atype, const void *A, long m, long kelems, size_t a_row_byt
     if (ldc != m) // keep the caller's bytes in the gaps of C
         if (g.api.h2d(g.c.p, C, cbytes, nullptr) != LFAMD_OK)
             return false;
-    if (g.api.mul_mat(Atype, w->d_packed, m, kelems, Btype, g.b.p, b_row_bytes, n, (float *)g.c.p, ldc, g.ws.p, g.ws.cap,
-                      flags_now() | (w->exact_only ? LFAMD_FLAG_PRECISE : 0u), nullptr) != LFAMD_OK)
+    if (g.api.mul_mat(Atype, w.d_packed, m, kelems, Btype, g.b.p, b_row_bytes, n, (float *)g.c.p, ldc, g.ws.p, g.ws.cap,
+                      flags_now() | (w.exact_only ? LFAMD_FLAG_PRECISE : 0u), nullptr) != LFAMD_OK)
         return false;
     if (g.api.d2h(C, g.c.p, cbytes, nullptr) != LFAMD_OK)
         return false;
@@ -295,30 +380,59 @@ const char *llamafile_sgemm_amd_error(void) {
 }
 
 void llamafile_sgemm_amd_set_precise(int precise) {
-    g.precise = precise;
+    g.precise.store(precise, std::memory_order_relaxed);
+}
+
+void llamafile_sgemm_amd_register_weights(const void *p, size_t bytes) {
+    if (!p || !bytes)
+        return;
+    std::lock_guard<std::mutex> lk(g.mu);
+    g.registered[(uintptr_t)p] = (uintptr_t)p + bytes;
+}
+
+void llamafile_sgemm_amd_unregister_weights(const void *p) {
+    std::lock_guard<std::mutex> lk(g.mu);
+    auto it = g.registered.find((uintptr_t)p);
+    if (it == g.registered.end())
+        return;
+    const uintptr_t lo = it->first, hi = it->second;
+    g.registered.erase(it);
+    if (!g.ok)
+        return;
+    for (auto c = g.cache.begin(); c != g.cache.end();) { // device copies of tensors inside the range go with it
+        auto next = std::next(c);
+        if ((uintptr_t)c->first >= lo && (uintptr_t)c->first < hi)
+            drop(c);
+        c = next;
+    }
+}
+
+void llamafile_sgemm_amd_set_cache_budget(size_t bytes) {
+    std::lock_guard<std::mutex> lk(g.mu);
+    g.cache_budget = bytes;
+}
+
+size_t llamafile_sgemm_amd_cached_bytes(void) {
+    std::lock_guard<std::mutex> lk(g.mu);
+    return g.cache_bytes;
 }
 
 void llamafile_sgemm_amd_forget(const void *A) {
     if (!available())
         return;
     std::lock_guard<std::mutex> lk(g.mu);
-    for (auto it = g.cache.begin(); it != g.cache.end();) {
-        if (it->first == A) {
-            g.api.free_(it->second.d_packed);
-            it = g.cache.erase(it);
-        } else {
-            ++it;
-        }
-    }
+    auto it = g.cache.find(A);
+    if (it != g.cache.end())
+        drop(it);
 }
 
 void llamafile_sgemm_amd_reset(void) {
     if (!available())
         return;
     std::lock_guard<std::mutex> lk(g.mu);
-    for (auto &kv : g.cache)
-        g.api.free_(kv.second.d_packed);
-    g.cache.clear();
+    while (!g.cache.empty())
+        drop(g.cache.begin());
+    g.ro_maps.clear();
 }
 
 bool llamafile_sgemm(long m, long n, long k, const void *A, long lda, const void *B, long ldb, void *C, long ldc,
@@ -372,12 +486,14 @@ bool iqk_mul_mat_moe(long Nx, long Ny, long ne00, int ne11, int typeA, const voi
     const lfamd_mmid_row_mapping *map = (const lfamd_mmid_row_mapping *)vrow_mapping;
     const size_t brow = lfamd_row_size(bt, ne00);
     // gather the mapped activation rows (DataInfo::src1_row, iqk_mul_mat.inc:84-88)
-    std::vector<uint8_t> bg((size_t)Ny * brow);
+    std::vector<uint8_t> &bg = g.h_gather; // (grow-only staging, reused across calls)
+    bg.resize((size_t)Ny * brow);
     for (long iy = 0; iy < Ny; iy++) {
         size_t src = ((size_t)(map[iy].i1 % ne11) + (size_t)map[iy].i2 * ne11) * brow;
         memcpy(bg.data() + (size_t)iy * brow, (const uint8_t *)B + src, brow);
     }
-    std::vector<float> cg((size_t)Ny * (size_t)Nx);
+    std::vector<float> &cg = g.h_out;
+    cg.resize((size_t)Ny * (size_t)Nx);
     if (!run_mul_mat(typeA, A, Nx, ne00, lfamd_row_size(typeA, ne00), bt, bg.data(), brow, Ny, cg.data(), Nx))
         die("device mat-mul failed after the request was accepted");
     for (long iy = 0; iy < Ny; iy++) { // DataInfo::dst_row, iqk_mul_mat.inc:94-101
@@ -426,37 +542,56 @@ bool llamafile_mixmul(const struct ggml_compute_params *params, const struct ggm
 
     std::lock_guard<std::mutex> lk(g.mu);
     const size_t packed = g.api.packed_size(wt, rows, cols);
-    // experts packed back to back in one device allocation, cached under the tensor's data pointer
-    const CachedWeights *w = nullptr;
+    // experts packed back to back in one device allocation; kept across calls only when the host bytes are immutable
+    // (registered, or a read-only mapping), otherwise packed into scratch on every call — like get_weights
+    DevWeights w{nullptr, false};
     {
-        size_t span = (size_t)experts * weights->nb[2];
-        uint64_t fp = fingerprint(weights->data, span);
+        const size_t span = (size_t)(experts - 1) * weights->nb[2] + (size_t)rows * weights->nb[1];
+        const bool keep = is_immutable(weights->data, span);
         auto it = g.cache.find(weights->data);
-        if (it != g.cache.end() && it->second.type == wt && it->second.rows == rows * experts && it->second.cols == cols &&
-            it->second.fingerprint == fp) {
-            w = &it->second;
+        if (it != g.cache.end() && !(keep && it->second.type == wt && it->second.rows == rows * experts && it->second.cols == cols &&
+                                     it->second.row_bytes == weights->nb[1])) {
+            drop(it);
+            it = g.cache.end();
+        }
+        if (it != g.cache.end()) {
+            g.lru.splice(g.lru.begin(), g.lru, it->second.lru);
+            w = {it->second.d_packed, it->second.exact_only};
         } else {
-            if (it != g.cache.end()) {
-                g.api.free_(it->second.d_packed);
-                g.cache.erase(it);
+            void *dst = nullptr;
+            const size_t bytes = packed * experts;
+            if (keep) {
+                while (!g.lru.empty() && g.cache_bytes + bytes > g.cache_budget)
+                    drop(g.cache.find(g.lru.back()));
+                while (g.api.malloc_(&dst, bytes) != LFAMD_OK) {
+                    if (g.lru.empty())
+                        die("device allocation for expert weights failed");
+                    drop(g.cache.find(g.lru.back()));
+                }
+            } else {
+                if (!reserve(g.a_scratch, bytes))
+                    die("device allocation for expert weights failed");
+                dst = g.a_scratch.p;
             }
-            CachedWeights nw{wt, rows * experts, cols, weights->nb[1], fp, nullptr, packed * experts};
-            if (g.api.malloc_(&nw.d_packed, nw.bytes) != LFAMD_OK)
-                die("device allocation for expert weights failed");
             for (int e = 0; e < experts; e++) {
                 size_t ebytes = (size_t)rows * weights->nb[1];
                 if (!reserve(g.raw, ebytes) ||
                     g.api.h2d(g.raw.p, (const uint8_t *)weights->data + (size_t)e * weights->nb[2], ebytes, nullptr) ||
-                    g.api.pack_weights(wt, rows, cols, g.raw.p, weights->nb[1], (uint8_t *)nw.d_packed + (size_t)e * packed,
-                                       nullptr) ||
+                    g.api.pack_weights(wt, rows, cols, g.raw.p, weights->nb[1], (uint8_t *)dst + (size_t)e * packed, nullptr) ||
                     g.api.sync(nullptr))
                     die("expert weight upload failed");
             }
-            const int in_range = g.api.scaled_ok(wt, (long)experts * ((rows + 31) / 32) * 32, cols, nw.d_packed, nullptr);
+            const int in_range = g.api.scaled_ok(wt, (long)experts * ((rows + 31) / 32) * 32, cols, dst, nullptr);
             if (in_range < 0)
                 die("expert weight range check failed");
-            nw.exact_only = in_range == 0;
-            w = &(g.cache[weights->data] = nw);
+            w = {dst, in_range == 0};
+            if (keep) {
+                CachedWeights nw{wt, rows * experts, cols, weights->nb[1], dst, bytes, in_range == 0};
+                g.lru.push_front(weights->data);
+                nw.lru = g.lru.begin();
+                g.cache_bytes += bytes;
+                g.cache[weights->data] = nw;
+            }
         }
     }
     // activations: contiguous [tokens][tasks] rows on the device, quantised there if given as f32
@@ -484,7 +619,8 @@ bool llamafile_mixmul(const struct ggml_compute_params *params, const struct ggm
                     die("activation upload failed");
     }
     // routing table, contiguous [tokens][thinkers]
-    std::vector<int32_t> hplan((size_t)tokens * thinkers);
+    std::vector<int32_t> &hplan = g.h_plan; // (grow-only host staging, reused across calls)
+    hplan.resize((size_t)tokens * thinkers);
     for (long t = 0; t < tokens; t++)
         for (int th = 0; th < thinkers; th++)
             hplan[(size_t)t * thinkers + th] =
@@ -495,10 +631,11 @@ bool llamafile_mixmul(const struct ggml_compute_params *params, const struct ggm
         die("device allocation failed");
     if (g.api.h2d(g.plan.p, hplan.data(), hplan.size() * 4, nullptr) || g.api.sync(nullptr))
         die("plan upload failed");
-    if (g.api.mul_mat_id(wt, w->d_packed, rows, cols, experts, bt, g.b.p, brow, tasks, tokens, (const int32_t *)g.plan.p,
-                         thinkers, (float *)g.c.p, g.ws.p, g.ws.cap, flags_now() | (w->exact_only ? LFAMD_FLAG_PRECISE : 0u), nullptr))
+    if (g.api.mul_mat_id(wt, w.d_packed, rows, cols, experts, bt, g.b.p, brow, tasks, tokens, (const int32_t *)g.plan.p,
+                         thinkers, (float *)g.c.p, g.ws.p, g.ws.cap, flags_now() | (w.exact_only ? LFAMD_FLAG_PRECISE : 0u), nullptr))
         die("device mul_mat_id failed");
-    std::vector<float> hres((size_t)tokens * thinkers * rows);
+    std::vector<float> &hres = g.h_out;
+    hres.resize((size_t)tokens * thinkers * rows);
     if (g.api.d2h(hres.data(), g.c.p, rbytes, nullptr) || g.api.sync(nullptr))
         die("result download failed");
     for (long t = 0; t < tokens; t++)

@@ -51,6 +51,20 @@ def random_weights(t: int, rows: int, cols: int, seed: int) -> np.ndarray:
     return raw.reshape(rows, nb * ts)
 
 
+def rescale_blocks(t: int, raw: np.ndarray, factor: float) -> None:
+    """Multiply the f16 block scales (d, and dmin / m where the type has one) of a raw tensor in place — e.g. 2^-5 moves
+    the synthetic d range 2^-10..2^-6 to the 2^-15..2^-11 of real K-quant files, where d * sc of a small sub-block
+    scale is an f16 subnormal."""
+    nb = raw.shape[1] // T.TYPE_SIZE[t]
+    blk = raw.reshape(raw.shape[0], nb, T.TYPE_SIZE[t])
+    d_off, s_off = _SCALE_OFF[t]
+    for off in (d_off, s_off):
+        if off is None:
+            continue
+        v = np.ascontiguousarray(blk[:, :, off:off + 2]).view(np.float16).astype(np.float32)[..., 0] * np.float32(factor)
+        blk[:, :, off:off + 2] = _f16_bytes(v)
+
+
 def random_activations(rows: int, cols: int, seed: int) -> np.ndarray:
     rng = np.random.default_rng(seed)
     return (rng.random((rows, cols), dtype=np.float32) * 2 - 1).astype(np.float32)

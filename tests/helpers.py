@@ -18,3 +18,14 @@ def rel_err(C, G):
     G = np.asarray(G, dtype=np.float64)
     C = np.asarray(C, dtype=np.float64)
     return float(np.abs(C - G).max() / max(np.abs(G).max(), 1e-30))
+
+
+def elem_err(C, G, rtol=1e-3):
+    """Element-wise statistic beside the normwise rel_err: the fraction of outputs with
+    |C - G| > rtol * |G| + rtol * rms(G), and the largest |C - G| / (|G| + rms(G)).  A normwise 1e-3 can hide small
+    outputs that are off by far more; this one cannot."""
+    G = np.asarray(G, dtype=np.float64)
+    C = np.asarray(C, dtype=np.float64)
+    rms = float(np.sqrt(np.mean(G * G))) or 1e-30
+    d = np.abs(C - G)
+    return float(np.mean(d > rtol * np.abs(G) + rtol * rms)), float((d / (np.abs(G) + rms)).max())

@@ -36,6 +36,11 @@ def host(gpu):
     lib.llamafile_sgemm_amd_available.restype = C.c_int
     lib.llamafile_sgemm_amd_error.restype = C.c_char_p
     assert lib.llamafile_sgemm_amd_available() == 1, lib.llamafile_sgemm_amd_error()
+    lib.llamafile_sgemm_amd_register_weights.argtypes = [C.c_void_p, C.c_size_t]
+    lib.llamafile_sgemm_amd_unregister_weights.argtypes = [C.c_void_p]
+    lib.llamafile_sgemm_amd_forget.argtypes = [C.c_void_p]
+    lib.llamafile_sgemm_amd_cached_bytes.restype = C.c_size_t
+    lib.llamafile_sgemm_amd_set_cache_budget.argtypes = [C.c_size_t]
     return lib
 
 
@@ -154,3 +159,111 @@ def test_llamafile_mixmul_iqk_row_mapping(host, oracle):
     assert np.array_equal(np.isnan(Cm), np.isnan(G))  # only mapped rows are written
     mask = ~np.isnan(G)
     assert rel_err(Cm[mask], G[mask]) <= 2e-6
+
+
+def test_mutable_A_is_uploaded_every_call(host, oracle):
+    """ggml also enters llamafile_sgemm with the KV cache as A (KQ, KQV): same address, same shape, bytes changed in
+    the MIDDLE between two calls.  The device copy of unregistered, writable host memory must never be reused
+    (round-1 hazard: a cache keyed by address + 3 x 64 sampled bytes)."""
+    m, n, k = 96, 1, 1024
+    rng = np.random.default_rng(11)
+    A = rng.standard_normal((m, k)).astype(np.float16)
+    B = rng.standard_normal((n, k)).astype(np.float32)
+    Cm = np.zeros((n, m), dtype=np.float32)
+    before = host.llamafile_sgemm_amd_cached_bytes()
+    assert host.llamafile_sgemm(m, n, k, A.ctypes.data, k, B.ctypes.data, k, Cm.ctypes.data, m, 0, 1, T.F16, T.F32, T.F32)
+    want = B.astype(np.float64) @ A.astype(np.float64).T
+    assert rel_err(Cm, want) <= 1e-5
+    assert host.llamafile_sgemm_amd_cached_bytes() == before, "writable, unregistered host memory was cached"
+    A[m // 2, 300:340] = np.float16(7.0)  # an interior row: first / middle / last 64 bytes unchanged
+    Cm2 = np.zeros_like(Cm)
+    assert host.llamafile_sgemm(m, n, k, A.ctypes.data, k, B.ctypes.data, k, Cm2.ctypes.data, m, 0, 1, T.F16, T.F32, T.F32)
+    want2 = B.astype(np.float64) @ A.astype(np.float64).T
+    assert abs(want2[0, m // 2] - want[0, m // 2]) > 1.0
+    assert rel_err(Cm2, want2) <= 1e-5, "stale device copy of a mutated A"
+    # the same for a quantised A (quantised KV cache: -ctk q8_0)
+    Aq, Bq, bt = make_case(T.Q8_0, m, 1, k, seed=5)
+    Cq = np.zeros((1, m), dtype=np.float32)
+    kb = k // 32
+    assert host.llamafile_sgemm(m, 1, kb, Aq.ctypes.data, kb, Bq.ctypes.data, kb, Cq.ctypes.data, m, 0, 1, T.Q8_0, bt, T.F32)
+    Aq[m // 2, 2 + 34 * 7:2 + 34 * 7 + 32] ^= 0x55
+    v = oracle.variant("zen4" if gpu_flags() & _hip.FLAG_Q0_VREGS32 else "avx2")
+    ok, G = oracle.sgemm(T.Q8_0, Aq, bt, Bq, m, 1, k, v=v)
+    Cq2 = np.zeros_like(Cq)
+    assert host.llamafile_sgemm(m, 1, kb, Aq.ctypes.data, kb, Bq.ctypes.data, kb, Cq2.ctypes.data, m, 0, 1, T.Q8_0, bt, T.F32)
+    assert ok == 1 and np.array_equal(Cq2.view(np.uint32), G.view(np.uint32))
+    assert not np.array_equal(Cq2, Cq)
+
+
+def test_registered_and_readonly_weights_are_kept(host, oracle, tmp_path):
+    """Device copies are kept only for immutable host bytes: a registered range, or a mapping without write permission
+    (an mmap'd GGUF).  LRU eviction inside the byte budget; unregister frees."""
+    t, m, n, k = T.Q4_K, 64, 1, 1024
+    A, B, bt = make_case(t, m, n, k, seed=21)
+    kb = k // 256
+    ok, G = oracle.sgemm(t, A, bt, B, m, n, k)
+    assert ok == 1
+
+    def call(a):
+        out = np.zeros((n, m), dtype=np.float32)
+        assert host.llamafile_sgemm(m, n, kb, a.ctypes.data, kb, B.ctypes.data, kb, out.ctypes.data, m, 0, 1, t, bt, T.F32)
+        return out
+
+    base = host.llamafile_sgemm_amd_cached_bytes()
+    assert rel_err(call(A), G) <= 2e-6
+    assert host.llamafile_sgemm_amd_cached_bytes() == base  # writable numpy memory: not kept
+    host.llamafile_sgemm_amd_register_weights(A.ctypes.data, A.nbytes)
+    assert rel_err(call(A), G) <= 2e-6
+    kept = host.llamafile_sgemm_amd_cached_bytes() - base
+    assert kept == _hip.lib().lfamd_packed_size(t, m, k)
+    assert rel_err(call(A), G) <= 2e-6  # served from the kept copy
+    assert host.llamafile_sgemm_amd_cached_bytes() - base == kept
+    host.llamafile_sgemm_amd_unregister_weights(A.ctypes.data)
+    assert host.llamafile_sgemm_amd_cached_bytes() == base
+    # a read-only file mapping needs no registration
+    f = tmp_path / "weights.bin"
+    A.tofile(f)
+    Am = np.memmap(f, dtype=np.uint8, mode="r", shape=A.shape)
+    assert rel_err(call(Am), G) <= 2e-6
+    assert host.llamafile_sgemm_amd_cached_bytes() - base == kept
+    # budget: a second tensor that does not fit evicts the least recently used one
+    host.llamafile_sgemm_amd_set_cache_budget(base + kept)
+    A2 = synth.random_weights(t, m, k, 22)
+    host.llamafile_sgemm_amd_register_weights(A2.ctypes.data, A2.nbytes)
+    ok2, G2 = oracle.sgemm(t, A2, bt, B, m, n, k)
+    assert rel_err(call(A2), G2) <= 2e-6
+    assert host.llamafile_sgemm_amd_cached_bytes() - base == kept
+    assert rel_err(call(Am), G) <= 2e-6  # (packed again)
+    host.llamafile_sgemm_amd_set_cache_budget(200 << 30)
+    host.llamafile_sgemm_amd_unregister_weights(A2.ctypes.data)
+    host.llamafile_sgemm_amd_forget(Am.ctypes.data)
+    assert host.llamafile_sgemm_amd_cached_bytes() == base
+
+
+def test_mixmul_mutated_experts(host, oracle):
+    """llamafile_mixmul with writable expert weights changed in place between two calls."""
+    wt, cols, rows, experts, thinkers, tokens, tasks = T.Q8_0, 512, 64, 4, 2, 3, 1
+    W = np.stack([synth.random_weights(wt, rows, cols, 60 + e) for e in range(experts)])
+    thought = synth.random_activations(tokens * tasks, cols, 8).reshape(tokens, tasks, cols)
+    plan = np.array([[0, 1], [2, 3], [1, 2]], dtype=np.int32)
+    rb = W.shape[2]
+    v = oracle.variant("zen4" if gpu_flags() & _hip.FLAG_Q0_VREGS32 else "avx2")
+
+    def call():
+        res = np.full((tokens, thinkers, rows), np.nan, dtype=np.float32)
+        wt_t = tensor(W, wt, (cols, rows, experts), (T.TYPE_SIZE[wt], rb, rb * rows))
+        th_t = tensor(thought, T.F32, (cols, tasks, tokens), (4, cols * 4, cols * 4 * tasks))
+        pl_t = tensor(plan, T.I32, (thinkers, tokens), (4, 4 * thinkers))
+        rs_t = tensor(res, T.F32, (rows, thinkers, tokens), (4, rows * 4, rows * 4 * thinkers))
+        p = ComputeParams(0, 1, 0, None, None)
+        assert host.llamafile_mixmul(C.byref(p), C.byref(wt_t), C.byref(th_t), C.byref(pl_t), C.byref(rs_t))
+        return res
+
+    r1 = call()
+    ok, G1 = oracle.mixmul(wt, W, cols, rows, experts, thought, plan, v=v)
+    assert ok == 1 and np.array_equal(r1.view(np.uint32), G1.view(np.uint32))
+    W[2, rows // 2, 2 + 34 * 5:2 + 34 * 5 + 32] ^= 0x33  # expert 2, an interior row
+    r2 = call()
+    ok, G2 = oracle.mixmul(wt, W, cols, rows, experts, thought, plan, v=v)
+    assert ok == 1 and np.array_equal(r2.view(np.uint32), G2.view(np.uint32))
+    assert not np.array_equal(r1, r2)
