@@ -47,7 +47,9 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--force-dist", action="store_true",
                    help="rehearsal: initialise the process group and issue the collectives even at world size 1")
-    p.add_argument("--model", default="llama3-8b-q4_k_m", choices=["llama3-8b-q4_k_m", "llama3-8b-q8_0"])
+    p.add_argument("--model", default="llama3-8b-q4_k_m", choices=["llama3-8b-q4_k_m", "llama3-8b-q8_0", "llama3-70b-q4_k_m"])
+    p.add_argument("--no-extra-configs", action="store_true",
+                   help="skip the BASELINE config 3 (Llama-3-8B Q8_0) and config 4 (Mixtral-8x7B expert path) legs of the line")
     return p.parse_args()
 
 
@@ -177,52 +179,164 @@ class Runner:
         return launches, nops
 
 
+def cpu_share():
+    """Host threads this process may really use: the affinity mask capped by the cgroup CPU quota (the GPU box gives a
+    1-GPU job 16 of its 256 hardware threads; 128 OpenMP threads under that quota were throttled at random, which is
+    what made round 1's baseline scatter by 8x)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(layers, prefill, decode):
-    """Time the CPU restatement (oracle, scalar C + OpenMP over ith like sgemm_matmul_test.cpp:32-40)
-    on a bounded sample: one transformer layer (layer 0: 5 Q4_K + 2 Q6_K mat-muls) at n=1 and at
-    n=min(prefill, 32), extrapolated to the whole model (x n_layers, output.weight added at its byte /
-    flop share)."""
+    """Time the CPU restatement (oracle: scalar C + OpenMP over ith like sgemm_matmul_test.cpp:32-40, kind "port") on a
+    bounded sample of the same workload, with pinned threads:
+      * prefill: n = `prefill` DIRECTLY on attn_output (Q4_K 4096 x 4096), ffn_gate (Q4_K 14336 x 4096) and layer 0's
+        ffn_down (Q6_K 4096 x 14336), median of 3 each; every other op of the model is priced at its type's measured
+        FLOP rate;
+      * decode: n = 1 on the seven ops of layer 0, median of 5 each, x layers, output.weight at its byte share.
+    Reports the median-based tokens/s, the spread of the repeats, and `unstable` if any op's repeats differ by more than
+    1.5x (then the measurement is repeated once before giving up)."""
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    os.environ.setdefault("OMP_PLACES", "cores")
     try:
         from oracle import ora
         ora.build()
     except Exception as e:  # the oracle is test infrastructure; the bench line survives without it
         return {"value": None, "unit": "tokens/s", "cores": 0, "kind": "port", "sample": f"unavailable: {e}"}
-    import numpy as np
-    nth = min(os.cpu_count() or 1, ora.lib().ora_max_threads())
+    import statistics
+    nth = min(cpu_share(), ora.lib().ora_max_threads())
     layer = layers[0]
-    n_layers = len(layers) - 1
-    n_pf = min(prefill, 32)
-    t_dec = t_pf = 0.0
-    for spec in layer:
+
+    def timed(spec, n, reps):
         A = synth.random_weights(spec.type, spec.m, spec.k, 1)
         vdt = T.VEC_DOT[spec.type]
-        B1 = synth.quantize_activations(vdt, synth.random_activations(1, spec.k, 2))
-        Bp = synth.quantize_activations(vdt, synth.random_activations(n_pf, spec.k, 3))
-        ora.sgemm_openmp(spec.type, A, vdt, B1, spec.m, 1, spec.k, nth)  # warm
-        best = float("inf")  # best of 5 / 2: the box's host cores are shared, single timings scatter by several x
-        for _ in range(5):
+        Bq = synth.quantize_activations(vdt, synth.random_activations(n, spec.k, 2))
+        ora.sgemm_openmp(spec.type, A, vdt, Bq, spec.m, min(n, 8), spec.k, nth)  # warm: page in the weights, wake the team
+        ts = []
+        for _ in range(reps):
             t0 = time.perf_counter()
-            ora.sgemm_openmp(spec.type, A, vdt, B1, spec.m, 1, spec.k, nth)
-            best = min(best, time.perf_counter() - t0)
-        t_dec += best
-        best = float("inf")
-        for _ in range(2):
-            t0 = time.perf_counter()
-            ora.sgemm_openmp(spec.type, A, vdt, Bp, spec.m, n_pf, spec.k, nth)
-            best = min(best, time.perf_counter() - t0)
-        t_pf += best
-    # extrapolate: output.weight costs (its weight bytes / one layer's weight bytes) of a layer pass
-    lb = sum(LS.weight_bytes(s) for s in layer)
-    scale = n_layers + LS.weight_bytes(layers[-1][0]) / lb
-    t_decode_token = t_dec * scale
-    t_prefill = t_pf * scale * (prefill / n_pf)
+            ora.sgemm_openmp(spec.type, A, vdt, Bq, spec.m, n, spec.k, nth)
+            ts.append(time.perf_counter() - t0)
+        return ts
+
+    def measure():
+        spreads, med_min = [], []
+        by_name = {s.name.split(".")[-1]: s for s in layer}
+        rate = {}  # weight type -> FLOP/s at n = prefill
+        pf_ops = [by_name["attn_output"], by_name["ffn_gate"], by_name["ffn_down"]]
+        fl = {T.Q4_K: 0.0, T.Q6_K: 0.0}
+        tm = {T.Q4_K: 0.0, T.Q6_K: 0.0}
+        for spec in pf_ops:
+            ts = timed(spec, prefill, 3)
+            spreads.append(max(ts) / min(ts))
+            med_min.append(statistics.median(ts) / min(ts))
+            fl[spec.type] += 2.0 * spec.m * spec.k * prefill
+            tm[spec.type] += statistics.median(ts)
+        for t in fl:
+            if tm[t] > 0:
+                rate[t] = fl[t] / tm[t]
+        for t in (T.Q4_K, T.Q6_K):  # (a model whose layer 0 lacks one of the types: price it like the other)
+            rate.setdefault(t, next(iter(rate.values())))
+        t_prefill = sum(2.0 * s.m * s.k * prefill / rate[s.type] for ops in layers for s in ops)
+        t_dec_layer = 0.0
+        for spec in layer:
+            ts = timed(spec, 1, 5)
+            spreads.append(max(ts) / min(ts))
+            med_min.append(statistics.median(ts) / min(ts))
+            t_dec_layer += statistics.median(ts)
+        lb = sum(LS.weight_bytes(s) for s in layer)
+        t_decode_token = t_dec_layer * ((len(layers) - 1) + LS.weight_bytes(layers[-1][0]) / lb)
+        return t_prefill, t_decode_token, max(spreads), max(med_min), rate
+
+    # the value is built from per-op MEDIANS; it is reproducible when every op's median sits within 1.5x of its fastest
+    # repeat (a single preempted repeat among five does not move a median; max / min is reported beside it)
+    t_prefill, t_decode_token, spread, mm, rate = measure()
+    unstable = mm > 1.5
+    if unstable:
+        print(f"bench.py: cpu_baseline medians are {mm:.2f}x their fastest repeat (> 1.5x): measuring again", file=sys.stderr)
+        t_prefill, t_decode_token, spread, mm, rate = measure()
+        unstable = mm > 1.5
+        if unstable:
+            print(f"bench.py: cpu_baseline STILL unstable (median {mm:.2f}x the fastest repeat): the value below is not "
+                  f"reproducible", file=sys.stderr)
     total = t_prefill + decode * t_decode_token
     return {
         "value": round((prefill + decode) / total, 3), "unit": "tokens/s", "cores": nth, "kind": "port",
-        "sample": f"layer 0 (7 mat-muls) at n=1 (best of 5) and n={n_pf} (best of 2) on {nth} threads, extrapolated x{scale:.2f} layers "
-                  f"and x{prefill / n_pf:.0f} prefill columns; decode {1.0 / t_decode_token:.2f} tok/s, "
-                  f"prefill {prefill / t_prefill:.2f} tok/s",
+        "median_over_fastest_repeat": round(mm, 3), "max_over_min_repeat": round(spread, 3), "unstable": unstable,
+        "sample": f"n={prefill} timed directly on attn_output 4096x4096, ffn_gate 14336x4096 (Q4_K) and ffn_down 4096x14336 "
+                  f"(layer 0's type), median of 3; n=1 on layer 0's 7 mat-muls, median of 5; {nth} pinned threads "
+                  f"(OMP_PROC_BIND=close, the cgroup's CPU share); other ops priced at their type's measured rate "
+                  f"({', '.join(f'{T.NAMES[t]} {r / 1e9:.1f} GFLOP/s' for t, r in rate.items())}); "
+                  f"decode {1.0 / t_decode_token:.2f} tok/s, prefill {prefill / t_prefill:.2f} tok/s",
     }
+
+
+def kernel_source_hash():
+    """sha256 over the kernel sources: a PMC traffic profile is quoted only for the sources it was measured on."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "llamafile_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "llamafile_amd", "csrc", "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
+def newest_traffic_profile():
+    import glob
+    import re
+    best = None
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")):
+        m = re.match(r"r(\d+)_v(\d+)_", os.path.basename(f)) or re.match(r"r(\d+)()_", os.path.basename(f))
+        key = (int(m.group(1)), int(m.group(2) or 0)) if m else (0, 0)
+        if best is None or key > best[0]:
+            best = (key, f)
+    return best[1] if best else None
+
+
+def config3_q8_0(a, dev):
+    """BASELINE config 3: Llama-3-8B Q8_0 — the batch-1 decode GEMV (bit-exact tinyBLAS_Q0 restatement) and the prefill
+    pass, 8.5 GB of packed weights, hipGraph replays timed with events."""
+    layers = LS.llama3_8b_q8_0()
+    r = Runner(layers, 0, 1, (a.prefill, 1), dev)
+    res = {"model": "llama3-8b-q8_0", "weight_bytes": r.weight_bytes()}
+    for n, reps, key in ((1, 20, "decode"), (a.prefill, 2, "prefill")):
+        r.run_pass(n)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            g.capture_begin(capture_error_mode="thread_local")
+            r.run_pass(n)
+            g.capture_end()
+        torch.cuda.current_stream().wait_stream(side)
+        g.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        res[f"{key}_pass_ms"] = round(ms, 4)
+        res[f"{key}_tokens_per_s"] = round(n / (ms * 1e-3), 1)
+        if n == 1:
+            res["decode_GBps"] = round(r.weight_bytes() / (ms * 1e-3) / 1e9, 1)
+            res["decode_hbm_frac"] = round(r.weight_bytes() / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        else:
+            fl = sum(2.0 * o.m * o.k * n for ops in r.layers for o in ops)
+            res["prefill_TFLOPs"] = round(fl / (ms * 1e-3) / 1e12, 1)
+        del g
+    del r
+    return res
 
 
 def main():
@@ -252,7 +366,8 @@ def main():
         else:
             torch.distributed.init_process_group(backend, rank=rank, world_size=world)
 
-    layers = LS.llama3_8b_q4_k_m() if a.model == "llama3-8b-q4_k_m" else LS.llama3_8b_q8_0()
+    layers = {"llama3-8b-q4_k_m": LS.llama3_8b_q4_k_m, "llama3-8b-q8_0": LS.llama3_8b_q8_0,
+              "llama3-70b-q4_k_m": LS.llama3_70b_q4_k_m}[a.model]()
     runner = Runner(layers, rank, world, (a.prefill, 1), dev, collectives=dist_on)
 
     def barrier():
@@ -355,7 +470,7 @@ def main():
 
     # ---- roofline of the dominant kernel: the decode GEMV of the dominant weight type, all its
     # launches of one decode pass, back to back on the stream, timed with HIP events
-    dom_type = T.Q4_K if a.model == "llama3-8b-q4_k_m" else T.Q8_0
+    dom_type = T.Q8_0 if a.model == "llama3-8b-q8_0" else T.Q4_K
     dom_ops = [o for ops in runner.layers for g in runner._groups(ops) if {q.spec.type for q in g} == {dom_type} for o in g]
     launches_per_pass, _ = runner.run_pass(1, only_type=dom_type)
     us, n_launch = time_region(lambda: runner.run_pass(1, only_type=dom_type), 10)
@@ -369,14 +484,20 @@ def main():
     # HBM traffic per launch: from the rocprofv3 PMC passes of this same workload (tools/profile_round.sh:
     # FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM), stored
     # under profiles/ — counters cannot be read from inside this process
-    traffic, traffic_src = None, None
-    tfile = os.path.join(ROOT, "profiles", "r01_v12_pmc_traffic.json")
-    if dom_type == T.Q4_K and world == 1 and os.path.exists(tfile):
+    traffic, traffic_src, tj = None, None, None
+    tfile = newest_traffic_profile()
+    if tfile and dom_type == T.Q4_K and world == 1:
         try:
-            traffic = json.load(open(tfile))["gemv_q4k"]["hbm_bytes_per_launch"]
-            traffic_src = "profiles/r01_v12_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2)"
-        except (KeyError, ValueError):
-            pass
+            tj = json.load(open(tfile))
+            rel = os.path.relpath(tfile, ROOT)
+            if tj.get("kernel_source_sha256") == kernel_source_hash():
+                traffic = tj["gemv_q4k"]["hbm_bytes_per_launch"]
+                traffic_src = f"{rel} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x2; same kernel sources)"
+            else:  # counters cannot be read from inside this process: a profile of OTHER kernel sources is not this code's traffic
+                traffic_src = f"{rel} was measured on different kernel sources (hash mismatch): traffic not reported"
+                tj = None
+        except (KeyError, ValueError, OSError):
+            tj = None
     kname = "gemv_kq_kernel<q4k_traits, 1, F32, 16, {1,2}>" if dom_type == T.Q4_K else "gemv_q80_kernel<1, F32, mode>"
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
@@ -406,16 +527,11 @@ def main():
                                             "achieved": round(tf, 1), "frac": round(tf / MFMA_F16_PEAK_TFLOPS, 4),
                                             "kernel": "prep_f32 + gemm_lw_kernel<Q4_K, 128x128 tile, scaled operands>"}
 
-    if roofline_gemm and os.path.exists(tfile):
-        # HBM traffic of the two GEMM tiles: averages over the launches of the profiled bench (each tile serves several
+    if roofline_gemm and tj:
+        # HBM traffic of the GEMM tiles: averages over the launches of the profiled bench (each tile serves several
         # shapes of the model), from the same PMC passes as the GEMV's
-        try:
-            tj = json.load(open(tfile))
-            roofline_gemm["traffic_avg_over_model_launches"] = {
-                "gemm_lw 128x64": tj.get("gemm_q4k_lw_128x64", {}).get("hbm_bytes_per_launch"),
-                "gemm_lw 128x128": tj.get("gemm_q4k_lw_128x128", {}).get("hbm_bytes_per_launch")}
-        except ValueError:
-            pass
+        roofline_gemm["traffic_avg_over_model_launches"] = {k: v.get("hbm_bytes_per_launch") for k, v in tj.items()
+                                                            if isinstance(v, dict) and k.startswith("gemm")}
 
     if rank != 0:
         if dist_on:
@@ -437,7 +553,7 @@ def main():
         "dtype": "int8",
         "data": "synthetic",
         "config": {
-            "workload": f"Llama-3-8B Q4_K_M mat-muls (225 GGML_OP_MUL_MAT per pass, f32 activations in, quantisation fused, sibling ops fused at decode), "
+            "workload": f"{a.model} mat-muls ({sum(len(l) for l in layers)} GGML_OP_MUL_MAT per pass, f32 activations in, quantisation fused, sibling ops fused at decode), "
                         f"{a.prefill}-token prefill + {a.decode} decode, matmul-only",
             "numerics": "decode: exact int8 x int4/int6 block dot products with f32 scales (v_dot4_i32_i8); prefill: f16 MFMA, "
                         "f32 accumulate, Q4_K and Q6_K on scaled operands f16(d*sc*q) x f16(d8*code) (<= 1e-3 relative, measured "
@@ -453,6 +569,18 @@ def main():
     }
     if roofline_gemm:
         out["roofline_prefill_gemm"] = roofline_gemm
+    # ---- BASELINE configs 3 and 4 beside the headline config, so the driver's record carries them (1 GPU, default model)
+    if world == 1 and a.model == "llama3-8b-q4_k_m" and not a.no_extra_configs:
+        del runner, graphs
+        torch.cuda.empty_cache()
+        out["config3"] = config3_q8_0(a, dev)
+        torch.cuda.empty_cache()
+        try:
+            from llamafile_amd import mixtral_bench
+            out["config4"] = mixtral_bench.run(32, 20, a.prefill, dev)
+        except Exception as e:  # noqa: BLE001 (the headline line must survive a failure of a side leg)
+            out["config4"] = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
+        torch.cuda.empty_cache()
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(layers, a.prefill, a.decode)
     else:

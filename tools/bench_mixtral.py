@@ -1,136 +1,12 @@
-"""BASELINE.json config 3: Mixtral-8x7B Q4_K_M, the llamafile_mixmul / GGML_OP_MUL_MAT_ID expert path on one MI355X.
-
-Decode pass = per layer attn_q/k/v (fused), attn_output, and the three MUL_MAT_ID ops (ffn_gate_exps, ffn_up_exps with the
-token's activations shared by both chosen experts; ffn_down_exps with one activation row per expert), then output.weight.
-Experts are picked INSIDE the GEMV kernels from the device-resident routing table (no host sync), so the whole pass is one
-hipGraph.  Synthetic weights (26 GB packed), random top-2 routing per layer.  Prints one JSON line.
-    python tools/bench_mixtral.py [--layers 32] [--iters 50]
-"""
-import argparse, ctypes as C, json, sys, time
-import torch
+"""BASELINE.json config 4 (Mixtral-8x7B Q4_K_M expert path) as a stand-alone run: python tools/bench_mixtral.py [--layers 32]"""
+import argparse, json, sys
 sys.path.insert(0, ".")
-from llamafile_amd import sgemm, synth, _hip, ggml_types as T
-from llamafile_amd.llama_shapes import use_more_bits
+from llamafile_amd import sgemm, mixtral_bench
 
 p = argparse.ArgumentParser()
 p.add_argument("--layers", type=int, default=32)
 p.add_argument("--iters", type=int, default=50)
 p.add_argument("--prefill", type=int, default=512)
 a = p.parse_args()
-E, TOPK, D, FF, KV, V = 8, 2, 4096, 14336, 1024, 32000
-dev = torch.device("cuda", 0)
 sgemm.init(0)
-L = _hip.lib()
-flags = sgemm.host_variant_flags()
-seed = [1]
-
-
-def W(t, m, k):
-    seed[0] += 1
-    return sgemm.upload_weights(t, synth.random_weights_torch(t, m, k, seed[0], dev), m, k, dev)
-
-
-def stack(t, m, k):  # experts back to back
-    ws = [W(t, m, k) for _ in range(E)]
-    data = torch.cat([w.data for w in ws])
-    return data, ws[0].nbytes
-
-
-layers = []
-wbytes = active = 0
-for il in range(a.layers):
-    hi = T.Q6_K if use_more_bits(il, a.layers) else T.Q4_K
-    lay = {"q": W(T.Q4_K, D, D), "k": W(T.Q4_K, KV, D), "v": W(hi, KV, D), "o": W(T.Q4_K, D, D), "hi": hi}
-    lay["gate"], gb = stack(T.Q4_K, FF, D)
-    lay["up"], ub = stack(T.Q4_K, FF, D)
-    lay["down"], db = stack(hi, D, FF)
-    lay["eb"] = (gb, ub, db)
-    g = torch.Generator(device="cpu"); g.manual_seed(il)
-    lay["plan"] = torch.stack([torch.randperm(E, generator=g)[:TOPK]]).to(torch.int32).to(dev)  # [1][2]
-    layers.append(lay)
-    attn = lay["q"].nbytes + lay["k"].nbytes + lay["v"].nbytes + lay["o"].nbytes
-    wbytes += attn + lay["gate"].numel() + lay["up"].numel() + lay["down"].numel()
-    active += attn + TOPK * (gb + ub + db)
-out_w = W(T.Q6_K, V, D)
-wbytes += out_w.nbytes
-active += out_w.nbytes
-torch.cuda.synchronize()
-
-x = torch.rand((1, D), device=dev) * 2 - 1
-xf = torch.rand((TOPK, FF), device=dev) * 2 - 1  # one activation row per chosen expert for ffn_down
-ws = torch.empty(1 << 26, dtype=torch.uint8, device=dev)
-res_gu = torch.empty((1, TOPK, FF), device=dev)
-res_d = torch.empty((1, TOPK, D), device=dev)
-ptr = lambda t: C.c_void_p(t.data_ptr())
-
-
-def mm(Ws, xin):
-    return sgemm.mul_mat_multi(Ws, xin.view(torch.uint8).view(xin.shape[0], -1), T.F32, n=1, flags=flags, workspace=ws)
-
-
-def moe(stackd, t, rows, cols, thought, tasks, plan, res):
-    rc = L.lfamd_mul_mat_id(t, ptr(stackd), rows, cols, E, T.F32, ptr(thought), thought.stride(0) * 4, tasks, 1, ptr(plan), TOPK,
-                            ptr(res), ptr(ws), ws.numel(), flags, C.c_void_p(torch.cuda.current_stream().cuda_stream))
-    _hip.check(rc, "mul_mat_id")
-
-
-def decode_pass():
-    for lay in layers:
-        if lay["hi"] == T.Q4_K:
-            mm([lay["q"], lay["k"], lay["v"]], x)
-        else:
-            mm([lay["q"], lay["k"]], x)
-            mm([lay["v"]], x)
-        mm([lay["o"]], x)
-        moe(lay["gate"], T.Q4_K, FF, D, x, 1, lay["plan"], res_gu)
-        moe(lay["up"], T.Q4_K, FF, D, x, 1, lay["plan"], res_gu)
-        moe(lay["down"], lay["hi"], D, FF, xf, TOPK, lay["plan"], res_d)
-    mm([out_w], x)
-
-
-decode_pass()
-torch.cuda.synchronize()
-g = torch.cuda.CUDAGraph()
-with torch.cuda.graph(g):
-    decode_pass()
-for _ in range(3):
-    g.replay()
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-for _ in range(a.iters):
-    g.replay()
-torch.cuda.synchronize()
-dec_ms = (time.perf_counter() - t0) / a.iters * 1e3
-
-# prefill: MUL_MAT_ID over a.prefill tokens goes through the routing read-back + per-expert GEMMs (host sync: eager);
-# one layer's three expert ops, timed and scaled by the layer count
-n = a.prefill
-xp = torch.rand((n, D), device=dev) * 2 - 1
-xq = sgemm.quantize_rows(T.Q8_K, xp)
-xfq = sgemm.quantize_rows(T.Q8_K, torch.rand((n * TOPK, FF), device=dev) * 2 - 1)
-gcpu = torch.Generator(device="cpu"); gcpu.manual_seed(7)
-planp = torch.stack([torch.randperm(E, generator=gcpu)[:TOPK] for _ in range(n)]).to(torch.int32).to(dev)
-lay = layers[0]
-
-
-def prefill_layer_moe():
-    sgemm.mul_mat_id(lay["gate"], T.Q4_K, FF, D, E, xq, T.Q8_K, 1, n, planp, TOPK, flags=flags)
-    sgemm.mul_mat_id(lay["up"], T.Q4_K, FF, D, E, xq, T.Q8_K, 1, n, planp, TOPK, flags=flags)
-    sgemm.mul_mat_id(lay["down"], lay["hi"], D, FF, E, xfq, T.Q8_K, TOPK, n, planp, TOPK, flags=flags)
-
-
-prefill_layer_moe()
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-for _ in range(3):
-    prefill_layer_moe()
-torch.cuda.synchronize()
-pf_moe_ms = (time.perf_counter() - t0) / 3 * 1e3
-print(json.dumps({
-    "config": "Mixtral-8x7B Q4_K_M, MUL_MAT_ID expert path, 1 x MI355X, synthetic weights, matmul-only",
-    "layers": a.layers, "weight_bytes": wbytes, "active_bytes_per_token": active,
-    "decode_pass_ms": round(dec_ms, 4), "decode_tokens_per_s": round(1e3 / dec_ms, 1),
-    "decode_active_GBps": round(active / (dec_ms * 1e-3) / 1e9, 1),
-    "prefill_tokens": n, "prefill_moe_ms_per_layer": round(pf_moe_ms, 3),
-    "prefill_moe_TFLOPs": round(2.0 * n * TOPK * (2 * FF * D + D * FF) / (pf_moe_ms * 1e-3) / 1e12, 1),
-}))
+print(json.dumps(mixtral_bench.run(a.layers, a.iters, a.prefill)))

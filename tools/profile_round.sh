@@ -5,7 +5,7 @@
 # Summaries are written to gpurun_out/prof/*.json|csv; copy what should be judged into profiles/.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/prof; rm -rf $OUT; mkdir -p $OUT
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_profiled.json 2> $OUT/stats.err
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra-configs > $OUT/bench_profiled.json 2> $OUT/stats.err
 f=$(find $OUT/stats -name "*kernel_stats.csv" | head -1)
 python3 - "$f" $OUT/kernel_stats_trimmed.csv <<'PY'
 import csv, sys
@@ -20,7 +20,7 @@ with open(sys.argv[2], "w") as o:
 PY
 rm -rf $OUT/stats/*/*kernel_trace.csv
 for ctr in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 300 rocprofv3 --pmc $ctr --output-format csv -d $OUT/pmc_$ctr -- python3 bench.py --steps 1 --warmup 0 --decode 4 --no-graph --no-cpu-baseline > $OUT/pmc_$ctr.json 2> $OUT/pmc_$ctr.err
+  timeout -k 10 300 rocprofv3 --pmc $ctr --output-format csv -d $OUT/pmc_$ctr -- python3 bench.py --steps 1 --warmup 0 --decode 4 --no-graph --no-cpu-baseline --no-extra-configs > $OUT/pmc_$ctr.json 2> $OUT/pmc_$ctr.err
 done
 python3 - $OUT <<'PY'
 import csv, glob, json, sys, collections
@@ -45,6 +45,9 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
 for k, d in res.items():
     # MI355X_MICROARCH.md §HBM: FETCH_SIZE (KB) reports 1/2 of a wide coalesced read on gfx950 -> x2; WRITE_SIZE exact
     d["hbm_bytes_per_launch"] = int((2 * d.get("FETCH_SIZE_KB_avg_per_launch", 0) + d.get("WRITE_SIZE_KB_avg_per_launch", 0)) * 1024)
+sys.path.insert(0, ".")
+import bench  # the profile is quoted by bench.py only for the kernel sources it was measured on
+res["kernel_source_sha256"] = bench.kernel_source_hash()
 json.dump(res, open(f"{out}/pmc_traffic.json", "w"), indent=1)
 print(json.dumps(res))
 PY
