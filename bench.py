@@ -60,10 +60,11 @@ class Op:
 class Runner:
     """Holds the sharded weights and pre-allocated buffers; runs one pass of all mat-muls at batch n."""
 
-    def __init__(self, layers, rank, world, batches, dev, collectives=False):
+    def __init__(self, layers, rank, world, batches, dev, collectives=False, comm=None):
         self.L = _hip.lib()
         self.rank, self.world, self.dev = rank, world, dev
         self.collectives = collectives
+        self.comm = comm  # llamafile_amd.tp.Comm (the C ABI's collectives); None: torch.distributed (LFAMD_COLLECTIVES=torch)
         self.flags = sgemm.host_variant_flags()
         self.layers = []
         seed = 0x5EED0000
@@ -107,6 +108,7 @@ class Runner:
                 vm = [o for ops in self.layers for o in ops if o.spec.shard == "vocab"]
                 if vm:
                     b["gather"] = [torch.empty((n, vm[0].m), dtype=torch.float32, device=dev) for _ in range(world)]
+                    b["gather_flat"] = torch.empty((world, n, vm[0].m), dtype=torch.float32, device=dev)
             self.buf[n] = b
 
     def weight_bytes(self):
@@ -172,10 +174,18 @@ class Runner:
             nops += len(g)
             if only_type is None and self.collectives:
                 for o, out in zip(g, outs):
-                    if o.spec.shard == "cols":
-                        torch.distributed.all_reduce(out)
-                    elif o.spec.shard == "vocab":
-                        torch.distributed.all_gather(b["gather"], out)
+                    if o.spec.shard == "cols":  # partial sums of the residual stream
+                        if self.comm is not None:
+                            self.comm.allreduce_add(out)
+                        else:
+                            torch.distributed.all_reduce(out)
+                    elif o.spec.shard == "vocab":  # vocabulary-row shards of the logits
+                        if self.comm is not None:
+                            if self.comm.has_rccl or out.numel() * 4 <= self.comm.oneshot:
+                                self.comm.allgather(out, b["gather_flat"])
+                            # (a same-device rehearsal has no RCCL: shards beyond the one-shot slot are not gathered)
+                        else:
+                            torch.distributed.all_gather(b["gather"], out)
         return launches, nops
 
 
@@ -300,6 +310,37 @@ def newest_traffic_profile():
     return best[1] if best else None
 
 
+def make_comm(rank, world, same_device=False):
+    """The C-ABI communicator for the tensor-parallel run.  The one-shot peer all-reduce (decode-sized messages) is
+    verified once against a known answer before it is trusted: on a mismatch or a lost peer the communicator is rebuilt
+    with RCCL only.  `same_device`: a rehearsal with several ranks on one GPU (RCCL refuses that): one-shot for every size."""
+    from llamafile_amd import tp
+    oneshot = int(os.environ.get("LFAMD_ONESHOT_BYTES", str((32 << 20) if same_device else 65536)))
+    use_rccl = not same_device and world > 1
+    comm = tp.Comm(rank, world, use_rccl=use_rccl, oneshot_bytes=oneshot)
+    comm.mode = ("RCCL" if use_rccl else "no RCCL") + (f" + one-shot peer kernel <= {oneshot} B" if oneshot and world > 1 else "")
+    if oneshot and world > 1:
+        x = torch.full((4096,), float(rank + 1), device="cuda") + torch.arange(4096, device="cuda", dtype=torch.float32) * 1e-3
+        y = torch.empty_like(x)
+        for _ in range(3):
+            comm.allreduce_add(x, None, y)
+        torch.cuda.synchronize()
+        want = world * (world + 1) / 2 + world * torch.arange(4096, device="cuda", dtype=torch.float32) * 1e-3
+        good = comm.check() == 0 and bool(torch.allclose(y, want, rtol=1e-6, atol=1e-6))
+        flag = torch.tensor([1 if good else 0])
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+        if not int(flag.item()):
+            if rank == 0:
+                print("bench.py: one-shot peer all-reduce failed its self-test on this node: RCCL for every size", file=sys.stderr)
+            comm.close()
+            comm = tp.Comm(rank, world, use_rccl=True, oneshot_bytes=0)
+            comm.mode = "RCCL (one-shot self-test failed)"
+    comm.describe = lambda: comm.mode + ", through the C ABI"
+    comm.has_rccl = use_rccl or "self-test failed" in comm.mode
+    comm.oneshot = oneshot if "self-test failed" not in comm.mode else 0
+    return comm
+
+
 def config3_q8_0(a, dev):
     """BASELINE config 3: Llama-3-8B Q8_0 — the batch-1 decode GEMV (bit-exact tinyBLAS_Q0 restatement) and the prefill
     pass, 8.5 GB of packed weights, hipGraph replays timed with events."""
@@ -340,6 +381,21 @@ def config3_q8_0(a, dev):
 
 
 def main():
+    # ONE JSON line on stdout: anything else a library prints there from C++ (gloo: "[Gloo] Rank 0 is connected ...") goes
+    # to stderr — file descriptor 1 is pointed at stderr for the run and the line is written to the saved descriptor
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        line = run()
+    finally:
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+    if line is not None:
+        os.write(real_stdout, (line + "\n").encode())
+
+
+def run():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -354,6 +410,8 @@ def main():
     dev = torch.device("cuda", local)
     sgemm.init(local)
     dist_on = world > 1 or a.force_dist
+    comm = None
+    abi_collectives = os.environ.get("LFAMD_COLLECTIVES", "abi") != "torch"
     if dist_on:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -361,14 +419,20 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         backend = os.environ.get("LFAMD_DIST_BACKEND", "nccl")
-        if backend == "nccl":
+        if abi_collectives:
+            # compute AND collectives through the C ABI (include/lfamd_hip.h): RCCL inside the HIP module + the one-shot
+            # peer all-reduce for the decode-sized messages; torch.distributed (gloo) only carries the bootstrap bytes,
+            # the barrier and the max over the ranks' clocks
+            torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+            comm = make_comm(rank, world, same_device=(backend != "nccl"))
+        elif backend == "nccl":
             torch.distributed.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
         else:
             torch.distributed.init_process_group(backend, rank=rank, world_size=world)
 
     layers = {"llama3-8b-q4_k_m": LS.llama3_8b_q4_k_m, "llama3-8b-q8_0": LS.llama3_8b_q8_0,
               "llama3-70b-q4_k_m": LS.llama3_70b_q4_k_m}[a.model]()
-    runner = Runner(layers, rank, world, (a.prefill, 1), dev, collectives=dist_on)
+    runner = Runner(layers, rank, world, (a.prefill, 1), dev, collectives=dist_on, comm=comm)
 
     def barrier():
         torch.cuda.synchronize()
@@ -379,7 +443,7 @@ def main():
     # hipGraph capture of a whole pass (kernels + RCCL collectives).  If capturing the collectives is not
     # possible on this stack, fall back to eager launches rather than fail.
     # (gloo rehearsals cannot capture their host-side collectives, and a failed capture leaves gloo unusable: eager)
-    use_graph = not a.no_graph and not (dist_on and os.environ.get("LFAMD_DIST_BACKEND", "nccl") != "nccl")
+    use_graph = not a.no_graph and not (dist_on and comm is None and os.environ.get("LFAMD_DIST_BACKEND", "nccl") != "nccl")
     graphs = {}
     dead = []  # failed capture objects are kept alive: destroying a half-captured graph can crash the runtime
     if use_graph:
@@ -445,7 +509,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist_on:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if comm is not None else dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed * 1000.0 / a.steps
@@ -536,7 +600,7 @@ def main():
     if rank != 0:
         if dist_on:
             torch.distributed.destroy_process_group()
-        return
+        return None
 
     tokens = a.prefill + a.decode
     out = {
@@ -559,7 +623,7 @@ def main():
                         "f32 accumulate, Q4_K and Q6_K on scaled operands f16(d*sc*q) x f16(d8*code) (<= 1e-3 relative, measured "
                         "~3e-4; exact integer codes with LFAMD_FLAG_PRECISE)",
             "model": a.model, "prefill_tokens": a.prefill, "decode_tokens": a.decode,
-            "parallelism": "single GPU" if world == 1 else f"tp{world} (RCCL all-reduce on attn_output/ffn_down)",
+            "parallelism": "single GPU" if world == 1 else f"tp{world} (all-reduce on attn_output/ffn_down: {comm.describe() if comm is not None else 'torch.distributed ' + os.environ.get('LFAMD_DIST_BACKEND', 'nccl')})",
             "hip_graph": use_graph, "weight_bytes_per_gpu": runner.weight_bytes(),
             "prefill_tokens_per_s": round(a.prefill / (pf_us * 1e-6), 1),
             "decode_tokens_per_s": round(1.0 / (dc_us * 1e-6), 1),
@@ -585,9 +649,9 @@ def main():
         out["cpu_baseline"] = cpu_baseline(layers, a.prefill, a.decode)
     else:
         out["cpu_baseline"] = None
-    print(json.dumps(out))
     if dist_on:
         torch.distributed.destroy_process_group()
+    return json.dumps(out)
 
 
 if __name__ == "__main__":

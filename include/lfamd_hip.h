@@ -147,6 +147,39 @@ int lfamd_mul_mat_id(int type, const void *d_W_packed, long rows, long cols, int
                      const int32_t *d_plan, int thinkers, float *d_result, void *d_workspace,
                      size_t workspace_bytes, unsigned flags, void *stream);
 
+/* ---- collectives (tensor parallel, one process per GPU) ---------------------------------------
+ * The exchange step of the sharded path: attn_output / ffn_down are split by input columns and
+ * the f32 partial sums of the residual stream are all-reduced; output.weight is split by vocabulary rows and the logits
+ * all-gathered.  The reference has no collective — its row split gathers every result on a main GPU with peer copies
+ * (ggml_cuda_op_mul_mat, ggml-cuda.cu.patch:17853-18153; :17781-17851, 18077-18121); these calls replace that step.
+ * All of them are asynchronous on `stream` and hipGraph-capturable.
+ *
+ * Bootstrap: rank 0 calls lfamd_comm_unique_id and hands the 128 bytes to every rank through whatever transport the
+ * host has (torch.distributed, MPI, a pipe); every rank calls lfamd_comm_init.  id128 may be NULL for world 1 or for a
+ * communicator that only ever uses the one-shot path.  RCCL (librccl.so.1) is dlopen()ed at that point, not before.
+ *
+ * One-shot all-reduce for decode-sized messages (n_embd * 4 bytes = 16-32 KB): every rank allocates an exchange block of
+ * lfamd_oneshot_bytes(max_message_bytes) device bytes (lfamd_malloc), exports it (64-byte IPC handle), the host gathers
+ * the world's handles in rank order and every rank attaches them (the host must barrier between attach and the first
+ * all-reduce).  lfamd_comm_allreduce_add_f32 then runs ONE kernel per call for messages that fit: publish (write-through),
+ * flag every peer, wait (bounded), sum the world's partials in rank order — bit-identical on every rank — and add the
+ * residual in the same pass.  Larger messages (the 8-16 MB prefill tensors) go through ncclAllReduce.
+ * lfamd_comm_check() != 0 reports a peer that never arrived (the kernels do not hang). */
+typedef struct lfamd_comm lfamd_comm;
+int lfamd_comm_unique_id(void *id128);
+int lfamd_comm_init(lfamd_comm **comm, int rank, int world, const void *id128);
+int lfamd_comm_destroy(lfamd_comm *comm);
+size_t lfamd_oneshot_bytes(size_t max_message_bytes);
+int lfamd_oneshot_export(void *d_block, void *handle64);
+int lfamd_oneshot_attach(lfamd_comm *comm, void *d_local_block, size_t block_bytes, const void *handles_world_x_64,
+                         size_t max_message_bytes);
+/* d_out = (d_residual ? d_residual : 0) + sum over ranks of d_partial   (d_out may alias d_partial) */
+int lfamd_comm_allreduce_add_f32(lfamd_comm *comm, const float *d_partial, const float *d_residual, float *d_out, long count,
+                                 void *stream);
+int lfamd_comm_allreduce_sum_f32(lfamd_comm *comm, float *d_inout, long count, void *stream);
+int lfamd_comm_allgather(lfamd_comm *comm, const void *d_send, void *d_recv, size_t bytes_per_rank, void *stream);
+int lfamd_comm_check(lfamd_comm *comm);
+
 /* ---- instrumentation ------------------------------------------------------------------------
  * Average device time (microseconds, HIP events on `stream`) of `iters` back-to-back launches of
  * the same lfamd_mul_mat call, after `warmup` untimed ones. */

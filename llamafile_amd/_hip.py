@@ -51,6 +51,16 @@ _SIGS = {
     "lfamd_mul_mat_multi_types": (_i, [_i, _vp, _vp, _vp, _l, _i, _vp, _sz, _l, _vp, _vp, _vp, _sz, _u, _vp]),
     "lfamd_mul_mat_id_workspace": (_sz, [_i, _l, _l, _i, _l, _i]),
     "lfamd_mul_mat_id": (_i, [_i, _vp, _l, _l, _i, _i, _vp, _sz, _i, _l, _vp, _i, _vp, _vp, _sz, _u, _vp]),
+    "lfamd_comm_unique_id": (_i, [_vp]),
+    "lfamd_comm_init": (_i, [C.POINTER(_vp), _i, _i, _vp]),
+    "lfamd_comm_destroy": (_i, [_vp]),
+    "lfamd_oneshot_bytes": (_sz, [_sz]),
+    "lfamd_oneshot_export": (_i, [_vp, _vp]),
+    "lfamd_oneshot_attach": (_i, [_vp, _vp, _sz, _vp, _sz]),
+    "lfamd_comm_allreduce_add_f32": (_i, [_vp, _vp, _vp, _vp, _l, _vp]),
+    "lfamd_comm_allreduce_sum_f32": (_i, [_vp, _vp, _l, _vp]),
+    "lfamd_comm_allgather": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "lfamd_comm_check": (_i, [_vp]),
     "lfamd_time_mul_mat": (_i, [_i, _vp, _l, _l, _i, _vp, _sz, _l, _vp, _l, _vp, _sz, _u, _vp, _i, _i,
                                 C.POINTER(C.c_float)]),
 }

@@ -90,6 +90,10 @@ const char *lfamd_last_error(void) {
     return g_err;
 }
 
+void lfamd_set_error(const char *msg) { // (for the module's other translation units: comm.hip, backend glue)
+    snprintf(g_err, sizeof(g_err), "%s", msg);
+}
+
 int lfamd_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess)

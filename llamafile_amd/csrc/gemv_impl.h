@@ -640,24 +640,6 @@ __device__ __forceinline__ void gemv_kq_body(const gemv_mats &mats, int nb, cons
 // Arithmetic (per-lane dot, wave reduction, fixed-order sum over the waves) is the body above's: results are
 // bit-identical.
 
-template <int CTRL>
-__device__ static inline uint32_t dpp_u32(uint32_t v) {
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
-}
-template <int CTRL>
-__device__ static inline float dpp_f32(float v) {
-    return __builtin_bit_cast(float, dpp_u32<CTRL>(__builtin_bit_cast(uint32_t, v)));
-}
-#define DPP_XOR1 0xB1        // quad_perm [1,0,3,2]
-#define DPP_XOR2 0x4E        // quad_perm [2,3,0,1]
-#define DPP_HALF_MIRROR 0x141
-#define DPP_MIRROR 0x140
-#define DPP_ROW_SHL4 0x104   // lane i reads lane i + 4 of its row of 16
-
-__device__ static inline float readlane_f32(float v, int l) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
-}
-
 // lane l holds codes y = (c[4l] .. c[4l+3]) of one 256-code block: write the code image, the group sums and the pair
 // sums (layout: XBLK above).  Two lanes form an 8-code group.
 __device__ static inline void put_codes_wave(uint8_t *dst, uint32_t y, int lane) {

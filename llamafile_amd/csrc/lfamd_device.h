@@ -150,6 +150,34 @@ __device__ static inline void q4k_scales_bytes(uint32_t a0, uint32_t a1, uint32_
     mn47 = ((a2 >> 4) & 0x0f0f0f0f) | ((a1 >> 2) & 0x30303030);
 }
 
+// ---- DPP lane exchanges (wave64 = 4 rows of 16 lanes): one VALU each instead of a ds_bpermute round trip
+template <int CTRL>
+__device__ static inline uint32_t dpp_u32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+}
+template <int CTRL>
+__device__ static inline float dpp_f32(float v) {
+    return __builtin_bit_cast(float, dpp_u32<CTRL>(__builtin_bit_cast(uint32_t, v)));
+}
+#define DPP_XOR1 0xB1        // quad_perm [1,0,3,2]
+#define DPP_XOR2 0x4E        // quad_perm [2,3,0,1]
+#define DPP_HALF_MIRROR 0x141
+#define DPP_MIRROR 0x140
+#define DPP_ROW_SHL4 0x104   // lane i reads lane i + 4 of its row of 16
+
+__device__ static inline float readlane_f32(float v, int l) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+
+// maximum over the wave's 64 lanes, in every lane (uniform)
+__device__ static inline float wave_max_f32(float v) {
+    v = fmaxf(v, dpp_f32<DPP_XOR1>(v));
+    v = fmaxf(v, dpp_f32<DPP_XOR2>(v));
+    v = fmaxf(v, dpp_f32<DPP_HALF_MIRROR>(v));
+    v = fmaxf(v, dpp_f32<DPP_MIRROR>(v));
+    return fmaxf(fmaxf(readlane_f32(v, 0), readlane_f32(v, 16)), fmaxf(readlane_f32(v, 32), readlane_f32(v, 48)));
+}
+
 __device__ static inline float wave_sum_xor(float v, int mask) {
     return v + __shfl_xor(v, mask, 64);
 }

@@ -502,16 +502,17 @@ __global__ __launch_bounds__(1024) void prep_scaled_kernel(const uint8_t *__rest
             dmax = fmaxf(dmax, block_amax(fv[0], dv[0]));
         }
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
-        dmax = fmaxf(dmax, __shfl_xor(dmax, off, 64));
+    // (DPP + readlane reductions: the ds_bpermute butterflies of the first version — about twenty LDS round trips per
+    // thread — made this 12 MB conversion take 7.5 us)
+    dmax = wave_max_f32(dmax);
     if (lane == 0)
         wmax[wave] = dmax;
     __syncthreads();
     dmax = wmax[lane & 15]; // (every wave reduces the 16 partial maxima itself)
-#pragma unroll
-    for (int off = 8; off > 0; off >>= 1)
-        dmax = fmaxf(dmax, __shfl_xor(dmax, off, 64));
+    dmax = fmaxf(dmax, dpp_f32<DPP_XOR1>(dmax));
+    dmax = fmaxf(dmax, dpp_f32<DPP_XOR2>(dmax));
+    dmax = fmaxf(dmax, dpp_f32<DPP_HALF_MIRROR>(dmax));
+    dmax = fmaxf(dmax, dpp_f32<DPP_MIRROR>(dmax));
     const bool ok = dmax > 0.0f && dmax < 3.0e38f; // (zero / non-finite rows: no normalisation)
     const float scale = ok ? ldexpf(1.0f, 9 - ilogbf(dmax)) : 1.0f;
     if (t == 0)
@@ -533,12 +534,9 @@ __global__ __launch_bounds__(1024) void prep_scaled_kernel(const uint8_t *__rest
             }
             // the block's largest |x| (one value through the butterfly), then the FIRST lane holding it: lanes are in index
             // order and `val` is already the lane's first such element, so this is quantize_row_q8_K's tie-break
-            float bmax = amax;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1)
-                bmax = fmaxf(bmax, __shfl_xor(bmax, off, 64));
-            const unsigned long long holders = __ballot(amax == bmax);
-            val = __shfl(val, (int)__ffsll((long long)holders) - 1, 64);
+            const float bmax = wave_max_f32(amax);
+            const unsigned long long holders = __builtin_amdgcn_ballot_w64(amax == bmax);
+            val = readlane_f32(val, holders ? __builtin_ctzll(holders) : 0);
             amax = bmax;
             (void)idx;
             if (amax != 0.0f) {
@@ -560,9 +558,9 @@ __global__ __launch_bounds__(1024) void prep_scaled_kernel(const uint8_t *__rest
         const half4_t h4 = {sat_f16((float)q[0] * xs), sat_f16((float)q[1] * xs), sat_f16((float)q[2] * xs), sat_f16((float)q[3] * xs)};
         *(half4_t *)(xo + 4 * lane) = h4;
         int S = q[0] + q[1] + q[2] + q[3]; // pair sum j = lane / 8 covers codes 32j .. 32j+31
-        S += __shfl_xor(S, 1, 64);
-        S += __shfl_xor(S, 2, 64);
-        S += __shfl_xor(S, 4, 64);
+        S += (int)dpp_u32<DPP_XOR1>((uint32_t)S);
+        S += (int)dpp_u32<DPP_XOR2>((uint32_t)S);
+        S += (int)dpp_u32<DPP_HALF_MIRROR>((uint32_t)S);
         if ((lane & 7) == 0) {
             _Float16 *mo = Xm + ((size_t)b * n_pad + tok) * 16;
             mo[lane >> 3] = sat_f16((float)S * xs);

@@ -54,3 +54,75 @@ def shard_activation(x: np.ndarray, t: int, mode: str, rank: int, world: int) ->
         return x
     c0, c1 = col_range(x.shape[1], t, rank, world)
     return np.ascontiguousarray(x[:, c0:c1])
+
+
+class Comm:
+    """The C-ABI communicator (include/lfamd_hip.h, "collectives") bootstrapped over an existing torch.distributed
+    process group: RCCL inside the HIP module for any size (`use_rccl`), plus the one-shot peer all-reduce for messages of
+    up to `oneshot_bytes` (0 = none).  torch.distributed only carries the 128-byte id and the 64-byte IPC handles."""
+
+    def __init__(self, rank: int, world: int, use_rccl: bool = True, oneshot_bytes: int = 0, group=None):
+        import ctypes as C
+
+        import torch
+        import torch.distributed as dist
+
+        from . import _hip
+        self.L = _hip.lib()
+        self.rank, self.world = rank, world
+        self.h = C.c_void_p()
+        idbuf = None
+        if use_rccl and world > 1:
+            idb = (C.c_char * 128)()
+            if rank == 0:
+                _hip.check(self.L.lfamd_comm_unique_id(idb), "lfamd_comm_unique_id")
+            box = [bytes(idb)]
+            dist.broadcast_object_list(box, src=0, group=group)
+            idbuf = C.create_string_buffer(box[0], 128)
+        _hip.check(self.L.lfamd_comm_init(C.byref(self.h), rank, world, idbuf), "lfamd_comm_init")
+        self.block = None
+        if oneshot_bytes and world > 1:
+            nbytes = int(self.L.lfamd_oneshot_bytes(oneshot_bytes))
+            self.block = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+            hb = (C.c_char * 64)()
+            _hip.check(self.L.lfamd_oneshot_export(C.c_void_p(self.block.data_ptr()), hb), "lfamd_oneshot_export")
+            handles = [None] * world
+            dist.all_gather_object(handles, bytes(hb), group=group)
+            allh = C.create_string_buffer(b"".join(handles), 64 * world)
+            _hip.check(self.L.lfamd_oneshot_attach(self.h, C.c_void_p(self.block.data_ptr()), nbytes, allh, oneshot_bytes),
+                       "lfamd_oneshot_attach")
+            dist.barrier(group=group)  # every rank's flag block is zeroed and mapped before the first all-reduce
+
+    def allreduce_add(self, partial, residual=None, out=None):
+        """out = residual + sum over ranks of partial (f32, on the current stream)."""
+        import ctypes as C
+
+        import torch
+
+        from . import _hip
+        out = partial if out is None else out
+        rc = self.L.lfamd_comm_allreduce_add_f32(self.h, C.c_void_p(partial.data_ptr()),
+                                                 C.c_void_p(residual.data_ptr()) if residual is not None else None,
+                                                 C.c_void_p(out.data_ptr()), partial.numel(),
+                                                 C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        _hip.check(rc, "lfamd_comm_allreduce_add_f32")
+        return out
+
+    def allgather(self, send, recv):
+        import ctypes as C
+
+        import torch
+
+        from . import _hip
+        rc = self.L.lfamd_comm_allgather(self.h, C.c_void_p(send.data_ptr()), C.c_void_p(recv.data_ptr()),
+                                         send.numel() * send.element_size(), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        _hip.check(rc, "lfamd_comm_allgather")
+        return recv
+
+    def check(self) -> int:
+        return int(self.L.lfamd_comm_check(self.h))
+
+    def close(self):
+        if self.h:
+            self.L.lfamd_comm_destroy(self.h)
+            self.h = None

@@ -1,0 +1,101 @@
+"""Two tensor-parallel ranks on ONE device (gloo carries the bootstrap; both processes use cuda:0): the HIP kernels on
+their shard shapes, the exchange step through the C ABI's one-shot peer all-reduce (IPC-shared exchange blocks,
+write-through stores, flags, rank-order sum + fused residual add), compared with the oracle on the unsharded problem.
+Replaces the reference's main-GPU gather (ggml-cuda.cu.patch:17853-18153).  What one device cannot show — coherence
+between two GPUs' caches over xGMI — is stated in DESIGN.md; the protocol uses system-scope (sc0 sc1) accesses only."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from llamafile_amd import ggml_types as T, sgemm, synth, tp
+        torch.cuda.set_device(0)
+        sgemm.init(0)
+        comm = tp.Comm(rank, world, use_rccl=False, oneshot_bytes=64 * 1024)
+        res = {}
+        for t, m, k in [(T.Q4_K, 4096, 4096), (T.Q6_K, 4096, 14336), (T.Q4_K, 8192, 8192)]:
+            A = synth.random_weights(t, m, k, 5)  # same seed on every rank: the "model"
+            x = synth.random_activations(1, k, 6)
+            resid = synth.random_activations(1, m, 7)
+            Al, ml, kl = tp.shard_weight(A, t, m, k, "cols", rank, world)
+            xl = tp.shard_activation(x, t, "cols", rank, world)
+            W = sgemm.upload_weights(t, Al, ml, kl)
+            part = sgemm.mul_mat(W, torch.from_numpy(xl).cuda().view(torch.uint8).view(1, kl * 4), T.F32, n=1)
+            rd = torch.from_numpy(resid).cuda()
+            outs = []
+            for rep in range(3):  # consecutive calls alternate the two slots and advance the sequence number
+                out = torch.empty_like(part)
+                comm.allreduce_add(part, rd, out)
+                outs.append(out)
+            torch.cuda.synchronize()
+            assert comm.check() == 0
+            assert all(torch.equal(outs[0], o) for o in outs[1:])
+            res[(t, m, k)] = (outs[0].cpu().numpy(), part.cpu().numpy())
+        # a message too large for the slot and no RCCL communicator: refused, not silently wrong
+        big = torch.zeros(1 << 20, device="cuda")
+        try:
+            comm.allreduce_add(big)
+            refused = False
+        except Exception:
+            refused = True
+        q.put((rank, res, refused))
+        dist.barrier()
+        comm.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_hip_shards_and_oneshot_allreduce(gpu, oracle):
+    import torch.multiprocessing as mp
+    from llamafile_amd import ggml_types as T, synth
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(2):
+        rank, res, refused = q.get(timeout=300)
+        got[rank] = res
+        assert refused
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for key in got[0]:
+        t, m, k = key
+        out0, part0 = got[0][key]
+        out1, part1 = got[1][key]
+        assert np.array_equal(out0, out1), "ranks disagree"  # rank-order sum: bit-identical everywhere
+        resid = synth.random_activations(1, m, 7)
+        assert np.array_equal(out0, (resid + part0) + part1)  # residual + rank 0 + rank 1, in that order
+        A = synth.random_weights(t, m, k, 5)
+        x = synth.random_activations(1, k, 6)
+        rows = np.arange(0, m, 61)
+        ok, G = oracle.sgemm(t, np.ascontiguousarray(A[rows]), T.Q8_K, synth.quantize_activations(T.Q8_K, x), len(rows), 1, k, nth=4)
+        assert ok == 1
+        want = G + resid[:, rows]
+        assert np.abs(out0[:, rows] - want).max() <= 2e-6 * np.abs(want).max()
