@@ -147,6 +147,19 @@ int lfamd_mul_mat_id(int type, const void *d_W_packed, long rows, long cols, int
                      const int32_t *d_plan, int thinkers, float *d_result, void *d_workspace,
                      size_t workspace_bytes, unsigned flags, void *stream);
 
+/* ---- F16 batched GEMM (attention KQ / KQV) ------------------------------------------------------
+ * The interface of tinyblasGemmStridedBatchedEx / tinyblasGemmBatchedEx (llamafile/tinyblas.h:59-71, tinyblas.cu:652-857)
+ * for the operand arrangement ggml calls them with (ggml_cuda_mul_mat_batched_cublas, ggml-cuda.cu.patch:18231-18376):
+ * transa = T, transb = N, f16 operands, result type Ctype = F16 or F32, f32 accumulation on MFMA:
+ *     C_b[j * ldc + i] = alpha * sum_l A_b[i * lda + l] * B_b[j * ldb + l] + beta * C_b[j * ldc + i],   b < batch
+ * Leading dimensions and strides in ELEMENTS (lda, ldb >= k; ldc >= m); beta is only applied when nonzero.  The
+ * pointer-array form takes DEVICE arrays of `batch` device pointers. */
+int lfamd_gemm_strided_batched_f16(long m, long n, long k, float alpha, const void *d_A, long lda, long long strideA,
+                                   const void *d_B, long ldb, long long strideB, float beta, void *d_C, int Ctype, long ldc,
+                                   long long strideC, int batch, void *stream);
+int lfamd_gemm_batched_f16(long m, long n, long k, float alpha, const void *const *d_Aarray, long lda, const void *const *d_Barray,
+                           long ldb, float beta, void *const *d_Carray, int Ctype, long ldc, int batch, void *stream);
+
 /* ---- collectives (tensor parallel, one process per GPU) ---------------------------------------
  * The exchange step of the sharded path: attn_output / ffn_down are split by input columns and
  * the f32 partial sums of the residual stream are all-reduced; output.weight is split by vocabulary rows and the logits
