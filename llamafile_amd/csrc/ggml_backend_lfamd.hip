@@ -1,0 +1,511 @@
+// ggml_backend_lfamd.hip — the 12 GGML_CALL (ms_abi) symbols llamafile/cuda.c:726-737 imports from ggml-rocm.so, served by
+// this module: a ggml backend whose supports_op says yes to GGML_OP_MUL_MAT / GGML_OP_MUL_MAT_ID only.
+//
+// Reference counterparts: ggml_cuda_link (ggml-cuda.cu.patch:468), the buffer interface (:16890-17027, set_tensor :16971),
+// the buffer type (:17040-17100, row padding :17072-17081), supports_op (:19221-19262), graph_compute (:18945),
+// ggml_cuda_mul_mat / _mul_mat_id (:18377-18443, 18499-18635), reg_devices (:19594-19610), device queries (:19532-19575).
+// Layouts: include/ggml_backend_lfamd.h.  Arithmetic: none here — every product goes through include/lfamd_hip.h.
+//
+// Weights: the host's set_tensor delivers raw GGUF rows into the buffer; the first mat-mul that uses a tensor of a
+// WEIGHTS buffer packs it once into the module's layout (kept until the buffer is freed or the tensor rewritten); src0
+// of any other buffer (the KV cache as KQ / KQV operand) is packed per call.
+#include "lfamd_device.h"
+#include "../../include/ggml_backend_lfamd.h"
+#include "../../include/lfamd_hip.h"
+
+#include <stdio.h>
+#include <string.h>
+
+#include <mutex>
+#include <unordered_map>
+
+namespace {
+
+const ggml_backend_api *g_api = nullptr;
+int g_op_mul_mat = -1, g_op_mul_mat_id = -1;
+bool g_linked = false;
+
+void logf(const char *fmt, const char *a = "", const char *b = "") {
+    if (g_api && g_api->FLAG_log_disable && *g_api->FLAG_log_disable)
+        return;
+    fprintf(stderr, fmt, a, b);
+}
+
+struct type_row {
+    int id;
+    const char *name;
+};
+// the types this module has kernels for, with upstream's names (ggml.c type_traits[].type_name)
+const type_row k_types[] = {{LFAMD_TYPE_F32, "f32"},   {LFAMD_TYPE_F16, "f16"},   {LFAMD_TYPE_Q4_0, "q4_0"}, {LFAMD_TYPE_Q4_1, "q4_1"},
+                            {LFAMD_TYPE_Q5_0, "q5_0"}, {LFAMD_TYPE_Q5_1, "q5_1"}, {LFAMD_TYPE_Q8_0, "q8_0"}, {LFAMD_TYPE_Q2_K, "q2_K"},
+                            {LFAMD_TYPE_Q3_K, "q3_K"}, {LFAMD_TYPE_Q4_K, "q4_K"}, {LFAMD_TYPE_Q5_K, "q5_K"}, {LFAMD_TYPE_Q6_K, "q6_K"},
+                            {LFAMD_TYPE_IQ4_XS, "iq4_xs"}, {LFAMD_TYPE_BF16, "bf16"}};
+
+bool type_ok(int t) {
+    for (const type_row &r : k_types)
+        if (r.id == t)
+            return true;
+    return false;
+}
+
+// ---- packed copies of weight tensors
+struct packed {
+    void *d = nullptr;
+    size_t bytes = 0;
+    int type;
+    long rows, cols;
+    size_t row_bytes;
+    bool exact_only = false;
+};
+std::mutex g_mu;
+std::unordered_map<const void *, packed> g_packed; // key: device address of the raw slice
+
+void drop_range(const uint8_t *lo, const uint8_t *hi) {
+    for (auto it = g_packed.begin(); it != g_packed.end();) {
+        const uint8_t *p = (const uint8_t *)it->first;
+        if (p >= lo && p < hi) {
+            (void)hipFree(it->second.d);
+            it = g_packed.erase(it);
+        } else {
+            ++it;
+        }
+    }
+}
+
+struct buffer_ctx {
+    void *base;
+    size_t size;
+};
+
+struct backend_ctx {
+    int device;
+    void *scratch = nullptr; // per-call packed src0 of non-weight buffers
+    size_t scratch_cap = 0;
+    void *ws = nullptr;
+    size_t ws_cap = 0;
+    void *plan = nullptr; // contiguous copy of a strided ids tensor
+    size_t plan_cap = 0;
+};
+
+bool grow(void *&p, size_t &cap, size_t need) {
+    if (need <= cap)
+        return true;
+    if (p)
+        (void)hipFree(p);
+    p = nullptr, cap = 0;
+    if (hipMalloc(&p, need + need / 4 + 256) != hipSuccess)
+        return false;
+    cap = need + need / 4 + 256;
+    return true;
+}
+
+// ------------------------------------------------------------------ buffer interface
+GGML_CALL const char *buf_get_name(ggml_backend_buffer_t) {
+    return "ROCm-lfamd";
+}
+GGML_CALL void buf_free(ggml_backend_buffer_t buffer) {
+    buffer_ctx *c = (buffer_ctx *)buffer->context;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        drop_range((const uint8_t *)c->base, (const uint8_t *)c->base + c->size);
+    }
+    (void)hipFree(c->base);
+    delete c;
+}
+GGML_CALL void *buf_get_base(ggml_backend_buffer_t buffer) {
+    return ((buffer_ctx *)buffer->context)->base;
+}
+GGML_CALL void buf_init_tensor(ggml_backend_buffer_t, struct ggml_tensor *) {}
+GGML_CALL void buf_set_tensor(ggml_backend_buffer_t, struct ggml_tensor *tensor, const void *data, size_t offset, size_t size) {
+    (void)hipMemcpy((uint8_t *)tensor->data + offset, data, size, hipMemcpyHostToDevice);
+    std::lock_guard<std::mutex> lk(g_mu); // the tensor's packed copies are stale now
+    drop_range((const uint8_t *)tensor->data, (const uint8_t *)tensor->data + g_api->ggml_nbytes(tensor));
+}
+GGML_CALL void buf_get_tensor(ggml_backend_buffer_t, const struct ggml_tensor *tensor, void *data, size_t offset, size_t size) {
+    (void)hipMemcpy(data, (const uint8_t *)tensor->data + offset, size, hipMemcpyDeviceToHost);
+}
+GGML_CALL bool buf_cpy_tensor(ggml_backend_buffer_t, const struct ggml_tensor *src, struct ggml_tensor *dst) {
+    if (src->buffer && src->buffer->iface.get_name == buf_get_name) {
+        (void)hipMemcpy(dst->data, src->data, g_api->ggml_nbytes(src), hipMemcpyDeviceToDevice);
+        std::lock_guard<std::mutex> lk(g_mu);
+        drop_range((const uint8_t *)dst->data, (const uint8_t *)dst->data + g_api->ggml_nbytes(dst));
+        return true;
+    }
+    return false;
+}
+GGML_CALL void buf_clear(ggml_backend_buffer_t buffer, uint8_t value) {
+    buffer_ctx *c = (buffer_ctx *)buffer->context;
+    (void)hipMemset(c->base, value, c->size);
+    (void)hipDeviceSynchronize();
+}
+const ggml_backend_buffer_i k_buffer_iface = {buf_get_name, buf_free, buf_get_base, buf_init_tensor, buf_set_tensor,
+                                              buf_get_tensor, buf_cpy_tensor, buf_clear, nullptr};
+
+// ------------------------------------------------------------------ buffer type
+GGML_CALL const char *buft_get_name(ggml_backend_buffer_type_t) {
+    return "ROCm-lfamd";
+}
+GGML_CALL ggml_backend_buffer_t buft_alloc(ggml_backend_buffer_type_t buft, size_t size) {
+    void *p = nullptr;
+    if (hipMalloc(&p, size ? size : 256) != hipSuccess) {
+        logf("%s: allocating a device buffer failed\n", "ggml_backend_lfamd");
+        return nullptr;
+    }
+    buffer_ctx *c = new buffer_ctx{p, size};
+    return g_api->ggml_backend_buffer_init(buft, k_buffer_iface, c, size);
+}
+GGML_CALL size_t buft_alignment(ggml_backend_buffer_type_t) {
+    return 128;
+}
+// the reference pads quantised tensors so that the last row can be read to a multiple of 512 elements
+// (MATRIX_ROW_PADDING, ggml-cuda.cu.patch:17072-17081); kept, so that allocation sizes match what llama.cpp budgets
+GGML_CALL size_t buft_alloc_size(ggml_backend_buffer_type_t, const struct ggml_tensor *tensor) {
+    size_t size = g_api->ggml_nbytes(tensor);
+    const int64_t ne0 = tensor->ne[0];
+    if (g_api->ggml_is_quantized(tensor->type) && ne0 % 512 != 0)
+        size += g_api->ggml_row_size(tensor->type, 512 - ne0 % 512);
+    return size;
+}
+ggml_backend_buffer_type g_buft = {{buft_get_name, buft_alloc, buft_alignment, nullptr, buft_alloc_size, nullptr}, nullptr};
+
+// ------------------------------------------------------------------ mat-mul nodes
+bool row_major(const struct ggml_tensor *t) { // elements of a row contiguous, rows / slices at any stride
+    return t->nb[0] == g_api->ggml_type_size(t->type);
+}
+
+// packed device copy of the (i02, i03) slice of src0
+const packed *get_packed(backend_ctx *ctx, const struct ggml_tensor *a, int64_t i02, int64_t i03, packed *tmp) {
+    const uint8_t *raw = (const uint8_t *)a->data + i02 * a->nb[2] + i03 * a->nb[3];
+    const long rows = (long)a->ne[1], cols = (long)a->ne[0];
+    const size_t need = lfamd_packed_size(a->type, rows, cols);
+    const bool keep = a->buffer && g_api->ggml_backend_buffer_get_usage(a->buffer) == GGML_BACKEND_BUFFER_USAGE_WEIGHTS;
+    if (keep) {
+        auto it = g_packed.find(raw);
+        if (it != g_packed.end() && it->second.type == a->type && it->second.rows == rows && it->second.cols == cols &&
+            it->second.row_bytes == a->nb[1])
+            return &it->second;
+    }
+    packed p;
+    p.bytes = need, p.type = a->type, p.rows = rows, p.cols = cols, p.row_bytes = a->nb[1];
+    if (keep) {
+        if (hipMalloc(&p.d, need ? need : 16) != hipSuccess)
+            return nullptr;
+    } else {
+        if (!grow(ctx->scratch, ctx->scratch_cap, need))
+            return nullptr;
+        p.d = ctx->scratch;
+    }
+    if (lfamd_pack_weights(a->type, rows, cols, raw, a->nb[1], p.d, nullptr) != LFAMD_OK) {
+        if (keep)
+            (void)hipFree(p.d);
+        return nullptr;
+    }
+    const int in_range = lfamd_scaled_gemm_ok(a->type, rows, cols, p.d, nullptr);
+    p.exact_only = in_range == 0;
+    if (keep)
+        return &(g_packed[raw] = p);
+    *tmp = p;
+    return tmp;
+}
+
+bool mul_mat_supported(const struct ggml_tensor *op) {
+    const struct ggml_tensor *a = op->src[0], *b = op->src[1];
+    if (!a || !b || !type_ok(a->type) || b->type != LFAMD_TYPE_F32 || op->type != LFAMD_TYPE_F32)
+        return false;
+    if (!row_major(a) || !row_major(b) || !g_api->ggml_is_contiguous(op))
+        return false;
+    if (a->ne[0] != b->ne[0] || a->ne[0] % lfamd_blck_size(a->type))
+        return false;
+    if (lfamd_packed_size(a->type, (long)a->ne[1], (long)a->ne[0]) == 0 && a->ne[1] && a->ne[0])
+        return false;
+    return true;
+}
+
+enum ggml_status run_mul_mat(backend_ctx *ctx, struct ggml_tensor *dst) {
+    const struct ggml_tensor *a = dst->src[0], *b = dst->src[1];
+    const long m = (long)a->ne[1], k = (long)a->ne[0], n = (long)b->ne[1];
+    if (m == 0 || n == 0)
+        return GGML_STATUS_SUCCESS;
+    // broadcast over dims 2 / 3 like ggml_compute_forward_mul_mat (upstream; ggml.c.patch:1942-2022): src1 slice (i12, i13)
+    // uses src0 slice (i12 / r2, i13 / r3)
+    const int64_t r2 = b->ne[2] / (a->ne[2] ? a->ne[2] : 1), r3 = b->ne[3] / (a->ne[3] ? a->ne[3] : 1);
+    const size_t wsb = lfamd_mul_mat_workspace(a->type, m, k, n);
+    if (!grow(ctx->ws, ctx->ws_cap, wsb))
+        return GGML_STATUS_ALLOC_FAILED;
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (int64_t i13 = 0; i13 < b->ne[3]; i13++)
+        for (int64_t i12 = 0; i12 < b->ne[2]; i12++) {
+            packed tmp;
+            const packed *w = get_packed(ctx, a, i12 / (r2 ? r2 : 1), i13 / (r3 ? r3 : 1), &tmp);
+            if (!w)
+                return GGML_STATUS_ALLOC_FAILED;
+            const uint8_t *bp = (const uint8_t *)b->data + i12 * b->nb[2] + i13 * b->nb[3];
+            float *cp = (float *)((uint8_t *)dst->data + i12 * dst->nb[2] + i13 * dst->nb[3]);
+            if (lfamd_mul_mat(a->type, w->d, m, k, LFAMD_TYPE_F32, bp, b->nb[1], n, cp, (long)(dst->nb[1] / sizeof(float)), ctx->ws,
+                              ctx->ws_cap, (w->exact_only ? LFAMD_FLAG_PRECISE : 0u) | LFAMD_FLAG_Q0_VREGS32, nullptr) != LFAMD_OK) {
+                logf("%s: lfamd_mul_mat: %s\n", "ggml_backend_lfamd", lfamd_last_error());
+                return GGML_STATUS_FAILED;
+            }
+        }
+    return GGML_STATUS_SUCCESS;
+}
+
+bool mul_mat_id_supported(const struct ggml_tensor *op) {
+    const struct ggml_tensor *as = op->src[0], *b = op->src[1], *ids = op->src[2];
+    if (!as || !b || !ids || !type_ok(as->type) || lfamd_blck_size(as->type) == 1 || b->type != LFAMD_TYPE_F32 ||
+        op->type != LFAMD_TYPE_F32 || ids->type != LFAMD_TYPE_I32)
+        return false;
+    if (!g_api->ggml_is_contiguous(as) || !g_api->ggml_is_contiguous(b) || !g_api->ggml_is_contiguous(op) || as->ne[3] != 1)
+        return false;
+    if (b->ne[1] != 1 && b->ne[1] != ids->ne[0])
+        return false;
+    return as->ne[0] % lfamd_blck_size(as->type) == 0 && lfamd_packed_size(as->type, (long)as->ne[1], (long)as->ne[0]) != 0;
+}
+
+enum ggml_status run_mul_mat_id(backend_ctx *ctx, struct ggml_tensor *dst) {
+    const struct ggml_tensor *as = dst->src[0], *b = dst->src[1], *ids = dst->src[2];
+    const long rows = (long)as->ne[1], cols = (long)as->ne[0], tokens = (long)b->ne[2];
+    const int experts = (int)as->ne[2], thinkers = (int)ids->ne[0], tasks = (int)b->ne[1];
+    if (!rows || !tokens || !thinkers)
+        return GGML_STATUS_SUCCESS;
+    const size_t one = lfamd_packed_size(as->type, rows, cols);
+    std::lock_guard<std::mutex> lk(g_mu);
+    // the whole expert stack packed back to back under the stack's address
+    const packed *w = nullptr;
+    packed tmp;
+    {
+        const bool keep = as->buffer && g_api->ggml_backend_buffer_get_usage(as->buffer) == GGML_BACKEND_BUFFER_USAGE_WEIGHTS;
+        auto it = g_packed.find(as->data);
+        if (keep && it != g_packed.end() && it->second.type == as->type && it->second.rows == rows * experts && it->second.cols == cols) {
+            w = &it->second;
+        } else {
+            packed p;
+            p.bytes = one * experts, p.type = as->type, p.rows = rows * experts, p.cols = cols, p.row_bytes = as->nb[1];
+            if (keep) {
+                if (hipMalloc(&p.d, p.bytes) != hipSuccess)
+                    return GGML_STATUS_ALLOC_FAILED;
+            } else {
+                if (!grow(ctx->scratch, ctx->scratch_cap, p.bytes))
+                    return GGML_STATUS_ALLOC_FAILED;
+                p.d = ctx->scratch;
+            }
+            for (int e = 0; e < experts; e++)
+                if (lfamd_pack_weights(as->type, rows, cols, (const uint8_t *)as->data + (size_t)e * as->nb[2], as->nb[1],
+                                       (uint8_t *)p.d + (size_t)e * one, nullptr) != LFAMD_OK)
+                    return GGML_STATUS_FAILED;
+            p.exact_only = lfamd_scaled_gemm_ok(as->type, (long)experts * ((rows + 31) / 32) * 32, cols, p.d, nullptr) == 0;
+            if (keep) {
+                w = &(g_packed[as->data] = p);
+            } else {
+                tmp = p;
+                w = &tmp;
+            }
+        }
+    }
+    // routing table as contiguous int32 [tokens][thinkers]
+    const int32_t *plan = (const int32_t *)ids->data;
+    if (ids->nb[1] != (size_t)thinkers * 4) {
+        if (!grow(ctx->plan, ctx->plan_cap, (size_t)tokens * thinkers * 4))
+            return GGML_STATUS_ALLOC_FAILED;
+        if (hipMemcpy2D(ctx->plan, (size_t)thinkers * 4, ids->data, ids->nb[1], (size_t)thinkers * 4, tokens, hipMemcpyDeviceToDevice) !=
+            hipSuccess)
+            return GGML_STATUS_FAILED;
+        plan = (const int32_t *)ctx->plan;
+    }
+    const size_t wsb = lfamd_mul_mat_id_workspace(as->type, rows, cols, experts, tokens, thinkers);
+    if (!grow(ctx->ws, ctx->ws_cap, wsb))
+        return GGML_STATUS_ALLOC_FAILED;
+    if (lfamd_mul_mat_id(as->type, w->d, rows, cols, experts, LFAMD_TYPE_F32, b->data, b->nb[1], tasks, tokens, plan, thinkers,
+                         (float *)dst->data, ctx->ws, ctx->ws_cap, (w->exact_only ? LFAMD_FLAG_PRECISE : 0u) | LFAMD_FLAG_Q0_VREGS32,
+                         nullptr) != LFAMD_OK) {
+        logf("%s: lfamd_mul_mat_id: %s\n", "ggml_backend_lfamd", lfamd_last_error());
+        return GGML_STATUS_FAILED;
+    }
+    return GGML_STATUS_SUCCESS;
+}
+
+// ------------------------------------------------------------------ backend interface
+GGML_CALL const char *be_get_name(ggml_backend_t) {
+    return "ROCm-lfamd";
+}
+GGML_CALL void be_free(ggml_backend_t backend) {
+    backend_ctx *c = (backend_ctx *)backend->context;
+    (void)hipDeviceSynchronize();
+    if (c->scratch)
+        (void)hipFree(c->scratch);
+    if (c->ws)
+        (void)hipFree(c->ws);
+    if (c->plan)
+        (void)hipFree(c->plan);
+    delete c;
+    delete backend;
+}
+GGML_CALL ggml_backend_buffer_type_t be_default_buft(ggml_backend_t) {
+    return &g_buft;
+}
+GGML_CALL void be_synchronize(ggml_backend_t) {
+    (void)hipDeviceSynchronize();
+}
+GGML_CALL enum ggml_status be_graph_compute(ggml_backend_t backend, struct ggml_cgraph *cgraph) {
+    backend_ctx *c = (backend_ctx *)backend->context;
+    for (int i = 0; i < cgraph->n_nodes; i++) {
+        struct ggml_tensor *node = cgraph->nodes[i];
+        enum ggml_status st = GGML_STATUS_SUCCESS;
+        if (node->op == g_op_mul_mat)
+            st = run_mul_mat(c, node);
+        else if (node->op == g_op_mul_mat_id)
+            st = run_mul_mat_id(c, node);
+        else if (g_api->ggml_is_empty(node))
+            continue;
+        else {
+            const char *name = g_api->ggml_op_name(node->op);
+            // views of this backend's tensors carry no work (the scheduler keeps them with their source)
+            if (!strcmp(name, "NONE") || !strcmp(name, "RESHAPE") || !strcmp(name, "VIEW") || !strcmp(name, "PERMUTE") ||
+                !strcmp(name, "TRANSPOSE"))
+                continue;
+            logf("%s: op %s is not supported by this backend\n", "ggml_backend_lfamd", name);
+            return GGML_STATUS_FAILED;
+        }
+        if (st != GGML_STATUS_SUCCESS)
+            return st;
+    }
+    return hipDeviceSynchronize() == hipSuccess ? GGML_STATUS_SUCCESS : GGML_STATUS_FAILED;
+}
+GGML_CALL bool be_supports_op(ggml_backend_t, const struct ggml_tensor *op) {
+    if (op->op == g_op_mul_mat)
+        return mul_mat_supported(op);
+    if (op->op == g_op_mul_mat_id)
+        return mul_mat_id_supported(op);
+    const char *name = g_api->ggml_op_name(op->op);
+    return !strcmp(name, "NONE") || !strcmp(name, "RESHAPE") || !strcmp(name, "VIEW") || !strcmp(name, "PERMUTE") ||
+           !strcmp(name, "TRANSPOSE");
+}
+GGML_CALL bool be_supports_buft(ggml_backend_t, ggml_backend_buffer_type_t buft) {
+    return buft == &g_buft;
+}
+GGML_CALL bool be_offload_op(ggml_backend_t, const struct ggml_tensor *) {
+    return false; // weights live in this backend's buffers; nothing is pulled over per batch
+}
+const ggml_backend_i k_backend_iface = {be_get_name, be_free, be_default_buft, nullptr, nullptr, nullptr, be_synchronize,
+                                        nullptr,     nullptr, nullptr,         nullptr, be_graph_compute, be_supports_op,
+                                        be_supports_buft, be_offload_op, nullptr, nullptr, nullptr, nullptr, nullptr};
+ggml_guid g_guid = {0x6c, 0x66, 0x61, 0x6d, 0x64, 0x2d, 0x6d, 0x69, 0x33, 0x35, 0x35, 0x78, 0x2d, 0x72, 0x30, 0x32};
+
+GGML_CALL ggml_backend_t reg_init(const char *, void *user_data) {
+    return ggml_backend_cuda_init((int)(intptr_t)user_data);
+}
+
+} // namespace
+
+extern "C" {
+
+GGML_CALL bool ggml_cuda_link(const struct ggml_backend_api *backend_api) {
+    g_api = backend_api;
+    g_linked = false;
+    if (!backend_api)
+        return false;
+    // operator numbers from the host's own table (un-vendored enum: never assumed)
+    g_op_mul_mat = g_op_mul_mat_id = -1;
+    for (int i = 0; i < 40 && (g_op_mul_mat < 0 || g_op_mul_mat_id < 0); i++) {
+        const char *n = backend_api->ggml_op_name(i);
+        if (!n)
+            continue;
+        if (!strcmp(n, "MUL_MAT"))
+            g_op_mul_mat = i;
+        else if (!strcmp(n, "MUL_MAT_ID"))
+            g_op_mul_mat_id = i;
+    }
+    if (g_op_mul_mat < 0 || g_op_mul_mat_id < 0) {
+        logf("%s: the host's ggml_op_name table has no MUL_MAT / MUL_MAT_ID below 40: refusing to link\n", "ggml_cuda_link");
+        return false;
+    }
+    // type numbers, block and element sizes must be the ones this module was built for
+    for (const type_row &r : k_types) {
+        const char *n = backend_api->ggml_type_name(r.id);
+        if (!n || strcmp(n, r.name) || backend_api->ggml_type_size(r.id) != lfamd_type_size(r.id) ||
+            backend_api->ggml_blck_size(r.id) != lfamd_blck_size(r.id)) {
+            logf("%s: ggml type %s does not match this module's block formats: refusing to link\n", "ggml_cuda_link", r.name);
+            return false;
+        }
+    }
+    if (lfamd_device_count() <= 0 || lfamd_init(0) != LFAMD_OK) {
+        logf("%s: no MI355X (gfx950) device: %s\n", "ggml_cuda_link", lfamd_last_error());
+        return false;
+    }
+    g_linked = true;
+    return true;
+}
+
+GGML_CALL int ggml_backend_cuda_get_device_count(void) {
+    return g_linked ? 1 : 0; // one backend per process and GPU (tensor parallelism: include/lfamd_hip.h, collectives)
+}
+
+GGML_CALL ggml_backend_buffer_type_t ggml_backend_cuda_buffer_type(int device) {
+    return device == 0 && g_linked ? &g_buft : nullptr;
+}
+
+GGML_CALL ggml_backend_buffer_type_t ggml_backend_cuda_host_buffer_type(void) {
+    return g_api ? g_api->ggml_backend_cpu_buffer_type() : nullptr; // (plain host memory; uploads go through set_tensor)
+}
+
+GGML_CALL ggml_backend_buffer_type_t ggml_backend_cuda_split_buffer_type(const float *) {
+    return g_linked ? &g_buft : nullptr; // no row split: layers shard over processes
+}
+
+GGML_CALL ggml_backend_t ggml_backend_cuda_init(int device) {
+    if (!g_linked || device != 0)
+        return nullptr;
+    backend_ctx *c = new backend_ctx;
+    c->device = device;
+    return new ggml_backend{&g_guid, k_backend_iface, c};
+}
+
+GGML_CALL int ggml_backend_cuda_reg_devices(void) {
+    const int n = ggml_backend_cuda_get_device_count();
+    for (int i = 0; i < n; i++) {
+        char name[32];
+        snprintf(name, sizeof name, "ROCm%d", i);
+        g_api->ggml_backend_register(name, reg_init, ggml_backend_cuda_buffer_type(i), (void *)(intptr_t)i);
+    }
+    return n;
+}
+
+GGML_CALL void ggml_backend_cuda_get_device_properties(int device, struct ggml_cuda_device_properties *properties) {
+    memset(properties, 0, sizeof *properties);
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, device) != hipSuccess)
+        return;
+    strncpy(properties->name, p.name, sizeof(properties->name) - 1);
+    properties->totalGlobalMem = p.totalGlobalMem;
+    properties->multiProcessorCount = p.multiProcessorCount;
+    properties->major = p.major;
+    properties->minor = p.minor;
+    strncpy(properties->compute, p.gcnArchName, sizeof(properties->compute) - 1);
+}
+
+GGML_CALL void ggml_backend_cuda_get_device_memory(int device, size_t *free, size_t *total) {
+    *free = *total = 0;
+    int cur = 0;
+    if (hipGetDevice(&cur) != hipSuccess || hipSetDevice(device) != hipSuccess)
+        return;
+    (void)hipMemGetInfo(free, total);
+    (void)hipSetDevice(cur);
+}
+
+GGML_CALL bool ggml_backend_cuda_register_host_buffer(void *buffer, size_t size) {
+    return hipHostRegister(buffer, size, hipHostRegisterPortable | hipHostRegisterReadOnly) == hipSuccess ||
+           hipHostRegister(buffer, size, hipHostRegisterPortable) == hipSuccess;
+}
+
+GGML_CALL void ggml_backend_cuda_unregister_host_buffer(void *buffer) {
+    (void)hipHostUnregister(buffer);
+}
+
+GGML_CALL void ggml_backend_cuda_get_device_description(int device, char *description, size_t description_size) {
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, device) == hipSuccess)
+        snprintf(description, description_size, "%s", p.name);
+    else if (description_size)
+        description[0] = 0;
+}
+}

@@ -1,0 +1,86 @@
+"""The GPU-module boundary: the 12 ms_abi symbols llamafile/cuda.c:726-737 imports, driven
+from a C host program that plays llamafile's side (tests/backend_host/backend_host.c): dlopen, symbol import,
+ggml_cuda_link with a ggml_backend_api callback table, buffers, set_tensor, supports_op, graph_compute, get_tensor."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from llamafile_amd import _hip, ggml_types as T, synth
+from helpers import rel_err
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "backend_host", "backend_host.c")
+EXE = os.path.join(ROOT, "tests", "backend_host", "backend_host")
+
+
+@pytest.fixture(scope="module")
+def host_exe():
+    if not os.path.exists(EXE) or os.path.getmtime(EXE) < os.path.getmtime(SRC):
+        subprocess.check_call(["gcc", "-O1", "-Wall", "-o", EXE, SRC, "-ldl"])
+    return EXE
+
+
+def test_module_exports_the_twelve_symbols_and_links_or_declines(host_exe):
+    """On a box without an MI355X ggml_cuda_link answers false (llamafile then falls back to the CPU, cuda.c:744-752)."""
+    out = subprocess.run([host_exe, _hip.HIP_SO, "exports"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.split()[0] in ("linked", "nolink")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("t,m,k,n,nb2", [(T.Q4_K, 96, 1024, 1, 1), (T.Q4_K, 160, 768, 40, 1), (T.Q6_K, 64, 512, 3, 2), (T.Q8_0, 72, 256, 1, 1),
+                                         (T.F16, 48, 256, 5, 3), (T.Q5_K, 32, 512, 12, 1), (T.Q4_0, 64, 256, 2, 1)],
+                         ids=lambda v: str(v))
+def test_mul_mat_node_through_the_backend_interface(gpu, oracle, host_exe, tmp_path, t, m, k, n, nb2):
+    """GGML_OP_MUL_MAT with f32 src1 and dims-2 broadcast (src1 has nb2 slices, src0 one): what
+    ggml_compute_forward_mul_mat computes — quantise src1 rows to the type's vec_dot format, llamafile_sgemm per slice."""
+    W = synth.random_weights(t, m, k, 7)
+    x = synth.random_activations(n * nb2, k, 8)
+    wp, xp, op = tmp_path / "w.bin", tmp_path / "x.bin", tmp_path / "o.bin"
+    W.tofile(wp)
+    x.tofile(xp)
+    r = subprocess.run([host_exe, _hip.HIP_SO, "mulmat", str(t), str(m), str(k), str(n), str(nb2), str(wp), str(xp), str(op)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stderr
+    got = np.fromfile(op, dtype=np.float32).reshape(nb2 * n, m)
+    bt = T.VEC_DOT[t]
+    if t == T.F16:
+        # ggml hands f16 weights their activations rounded to f16 (n > 2) or as f32 (n <= 2, tinyblas_cpu_sgemm.inc:121-136);
+        # the module keeps f32 activations for n <= 8: at least as accurate — within f16 rounding of either form
+        G16 = oracle.f64_gemm(t, W, T.F16, synth.quantize_activations(T.F16, x), m, n * nb2, k)
+        G32 = oracle.f64_gemm(t, W, T.F32, synth.quantize_activations(T.F32, x), m, n * nb2, k)
+        assert min(rel_err(got, G16), rel_err(got, G32)) <= 2e-6 and rel_err(got, G16) <= 1e-3
+        return
+    v = oracle.variant("zen4")  # the module passes LFAMD_FLAG_Q0_VREGS32 (AVX512 build of tinyBLAS_Q0)
+    for s in range(nb2):  # every slice is its own llamafile_sgemm problem (the Q0 Kahan geometry depends on n)
+        ok, G = oracle.sgemm(t, W, bt, synth.quantize_activations(bt, x[s * n:(s + 1) * n]), m, n, k, v=v)
+        assert ok == 1
+        g = got[s * n:(s + 1) * n]
+        if t == T.Q8_0:
+            assert np.array_equal(g.view(np.uint32), G.view(np.uint32))
+        else:
+            assert rel_err(g, G) <= (1e-3 if n > 8 else 2e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tokens,tasks", [(1, 1), (3, 2), (20, 1)])
+def test_mul_mat_id_node_through_the_backend_interface(gpu, oracle, host_exe, tmp_path, tokens, tasks):
+    t, m, k, experts, thinkers = T.Q4_K, 64, 512, 6, 2
+    W = np.stack([synth.random_weights(t, m, k, 50 + e) for e in range(experts)])
+    x = synth.random_activations(tokens * tasks, k, 9).reshape(tokens, tasks, k)
+    rng = np.random.default_rng(4)
+    ids = np.stack([rng.permutation(experts)[:thinkers] for _ in range(tokens)]).astype(np.int32)
+    wp, xp, ip, op = (tmp_path / n for n in ("w.bin", "x.bin", "i.bin", "o.bin"))
+    W.tofile(wp), x.tofile(xp), ids.tofile(ip)
+    r = subprocess.run([host_exe, _hip.HIP_SO, "mulmatid", str(t), str(m), str(k), str(experts), str(thinkers), str(tasks), str(tokens),
+                        str(wp), str(xp), str(ip), str(op)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stderr
+    got = np.fromfile(op, dtype=np.float32).reshape(tokens, thinkers, m)
+    q = oracle.quantize(T.Q8_K, x.reshape(-1, k))
+    for tk in range(tokens):
+        for th in range(thinkers):
+            ok, c = oracle.sgemm(t, W[ids[tk, th]], T.Q8_K, q[tk * tasks + th % tasks][None, :], m, 1, k)
+            assert ok == 1
+            assert rel_err(got[tk, th], c[0]) <= (1e-3 if tokens > 4 else 2e-6)
