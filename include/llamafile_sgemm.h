@@ -112,6 +112,25 @@ void llamafile_sgemm_amd_reset(void);
 /* FLAG_precise of the reference (--precise): Kahan summation in the Q8_0/Q4_0 kernels. */
 void llamafile_sgemm_amd_set_precise(int precise);
 
+/* ---- model files ----
+ * Minimal GGUF v2 / v3 reader (reference: gguf_init_from_file, upstream ggml.c; llamafile's changes at
+ * llama.cpp.patches/patches/ggml.c.patch:2503-2612).  The file is mapped read-only; a tensor is handed out as a pointer into
+ * that mapping — immutable bytes in the sense above, so llamafile_sgemm uploads and packs it once.  Tensor i: ne[0] = row
+ * length (k), ne[1] = rows (m); `nbytes` is 0 for a type without a block format here. */
+typedef struct lfamd_gguf lfamd_gguf;
+lfamd_gguf *lfamd_gguf_open(const char *path, char *err, size_t errlen);
+void lfamd_gguf_close(lfamd_gguf *g);
+int lfamd_gguf_version(const lfamd_gguf *g);
+long lfamd_gguf_n_tensors(const lfamd_gguf *g);
+long lfamd_gguf_n_kv(const lfamd_gguf *g);
+size_t lfamd_gguf_alignment(const lfamd_gguf *g);
+int lfamd_gguf_tensor(const lfamd_gguf *g, long i, const char **name, int *type, int *n_dims, int64_t ne[4], const void **data,
+                      size_t *nbytes);
+long lfamd_gguf_find_tensor(const lfamd_gguf *g, const char *name);
+int lfamd_gguf_get_u64(const lfamd_gguf *g, const char *key, uint64_t *v);
+int lfamd_gguf_get_f64(const lfamd_gguf *g, const char *key, double *v);
+const char *lfamd_gguf_get_str(const lfamd_gguf *g, const char *key);
+
 #ifdef __cplusplus
 }
 #endif
