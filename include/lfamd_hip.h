@@ -47,6 +47,10 @@ enum lfamd_status {
 #define LFAMD_FLAG_GEMM_NARROW 8u   /* testing: force the 128x64 split-K MFMA body (default: chosen by grid size) */
 #define LFAMD_FLAG_GEMM_WIDE 16u    /* testing: force the 128x128 MFMA body */
 #define LFAMD_FLAG_GEMM_PLAIN 32u   /* testing: the 128x128 body without loader waves (Q4_K / Q5_K default to them) */
+#define LFAMD_FLAG_Q80_EXACT 64u    /* Q8_0 batches (n > 8): the BIT-EXACT restatement of tinyBLAS_Q0's 8-lane chains (VALU, ~12x
+                                       slower) instead of the default MFMA body (exact integer block dots, f32 scales: within 2e-6
+                                       of the reference).  n <= 8 — the Q8_0 vecdot of the north star — is always bit-exact;
+                                       LFAMD_FLAG_PRECISE implies this flag. */
 
 int lfamd_abi_version(void);
 const char *lfamd_last_error(void);

@@ -19,6 +19,7 @@ FLAG_FORCE_GENERIC = 4
 FLAG_GEMM_NARROW = 8
 FLAG_GEMM_WIDE = 16
 FLAG_GEMM_PLAIN = 32
+FLAG_Q80_EXACT = 64
 
 
 class LfamdError(RuntimeError):

@@ -294,9 +294,19 @@ static bool use_gemm_float(int Atype, long n, unsigned flags, long k) {
     return !(flags & LFAMD_FLAG_FORCE_GENERIC) && n > 8 && k % 256 == 0 && (Atype == LFAMD_TYPE_F16 || Atype == LFAMD_TYPE_BF16);
 }
 
-// Q8_0 batches: the register-tiled bit-exact kernel (gemm_q80.hip)
-static bool use_gemm_q80(int Atype, long n, unsigned flags) {
-    return !(flags & LFAMD_FLAG_FORCE_GENERIC) && n > 8 && Atype == LFAMD_TYPE_Q8_0;
+// Q8_0 batches.  Default (rows of whole 256-weight groups): the MFMA body on a per-call byte image — exact integer block
+// dots, f32 block scales, <= 2e-6 of the reference; the north star asks for bit-exactness of the Q8_0 VECDOT (n <= 8: the
+// GEMV), not for replaying tinyBLAS's 8-lane chains at n = 512.  LFAMD_FLAG_PRECISE (or other row lengths): the
+// register-tiled BIT-EXACT kernel (gemm_q80.hip), 12x slower.
+static bool use_gemm_q80_mfma(int Atype, long n, unsigned flags, long k) {
+    return !(flags & (LFAMD_FLAG_FORCE_GENERIC | LFAMD_FLAG_PRECISE | LFAMD_FLAG_Q80_EXACT)) && n > 8 && Atype == LFAMD_TYPE_Q8_0 && k % 256 == 0;
+}
+static bool use_gemm_q80(int Atype, long n, unsigned flags, long k) {
+    return !(flags & LFAMD_FLAG_FORCE_GENERIC) && n > 8 && Atype == LFAMD_TYPE_Q8_0 && !use_gemm_q80_mfma(Atype, n, flags, k);
+}
+static size_t gemm_q80_mfma_ws(long m, long k, long n) { // Xh, d8T [nb*8][n_pad], image
+    size_t n_pad = align_up((size_t)n, 128), nb = (size_t)(k / 256);
+    return align_up(n_pad * (size_t)k * 2, 256) + align_up(nb * 8 * n_pad * 4, 256) + align_up(lfamd_wprep8_bytes(m, k), 256);
 }
 
 static bool use_gemv(int Atype, long n, unsigned flags, long k) {
@@ -320,8 +330,11 @@ size_t lfamd_mul_mat_workspace(int Atype, long m, long k, long n) {
         return align_up(n_pad * (size_t)k * 2, 256) + align_up(nb * n_pad * 4, 256) + align_up(n_pad * nb * 32, 256) +
                (Atype == LFAMD_TYPE_Q4_0 ? 0 : lfamd_gemm_lw_ksplit_bytes(m, n)); // partial tiles of a K-split launch
     }
-    if (use_gemm_q80(Atype, n, 0))
-        return align_up(lfamd_gemm_q80_workspace(k, n), 256);
+    if (Atype == LFAMD_TYPE_Q8_0 && n > 8) { // (either body may be asked for through the flags: the larger of the two)
+        const size_t exact = align_up(lfamd_gemm_q80_workspace(k, n), 256);
+        const size_t mfma = k % 256 == 0 ? gemm_q80_mfma_ws(m, k, n) : 0;
+        return exact > mfma ? exact : mfma;
+    }
     if (use_gemm_float(Atype, n, 0, k))
         return align_up(align_up((size_t)n, 128) * (size_t)k * 2, 256);
     if (use_gemm_canon(Atype, n, 0))
@@ -448,8 +461,21 @@ int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const v
         HIPCHK(lfamd_launch_gemm_wide(Atype, img, m, k, Xh, d8T, Xm, n, (long)n_pad, d_C, ldc, plain, nullptr, 0, s), "gemm_wide");
         return LFAMD_OK;
     }
-    if (use_gemm_q80(Atype, n, flags)) {
-        size_t need = lfamd_mul_mat_workspace(Atype, m, k, n);
+    if (use_gemm_q80_mfma(Atype, n, flags, k)) {
+        if (ws_bytes < gemm_q80_mfma_ws(m, k, n) || !d_ws)
+            return fail(LFAMD_ERR_WORKSPACE, "mul_mat: workspace too small%s", "");
+        size_t n_pad = align_up((size_t)n, 128), nb = (size_t)(k / 256);
+        uint8_t *ws = (uint8_t *)d_ws;
+        void *Xh = ws;
+        void *d8T = ws + align_up(n_pad * (size_t)k * 2, 256);
+        void *img = (uint8_t *)d8T + align_up(nb * 8 * n_pad * 4, 256);
+        HIPCHK(lfamd_launch_wprep8(Atype, d_A, m, k, img, s), "wprep8 (Q8_0)");
+        HIPCHK(lfamd_launch_prep80(Btype, d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, nullptr, s), "prep80");
+        HIPCHK(lfamd_launch_gemm_wide(Atype, img, m, k, Xh, d8T, nullptr, n, (long)n_pad, d_C, ldc, plain, nullptr, 0, s), "gemm_wide (Q8_0)");
+        return LFAMD_OK;
+    }
+    if (use_gemm_q80(Atype, n, flags, k)) {
+        size_t need = align_up(lfamd_gemm_q80_workspace(k, n), 256);
         if (ws_bytes < need || !d_ws)
             return fail(LFAMD_ERR_WORKSPACE, "mul_mat: workspace too small%s", "");
         HIPCHK(lfamd_launch_gemm_q80(d_A, m, k, Btype, d_B, b_row_bytes, n, d_C, ldc, d_ws, vregs32, precise, s), "gemm_q80");

@@ -161,6 +161,9 @@ void load_module() {
     if (__builtin_cpu_supports("avx512f"))
         g.flags |= LFAMD_FLAG_Q0_VREGS32;
 #endif
+    if (const char *e = getenv("LFAMD_Q80_EXACT")) // Q8_0 batches bit for bit like tinyBLAS_Q0 (default: MFMA body, within 2e-6)
+        if (atoi(e))
+            g.flags |= LFAMD_FLAG_Q80_EXACT;
     g.ok = true;
     g.error.clear();
 }

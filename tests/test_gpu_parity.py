@@ -62,7 +62,8 @@ def test_q8_0_bit_exact(gpu, oracle, variant, precise, shape):
     v = oracle.variant(variant, precise=precise)
     ok, G = oracle.sgemm(T.Q8_0, A, bt, B, m, n, k, v=v, nth=2)
     assert ok == 1
-    flags = (_hip.FLAG_Q0_VREGS32 if variant == "zen4" else 0) | (_hip.FLAG_PRECISE if precise else 0)
+    # (batches default to the MFMA body — test_q8_0_batches_on_mfma; the bit-exact kernel is asked for explicitly)
+    flags = (_hip.FLAG_Q0_VREGS32 if variant == "zen4" else 0) | (_hip.FLAG_PRECISE if precise else 0) | _hip.FLAG_Q80_EXACT
     C = run_gpu(gpu, T.Q8_0, A, B, bt, m, n, k, flags=flags)
     # Reference quirk: the 16-vector-register --precise build switches on MIN(n - n0, 1)
     # (tinyblas_cpu.h:904) and so runs gemm<2,1>/<1,1> with xtiles = 1: for n > 1 it writes column 0
@@ -73,6 +74,27 @@ def test_q8_0_bit_exact(gpu, oracle, variant, precise, shape):
         assert written.all()
     assert np.array_equal(C.view(np.uint32)[written], G.view(np.uint32)[written]), np.abs(C - G)[written].max()
     assert not np.isnan(C).any()
+
+
+@pytest.mark.parametrize("shape", [(128, 64, 512), (96, 100, 1024), (33, 9, 256), (256, 512, 2048), (64, 130, 768), (300, 40, 4096)], ids=str)
+@pytest.mark.parametrize("f32in", [False, True], ids=["q80", "f32"])
+def test_q8_0_batches_on_mfma(gpu, oracle, shape, f32in):
+    """Q8_0, n > 8, default flags: the MFMA body on a per-call byte image (exact integer block dots; per-block f32 scaling) —
+    within 2e-6 of the reference (normwise AND element-wise), not bit-exact; LFAMD_FLAG_Q80_EXACT gives the bit-exact kernel."""
+    from llamafile_amd import synth
+    m, n, k = shape
+    A = synth.random_weights(T.Q8_0, m, k, 31)
+    x = synth.random_activations(n, k, 32)
+    B = synth.quantize_activations(T.Q8_0, x)
+    ok, G = oracle.sgemm(T.Q8_0, A, T.Q8_0, B, m, n, k, nth=4)
+    assert ok == 1
+    W = gpu.upload_weights(T.Q8_0, A, m, k)
+    Bd = torch.from_numpy(x).cuda().view(torch.uint8).view(n, k * 4) if f32in else torch.from_numpy(B).cuda()
+    C = gpu.mul_mat(W, Bd, T.F32 if f32in else T.Q8_0).cpu().numpy()
+    assert rel_err(C, G) <= 2e-6, rel_err(C, G)
+    from helpers import elem_err
+    frac, worst = elem_err(C, G, rtol=1e-5)
+    assert frac == 0.0, (frac, worst)
 
 
 @pytest.mark.parametrize("t", [T.Q4_K, T.Q5_K, T.Q6_K], ids=lambda t: T.NAMES[t])
@@ -466,7 +488,12 @@ def test_tuned_types_random_shapes(gpu, oracle, t):
         for body in bodies:
             C = run_gpu(gpu, t, A, B, bt, m, n, k, flags=gpu.host_variant_flags() | body)
             if t == T.Q8_0:
-                assert np.array_equal(C.view(np.uint32), G.view(np.uint32)), (m, n, k)
+                if n <= 8:  # the vecdot
+                    assert np.array_equal(C.view(np.uint32), G.view(np.uint32)), (m, n, k)
+                else:  # batches: MFMA body by default, the bit-exact kernel on request
+                    assert rel_err(C, G) <= 2e-6, (m, n, k)
+                    Cx = run_gpu(gpu, t, A, B, bt, m, n, k, flags=gpu.host_variant_flags() | _hip.FLAG_Q80_EXACT)
+                    assert np.array_equal(Cx.view(np.uint32), G.view(np.uint32)), (m, n, k)
             else:
                 tol = gemm_tol(t, body, n)
                 assert rel_err(C, G) <= tol, (T.NAMES[t], m, n, k, body, rel_err(C, G))
