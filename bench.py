@@ -335,6 +335,12 @@ def make_comm(rank, world, same_device=False):
             comm.close()
             comm = tp.Comm(rank, world, use_rccl=True, oneshot_bytes=0)
             comm.mode = "RCCL (one-shot self-test failed)"
+    if use_rccl or "self-test failed" in comm.mode:  # the RCCL path too, on a message beyond the one-shot slot
+        big = torch.full((1 << 18,), float(rank + 1), device="cuda")
+        comm.allreduce_add(big)
+        torch.cuda.synchronize()
+        if abs(float(big[0].item()) - world * (world + 1) / 2) > 1e-3 or abs(float(big[-1].item()) - world * (world + 1) / 2) > 1e-3:
+            raise RuntimeError("RCCL all-reduce through the C ABI returned a wrong sum")
     comm.describe = lambda: comm.mode + ", through the C ABI"
     comm.has_rccl = use_rccl or "self-test failed" in comm.mode
     comm.oneshot = oneshot if "self-test failed" not in comm.mode else 0
@@ -421,10 +427,22 @@ def run():
         backend = os.environ.get("LFAMD_DIST_BACKEND", "nccl")
         if abi_collectives:
             # compute AND collectives through the C ABI (include/lfamd_hip.h): RCCL inside the HIP module + the one-shot
-            # peer all-reduce for the decode-sized messages; torch.distributed (gloo) only carries the bootstrap bytes,
-            # the barrier and the max over the ranks' clocks
-            torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
-            comm = make_comm(rank, world, same_device=(backend != "nccl"))
+            # peer all-reduce for the decode-sized messages.  torch.distributed carries the bootstrap bytes, the barrier and
+            # the max over the ranks' clocks on gloo; its own NCCL backend (created lazily, only if ever used) is the fallback
+            # should the module's communicator fail its self-test on this node.
+            same_device = backend != "nccl"
+            torch.distributed.init_process_group("gloo" if same_device else "cpu:gloo,cuda:nccl", rank=rank, world_size=world)
+            try:
+                comm = make_comm(rank, world, same_device=same_device)
+            except Exception as e:  # noqa: BLE001
+                print(f"bench.py[rank {rank}]: C-ABI communicator unavailable ({type(e).__name__}: {str(e)[:160]}); "
+                      f"torch.distributed collectives instead", file=sys.stderr)
+                comm = None
+            ok = torch.tensor([1 if comm is not None else 0])
+            torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN)  # all ranks take the same path
+            if not int(ok.item()) and comm is not None:
+                comm.close()
+                comm = None
         elif backend == "nccl":
             torch.distributed.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
         else:
@@ -437,7 +455,10 @@ def run():
     def barrier():
         torch.cuda.synchronize()
         if dist_on:
-            torch.distributed.barrier()
+            if abi_collectives:
+                torch.distributed.all_reduce(torch.zeros(1))  # (gloo, CPU tensor: no NCCL communicator is created for it)
+            else:
+                torch.distributed.barrier()
         torch.cuda.synchronize()
 
     # hipGraph capture of a whole pass (kernels + RCCL collectives).  If capturing the collectives is not
@@ -509,7 +530,7 @@ def run():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist_on:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if comm is not None else dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if abi_collectives else dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed * 1000.0 / a.steps

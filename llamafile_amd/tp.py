@@ -76,9 +76,9 @@ class Comm:
             idb = (C.c_char * 128)()
             if rank == 0:
                 _hip.check(self.L.lfamd_comm_unique_id(idb), "lfamd_comm_unique_id")
-            box = [bytes(idb)]
-            dist.broadcast_object_list(box, src=0, group=group)
-            idbuf = C.create_string_buffer(box[0], 128)
+            idt = torch.frombuffer(bytearray(bytes(idb)), dtype=torch.uint8).clone()  # CPU tensors: the gloo side of the group
+            dist.broadcast(idt, src=0, group=group)
+            idbuf = C.create_string_buffer(bytes(idt.numpy().tobytes()), 128)
         _hip.check(self.L.lfamd_comm_init(C.byref(self.h), rank, world, idbuf), "lfamd_comm_init")
         self.block = None
         if oneshot_bytes and world > 1:
@@ -86,12 +86,14 @@ class Comm:
             self.block = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
             hb = (C.c_char * 64)()
             _hip.check(self.L.lfamd_oneshot_export(C.c_void_p(self.block.data_ptr()), hb), "lfamd_oneshot_export")
-            handles = [None] * world
-            dist.all_gather_object(handles, bytes(hb), group=group)
-            allh = C.create_string_buffer(b"".join(handles), 64 * world)
+            mine = torch.frombuffer(bytearray(bytes(hb)), dtype=torch.uint8).clone()
+            handles = [torch.empty(64, dtype=torch.uint8) for _ in range(world)]
+            dist.all_gather(handles, mine, group=group)
+            allh = C.create_string_buffer(b"".join(h.numpy().tobytes() for h in handles), 64 * world)
             _hip.check(self.L.lfamd_oneshot_attach(self.h, C.c_void_p(self.block.data_ptr()), nbytes, allh, oneshot_bytes),
                        "lfamd_oneshot_attach")
-            dist.barrier(group=group)  # every rank's flag block is zeroed and mapped before the first all-reduce
+            dist.all_reduce(torch.zeros(1), group=group)  # (a barrier on the CPU side) every rank's flag block is zeroed and
+            # mapped before the first all-reduce
 
     def allreduce_add(self, partial, residual=None, out=None):
         """out = residual + sum over ranks of partial (f32, on the current stream)."""

@@ -62,7 +62,7 @@ def _worker(rank, world, port, q):
         except Exception:
             refused = True
         q.put((rank, res, refused))
-        dist.barrier()
+        dist.all_reduce(torch.zeros(1))
         comm.close()
     finally:
         dist.destroy_process_group()
