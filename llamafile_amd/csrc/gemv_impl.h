@@ -779,22 +779,26 @@ __device__ static inline void stage_f32_q80_wave2(uint8_t *dst, const float4 va,
 
 // one block of already-quantised activations, staged by one wave (lanes 0..31: one 8-code group each)
 template <int ACT>
-__device__ static inline void stage_quantised_wave(uint8_t *dst, const uint8_t *row, int b, int lane) {
+__device__ static inline void stage_quantised_wave(uint8_t *dst, const uint8_t *row_generic, int b, int lane) {
+    // (explicitly GLOBAL: the pointer went through an SGPR pin and would otherwise be read with FLAT loads, which make
+    // hipcc's wait counts conservative for the whole kernel — tests/test_isa_hazards.py)
+    typedef const __attribute__((address_space(1))) uint8_t *gptr;
+    const gptr row = (gptr)row_generic;
     if (lane < 32) {
         const int grp = lane;
         uint32_t y0, y1;
         if constexpr (ACT == LFAMD_TYPE_Q8_K) {
-            const uint8_t *y = row + (size_t)b * 292;
-            const uint32_t *src = (const uint32_t *)(y + 36 + 8 * grp);
+            const gptr y = row + (size_t)b * 292;
+            const __attribute__((address_space(1))) uint32_t *src = (const __attribute__((address_space(1))) uint32_t *)(y + 36 + 8 * grp);
             y0 = src[0], y1 = src[1];
             if (grp == 0)
-                *(float *)(dst + XBLK_D) = *(const float *)y;
+                *(float *)(dst + XBLK_D) = *(const __attribute__((address_space(1))) float *)y;
         } else {
-            const uint8_t *blk = row + (size_t)(b * 8 + (grp >> 2)) * 34;
-            const uint16_t *src = (const uint16_t *)(blk + 2 + 8 * (grp & 3));
+            const gptr blk = row + (size_t)(b * 8 + (grp >> 2)) * 34;
+            const __attribute__((address_space(1))) uint16_t *src = (const __attribute__((address_space(1))) uint16_t *)(blk + 2 + 8 * (grp & 3));
             y0 = (uint32_t)src[0] | ((uint32_t)src[1] << 16), y1 = (uint32_t)src[2] | ((uint32_t)src[3] << 16);
             if ((grp & 3) == 0)
-                *(float *)(dst + XBLK_D + 4 * (grp >> 2)) = h2f(*(const uint16_t *)blk);
+                *(float *)(dst + XBLK_D + 4 * (grp >> 2)) = h2f(*(const __attribute__((address_space(1))) uint16_t *)blk);
         }
         const int hs = put_group(dst, grp, y0, y1);
         const int other = (int)dpp_u32<DPP_XOR2>((uint32_t)hs); // group grp ^ 2

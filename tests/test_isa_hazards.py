@@ -36,3 +36,20 @@ _Z4demov: ; @demo
     assert isa_hazards.check_asm(asm)["_Z4demov"] == ["v_mov_b64_e32 v[20:21], v[10:11]"]
     ok = asm.replace("v_mov_b64_e32 v[20:21], v[10:11]\n\ts_waitcnt lgkmcnt(0)", "s_waitcnt lgkmcnt(0)\n\tv_mov_b64_e32 v[20:21], v[10:11]")
     assert isa_hazards.check_asm(ok)["_Z4demov"] == []
+
+
+GEMV_TUS = ["gemv_q4k.hip", "gemv_q5k.hip", "gemv_q6k.hip", "gemv_q40.hip", "gemv_dual.hip"]
+
+
+@pytest.mark.skipif(not os.path.exists(isa_hazards.HIPCC), reason="needs hipcc")
+def test_decode_kernels_have_no_flat_access_and_no_stack():
+    """hipcc counts vmcnt exactly only without FLAT instructions and without a stack frame in the kernel; either one turned
+    every counted wait of the decode GEMV into vmcnt(0) (no weight prefetch) while all parity tests stayed green."""
+    flags = ("-mllvm", "-amdgpu-kernarg-preload-count=9")
+    with ThreadPoolExecutor(max_workers=3) as ex:
+        results = list(ex.map(lambda f: isa_hazards.check_decode_hygiene(os.path.join(ROOT, "llamafile_amd", "csrc", f), flags), GEMV_TUS))
+    for f, res in zip(GEMV_TUS, results):
+        decode = {k: v for k, v in res.items() if "gemv_kq" in k and ("Li1ELi" in k or "dual" in k)}  # NC = 1 bodies
+        assert decode, f
+        for kernel, probs in decode.items():
+            assert not probs, (f, kernel[:80], probs)

@@ -73,6 +73,27 @@ def check_asm(text):
     return res
 
 
+def check_decode_hygiene(path, extra_flags=()):
+    """The decode GEMVs keep their weight prefetch only while hipcc can COUNT the loads in flight: a FLAT memory
+    instruction anywhere in the kernel (a pointer that lost its address space) or a stack frame (closures that were not
+    promoted to registers) makes its wait-count pass drain vmcnt(0) in front of every use — found the hard way in round 2.
+    -> {kernel: [problems]} for every kernel of the translation unit."""
+    flags = [f for f in FLAGS if f != "-fno-slp-vectorize"] + list(extra_flags)
+    with tempfile.NamedTemporaryFile(suffix=".s") as f:
+        subprocess.run([HIPCC, *flags, path, "-o", f.name], check=True, stderr=subprocess.DEVNULL)
+        text = open(f.name).read()
+    res = {}
+    for name, body in re.findall(r"^(_Z\w+):[^\n]*\n(.*?)\.Lfunc_end", text, re.S | re.M):
+        probs = []
+        n_flat = len(re.findall(r"^\s*flat_(load|store|atomic)", body, re.M))
+        if n_flat:
+            probs.append(f"{n_flat} FLAT memory instruction(s)")
+        if re.search(r"^\s*scratch_(load|store)", body, re.M):
+            probs.append("scratch (stack) traffic")
+        res[name] = probs
+    return res
+
+
 def check_file(path):
     with tempfile.NamedTemporaryFile(suffix=".s") as f:
         subprocess.run([HIPCC, *FLAGS, path, "-o", f.name], check=True, stderr=subprocess.DEVNULL)
