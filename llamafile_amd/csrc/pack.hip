@@ -444,11 +444,11 @@ __global__ __launch_bounds__(64) void prep_f32_kernel(const uint8_t *__restrict_
 // MAXJ > 0: the wave's super-blocks (b = wave + 16 j, j < MAXJ) are loaded ONCE, all loads in flight together, and both
 // passes run from registers (one memory round trip per token; 16 waves per token keep as many waves in flight as the per-super-block kernels);
 // MAXJ == 0: any nb, the row is read twice (the second time from the caches).
-template <bool F32IN, int MAXJ>
-__global__ __launch_bounds__(1024) void prep_scaled_kernel(const uint8_t *__restrict__ X, size_t row_bytes, long n, long n_pad, int nb,
+template <bool F32IN, int MAXJ, int NW>
+__global__ __launch_bounds__(NW * 64) void prep_scaled_kernel(const uint8_t *__restrict__ X, size_t row_bytes, long n, long n_pad, int nb,
                                                           _Float16 *__restrict__ Xh, float *__restrict__ tok_scale,
                                                           _Float16 *__restrict__ Xm, const int32_t *__restrict__ src_idx) {
-    __shared__ float wmax[16];
+    __shared__ float wmax[NW]; // NW = 4 or 16 waves per token
     typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
     constexpr int NJ = MAXJ > 0 ? MAXJ : 1;
     const long tok = blockIdx.x;
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(1024) void prep_scaled_kernel(const uint8_t *__rest
     const long src = src_idx ? (long)src_idx[tok] : (tok < n ? tok : -1);
     if (src < 0) { // padding slot: zero codes, never stored
         const half4_t z = {(_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0};
-        for (int b = wave; b < nb; b += 16) {
+        for (int b = wave; b < nb; b += NW) {
             *(half4_t *)(Xh + ((size_t)b * n_pad + tok) * 256 + 4 * lane) = z;
             if (lane < 16)
                 Xm[((size_t)b * n_pad + tok) * 16 + lane] = (_Float16)0;
@@ -490,14 +490,14 @@ __global__ __launch_bounds__(1024) void prep_scaled_kernel(const uint8_t *__rest
 #pragma unroll
         for (int j = 0; j < NJ; j++) {
             fv[j] = make_float4(0.f, 0.f, 0.f, 0.f), qv[j] = 0, dv[j] = 0.0f;
-            if (wave + 16 * j < nb)
-                load(wave + 16 * j, fv[j], qv[j], dv[j]);
+            if (wave + NW * j < nb)
+                load(wave + NW * j, fv[j], qv[j], dv[j]);
         }
 #pragma unroll
         for (int j = 0; j < NJ; j++)
             dmax = fmaxf(dmax, block_amax(fv[j], dv[j]));
     } else {
-        for (int b = wave; b < nb; b += 16) {
+        for (int b = wave; b < nb; b += NW) {
             load(b, fv[0], qv[0], dv[0]);
             dmax = fmaxf(dmax, block_amax(fv[0], dv[0]));
         }
@@ -508,7 +508,7 @@ __global__ __launch_bounds__(1024) void prep_scaled_kernel(const uint8_t *__rest
     if (lane == 0)
         wmax[wave] = dmax;
     __syncthreads();
-    dmax = wmax[lane & 15]; // (every wave reduces the 16 partial maxima itself)
+    dmax = wmax[lane & (NW - 1)]; // (every wave reduces the NW partial maxima itself)
     dmax = fmaxf(dmax, dpp_f32<DPP_XOR1>(dmax));
     dmax = fmaxf(dmax, dpp_f32<DPP_XOR2>(dmax));
     dmax = fmaxf(dmax, dpp_f32<DPP_HALF_MIRROR>(dmax));
@@ -570,10 +570,10 @@ __global__ __launch_bounds__(1024) void prep_scaled_kernel(const uint8_t *__rest
     if constexpr (MAXJ > 0) {
 #pragma unroll
         for (int j = 0; j < NJ; j++)
-            if (wave + 16 * j < nb) // (wave-uniform)
-                emit(wave + 16 * j, fv[j], qv[j], dv[j]);
+            if (wave + NW * j < nb) // (wave-uniform)
+                emit(wave + NW * j, fv[j], qv[j], dv[j]);
     } else {
-        for (int b = wave; b < nb; b += 16) {
+        for (int b = wave; b < nb; b += NW) {
             load(b, fv[0], qv[0], dv[0]);
             emit(b, fv[0], qv[0], dv[0]);
         }
@@ -738,17 +738,19 @@ hipError_t lfamd_launch_pack_raw(const void *raw, size_t raw_row_bytes, long row
 }
 
 // the register-resident forms up to 16 / 64 super-blocks (k <= 4096 / 16384: 1 / 4 per wave), the looping one beyond
+// register-resident forms: 4 waves per token with 4 / 16 super-blocks each (k <= 4096 / 16384) — a quarter of the waves of
+// the 16-wave form to launch and to meet at the barrier, four loads in flight per lane instead of one; the looping form beyond
 #define PREP_SCALED_GO(F32IN, SRC, RB)                                                                                 \
     do {                                                                                                               \
         if (nb <= 16)                                                                                                  \
-            prep_scaled_kernel<F32IN, 1><<<(unsigned)n_pad, 1024, 0, s>>>((const uint8_t *)SRC, RB, n, n_pad, nb, (_Float16 *)Xh, \
-                                                                         (float *)d8T, (_Float16 *)Xm, src_idx);        \
+            prep_scaled_kernel<F32IN, 4, 4><<<(unsigned)n_pad, 256, 0, s>>>((const uint8_t *)SRC, RB, n, n_pad, nb, (_Float16 *)Xh, \
+                                                                           (float *)d8T, (_Float16 *)Xm, src_idx);      \
         else if (nb <= 64)                                                                                             \
-            prep_scaled_kernel<F32IN, 4><<<(unsigned)n_pad, 1024, 0, s>>>((const uint8_t *)SRC, RB, n, n_pad, nb, (_Float16 *)Xh, \
-                                                                          (float *)d8T, (_Float16 *)Xm, src_idx);       \
+            prep_scaled_kernel<F32IN, 16, 4><<<(unsigned)n_pad, 256, 0, s>>>((const uint8_t *)SRC, RB, n, n_pad, nb, (_Float16 *)Xh, \
+                                                                            (float *)d8T, (_Float16 *)Xm, src_idx);     \
         else                                                                                                           \
-            prep_scaled_kernel<F32IN, 0><<<(unsigned)n_pad, 1024, 0, s>>>((const uint8_t *)SRC, RB, n, n_pad, nb, (_Float16 *)Xh, \
-                                                                         (float *)d8T, (_Float16 *)Xm, src_idx);        \
+            prep_scaled_kernel<F32IN, 0, 16><<<(unsigned)n_pad, 1024, 0, s>>>((const uint8_t *)SRC, RB, n, n_pad, nb, (_Float16 *)Xh, \
+                                                                             (float *)d8T, (_Float16 *)Xm, src_idx);    \
     } while (0)
 
 hipError_t lfamd_launch_prep_f32(const void *X, size_t x_row_bytes, long n, long n_pad, long cols, void *Xh, void *d8T,
