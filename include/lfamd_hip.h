@@ -151,6 +151,15 @@ int lfamd_mul_mat_id(int type, const void *d_W_packed, long rows, long cols, int
                      const int32_t *d_plan, int thinkers, float *d_result, void *d_workspace,
                      size_t workspace_bytes, unsigned flags, void *stream);
 
+/* ---- the step in front of the path, fused: RMS-norm x weight -> Q8_K -----------------------------
+ * y[i] = (x[i] * 1/sqrtf(mean(x^2) + eps)) * weight[i] per row (ggml_compute_forward_rms_norm_f32 + the MUL node; GPU
+ * reference rms_norm_f32, ggml-cuda.cu.patch:14926-14960), written as the reference's Q8_K activation blocks
+ * (quantize_row_q8_K, llamafile field order) to d_yq and / or as f32 to d_yf (either may be NULL; d_weight may be NULL = 1).
+ * The mat-muls behind the norm then take Btype = Q8_K: no quantisation left in their prologue.  k % 256 == 0;
+ * vec_dot_type must be Q8_K (the K-quant and IQ4_XS weights' activation format). */
+int lfamd_rms_norm_quantize(const float *d_x, size_t x_row_bytes, const float *d_weight, float eps, long nrows, long k,
+                            int vec_dot_type, void *d_yq, size_t yq_row_bytes, float *d_yf, size_t yf_row_bytes, void *stream);
+
 /* ---- F16 batched GEMM (attention KQ / KQV) ------------------------------------------------------
  * The interface of tinyblasGemmStridedBatchedEx / tinyblasGemmBatchedEx (llamafile/tinyblas.h:59-71, tinyblas.cu:652-857)
  * for the operand arrangement ggml calls them with (ggml_cuda_mul_mat_batched_cublas, ggml-cuda.cu.patch:18231-18376):

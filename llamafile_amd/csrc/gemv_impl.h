@@ -1116,9 +1116,11 @@ struct q80_mats {
 };
 
 template <int NC, int BT, int MODE, int Q80_DEPTH>
-__global__ __launch_bounds__(Q80_WAVES * 64) void gemv_q80_kernel(const q80_mats mats, long n_total, int nblocks, int nquads,
-                                                                 const uint8_t *__restrict__ B, size_t b_row_bytes, long col0,
-                                                                 int vregs32, int precise) {
+__global__ __launch_bounds__(Q80_WAVES * 64) void gemv_q80_kernel(const uint8_t *__restrict__ B, size_t b_row_bytes, long col0, int nblocks,
+                                                                 int nquads, long n_total, int vregs32, int precise,
+                                                                 const q80_mats mats) {
+    // (activation pointer and sizes lead the argument list: they arrive preloaded in SGPRs — Makefile,
+    // -amdgpu-kernarg-preload-count — and the activation loads below need nothing else)
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane >> 3, j = lane & 7;
@@ -1126,6 +1128,18 @@ __global__ __launch_bounds__(Q80_WAVES * 64) void gemv_q80_kernel(const q80_mats
     int stamp_n = 0;
 #endif
     GSTAMP();
+    // the first two activation pieces of this thread go out before anything else: they need only the preloaded leading
+    // arguments, while the matrix pick below waits for three dependent rounds of scalar loads
+    float va0[16], vb0[16];
+    if constexpr (BT == LFAMD_TYPE_F32) {
+        const float *x0 = (const float *)(B + col0 * b_row_bytes);
+        const int pieces0 = nblocks * 2;
+        if ((int)threadIdx.x < pieces0)
+            load_piece(va0, x0, threadIdx.x);
+        if ((int)threadIdx.x + Q80_WAVES * 64 < pieces0)
+            load_piece(vb0, x0, threadIdx.x + Q80_WAVES * 64);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     long rg = (long)blockIdx.x * Q80_WAVES + wave;
     int mj = 0;
 #pragma unroll
@@ -1162,10 +1176,16 @@ __global__ __launch_bounds__(Q80_WAVES * 64) void gemv_q80_kernel(const q80_mats
             for (int p0 = 0; p0 < pieces; p0 += 2 * nthr) {
                 const int pa = p0 + threadIdx.x, pb = pa + nthr;
                 float va[16], vb[16];
-                if (pa < pieces)
-                    load_piece(va, x, pa);
-                if (pb < pieces)
-                    load_piece(vb, x, pb);
+                if (c == 0 && p0 == 0) { // (fetched at the top of the kernel)
+#pragma unroll
+                    for (int e = 0; e < 16; e++)
+                        va[e] = va0[e], vb[e] = vb0[e];
+                } else {
+                    if (pa < pieces)
+                        load_piece(va, x, pa);
+                    if (pb < pieces)
+                        load_piece(vb, x, pb);
+                }
                 if (c == 0 && p0 == 0) {
 #pragma unroll
                     for (int s = 0; s < Q80_DEPTH; s++)
@@ -1476,8 +1496,8 @@ static hipError_t launch_q80(const q80_mats &mats, long n_total, long k, const v
             if (e != hipSuccess)                                                                                       \
                 return e;                                                                                              \
         }                                                                                                              \
-        kernel<<<grid, Q80_WAVES * 64, smem, s>>>(mats, n_total, nblocks, nquads, (const uint8_t *)B, brb, col0, vregs32, \
-                                                  precise);                                                            \
+        kernel<<<grid, Q80_WAVES * 64, smem, s>>>((const uint8_t *)B, brb, col0, nblocks, nquads, n_total, vregs32, precise, \
+                                                  mats);                                                               \
     } while (0)
     if (mode == 0)
         Q80_GO(0);

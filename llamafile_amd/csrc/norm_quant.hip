@@ -1,0 +1,111 @@
+// norm_quant.hip — the step in front of the path, fused: RMS-norm x weight -> the reference's
+// Q8_K activation blocks in ONE kernel, so that the mat-muls behind a norm (attn_q/k/v, ffn_gate/up, output) receive
+// Btype = Q8_K and their prologue is a copy instead of a quantisation.
+//
+// Reference counterparts: ggml_compute_forward_rms_norm_f32 + the MUL by the norm weight (upstream ggml.c; GPU:
+// rms_norm_f32, ggml-cuda.cu.patch:14926-14960) followed by quantize_row_q8_K inside ggml_compute_forward_mul_mat
+// (llamafile order {d, bsums, qs}: ggml-common.h.patch:25-35).  Arithmetic restated:
+//     sum  = sum_i (double)(x[i] * x[i])          (f32 products, f64 accumulation)
+//     mean = (float)(sum / k);  scale = 1.0f / sqrtf(mean + eps)
+//     y[i] = (x[i] * scale) * w[i]                (two f32 roundings: the norm, then the MUL node)
+//     Q8_K per 256 values: first index of the largest |y| -> iscale = -128 / max, nearest-even codes clamped at 127,
+//     d = 1 / iscale, bsums of 16
+// The f64 sum is a tree here and a sequential loop on the CPU: they differ only below 1e-15 relative, i.e. the f32 `mean`
+// (and everything after it) is identical unless the sum sits within 1e-9 relative of a rounding boundary.
+#include "lfamd_device.h"
+#include "../../include/lfamd_hip.h"
+
+extern "C" void lfamd_set_error(const char *msg);
+
+namespace {
+
+__device__ static inline double wave_sum_f64(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// one work-group (4 waves) per row; wave w owns the 256-blocks w, w + 4, ...
+__global__ __launch_bounds__(256) void rms_norm_q8k_kernel(const float *__restrict__ x, size_t x_row_bytes, const float *__restrict__ w,
+                                                           float eps, long k, uint8_t *__restrict__ yq, size_t yq_row_bytes,
+                                                           float *__restrict__ yf, size_t yf_row_bytes) {
+    __shared__ double part[4];
+    const long row = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float *xr = (const float *)((const uint8_t *)x + row * x_row_bytes);
+    const int nb = (int)(k / 256);
+    double s = 0.0;
+    for (int b = wave; b < nb; b += 4) {
+        const float4 v = *(const float4 *)(xr + (size_t)b * 256 + 4 * lane);
+        s += (double)(v.x * v.x) + (double)(v.y * v.y) + (double)(v.z * v.z) + (double)(v.w * v.w);
+    }
+    s = wave_sum_f64(s);
+    if (lane == 0)
+        part[wave] = s;
+    __syncthreads();
+    const double sum = (part[0] + part[1]) + (part[2] + part[3]);
+    const float mean = (float)(sum / (double)k);
+    const float scale = 1.0f / sqrtf(mean + eps);
+    uint8_t *qrow = yq ? yq + row * yq_row_bytes : nullptr;
+    float *frow = yf ? (float *)((uint8_t *)yf + row * yf_row_bytes) : nullptr;
+    for (int b = wave; b < nb; b += 4) {
+        const float4 v = *(const float4 *)(xr + (size_t)b * 256 + 4 * lane); // (second read: L1 / L2)
+        const float4 g = w ? *(const float4 *)(w + (size_t)b * 256 + 4 * lane) : make_float4(1.f, 1.f, 1.f, 1.f);
+        float y[4] = {v.x * scale, v.y * scale, v.z * scale, v.w * scale};
+        if (w)
+            y[0] *= g.x, y[1] *= g.y, y[2] *= g.z, y[3] *= g.w;
+        if (frow)
+            *(float4 *)(frow + (size_t)b * 256 + 4 * lane) = make_float4(y[0], y[1], y[2], y[3]);
+        if (!qrow)
+            continue;
+        // quantize_row_q8_K on the block (cf. gemv_impl.h stage_f32_q8k_wave: same arithmetic, reference block format out)
+        const float a0 = fabsf(y[0]), a1 = fabsf(y[1]), a2 = fabsf(y[2]), a3 = fabsf(y[3]);
+        const float amax = wave_max_f32(fmaxf(fmaxf(a0, a1), fmaxf(a2, a3)));
+        const bool m0 = a0 == amax, m1 = a1 == amax, m2 = a2 == amax, m3 = a3 == amax;
+        const unsigned long long ball = __builtin_amdgcn_ballot_w64(m0 || m1 || m2 || m3);
+        const float cand = m0 ? y[0] : (m1 ? y[1] : (m2 ? y[2] : y[3]));
+        const bool nz = amax != 0.0f;
+        const float val = nz ? readlane_f32(cand, ball ? __builtin_ctzll(ball) : 0) : 1.0f;
+        const float iscale = -128.0f / val;
+        int q[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int c = (int)rintf(iscale * y[e]);
+            q[e] = nz ? (c > 127 ? 127 : c) : 0;
+        }
+        uint8_t *blk = qrow + (size_t)b * 292;
+        *(uint32_t *)(blk + 36 + 4 * lane) = (uint32_t)(q[0] & 0xff) | ((uint32_t)(q[1] & 0xff) << 8) | ((uint32_t)(q[2] & 0xff) << 16) |
+                                            ((uint32_t)(q[3] & 0xff) << 24);
+        int bs = q[0] + q[1] + q[2] + q[3];
+        bs += (int)dpp_u32<DPP_XOR1>((uint32_t)bs);
+        bs += (int)dpp_u32<DPP_XOR2>((uint32_t)bs);
+        if ((lane & 3) == 0)
+            *(int16_t *)(blk + 4 + 2 * (lane >> 2)) = (int16_t)bs;
+        if (lane == 0)
+            *(float *)blk = nz ? 1.0f / iscale : 0.0f;
+    }
+}
+
+} // namespace
+
+extern "C" int lfamd_rms_norm_quantize(const float *d_x, size_t x_row_bytes, const float *d_weight, float eps, long nrows, long k,
+                                       int vec_dot_type, void *d_yq, size_t yq_row_bytes, float *d_yf, size_t yf_row_bytes,
+                                       void *stream) {
+    if (nrows < 0 || k <= 0 || k % 256 || (d_yq && vec_dot_type != LFAMD_TYPE_Q8_K) || (!d_yq && !d_yf) ||
+        ((uintptr_t)d_x & 15) || (x_row_bytes & 15) || ((uintptr_t)d_weight & 15) || ((uintptr_t)d_yf & 15) || (yf_row_bytes & 15) ||
+        ((uintptr_t)d_yq & 3) || (yq_row_bytes & 3)) {
+        lfamd_set_error("lfamd_rms_norm_quantize: k must be a multiple of 256, output format Q8_K, 16-byte aligned f32 rows");
+        return LFAMD_ERR_INVALID;
+    }
+    if (nrows == 0)
+        return LFAMD_OK;
+    rms_norm_q8k_kernel<<<(unsigned)nrows, 256, 0, (hipStream_t)stream>>>(d_x, x_row_bytes, d_weight, eps, k, (uint8_t *)d_yq, yq_row_bytes,
+                                                                            d_yf, yf_row_bytes);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        lfamd_set_error(hipGetErrorString(e));
+        return LFAMD_ERR_HIP;
+    }
+    return LFAMD_OK;
+}
