@@ -893,10 +893,10 @@ __device__ static inline float kq_sum_rows(float v) {
     return p + q;
 }
 
-template <typename TR, int BT, int NW, int GEMV_CH, bool IDS>
+template <typename TR, int BT, int NW, int GEMV_CH, bool IDS, bool EARLY = false>
 __device__ __forceinline__ void gemv_kq_body1(const gemv_mats &mats, int nb, const uint8_t *__restrict__ B,
                                               size_t b_row_bytes, long col0, int n_ht, const int bid, int gdim,
-                                              uint8_t *lds) {
+                                              uint8_t *lds, const uint8_t *A0_pre, int cnt_pre) {
     asm volatile("" : "+s"(nb), "+s"(B), "+s"(b_row_bytes), "+s"(col0), "+s"(n_ht), "+s"(gdim)); // (one s_load round)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -926,6 +926,30 @@ __device__ __forceinline__ void gemv_kq_body1(const gemv_mats &mats, int nb, con
             xv[j] = buf_ld16(rx, x_off(0, j));
         __builtin_amdgcn_sched_barrier(0); // (the scheduler would put the weight loads first)
     }
+    // pre-quantised Q8_K rows, one block per wave: the block's codes (8 bytes per lane of the lower half-wave) and its scale
+    // are fetched here too, ahead of the weights
+    constexpr bool PRE1 = BT == LFAMD_TYPE_Q8_K && TR::ACT == LFAMD_TYPE_Q8_K && JX == 1;
+    uint2 pq = make_uint2(0, 0);
+    uint32_t pd = 0;
+    if constexpr (PRE1) {
+        const lfamd_rsrc rq = make_rsrc(xrow, (uint32_t)nb * 292u);
+        pq = buf_ld8(rq, (uint32_t)wave * 292u + 36u + (uint32_t)(lane & 31) * 8u);
+        pd = __builtin_amdgcn_raw_buffer_load_b32(rq, (uint32_t)wave * 292u, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // a single-matrix launch (attn_output, ffn_down) knows its weights from the preloaded arguments: its first item goes
+    // out BEFORE the argument table's scalar loads have returned (~0.4 us earlier); both branches issue the same loads
+    typename TR::chunk bufA, bufB;
+    constexpr bool early = EARLY && !IDS; // (a kernel variant, not a run-time branch: hipcc merges its wait counts at a join)
+    (void)cnt_pre;
+    if constexpr (early) {
+        const int hh = bid & 1;
+        const uint32_t rtb = (uint32_t)nb * TR::TILE;
+        const lfamd_rsrc r = make_rsrc(A0_pre + (size_t)(bid >> 1) * rtb, bid < n_ht ? rtb : 0u);
+#pragma unroll
+        for (int s = 0; s < GEMV_CH; s++)
+            TR::load(bufA, s, r, (uint32_t)(wave + NW * s) * TR::TILE, gsel, h * 32 + hh * 16 + i16, hh * 16 + i16);
+    }
     const kq_tab tab = kq_table(mats);
 
     const int sb_per_wave = (nb + NW - 1) / NW;
@@ -934,7 +958,6 @@ __device__ __forceinline__ void gemv_kq_body1(const gemv_mats &mats, int nb, con
 
     float acc = 0.0f;
     int par = 0;
-    typename TR::chunk bufA, bufB;
     kq_cursor ci{bid, 0}, cc{bid, 0};
 #define KQ_ADVANCE(c)                                                                                                  \
     do {                                                                                                               \
@@ -994,7 +1017,10 @@ __device__ __forceinline__ void gemv_kq_body1(const gemv_mats &mats, int nb, con
         // into the wave's dummy slot): with a branch per block hipcc merges its vmcnt bookkeeping at the joins and
         // makes the second block wait for the WEIGHTS.
         uint8_t *dummy = (uint8_t *)(red + 2 * NW * 16) + (size_t)wave * XBLK;
-        KQ_ISSUE(bufA);
+        if constexpr (early)
+            KQ_ADVANCE(ci);
+        else
+            KQ_ISSUE(bufA);
         __builtin_amdgcn_sched_barrier(0);
         GSTAMP();
 #define KQ_F4(u) make_float4(__builtin_bit_cast(float, (u).x), __builtin_bit_cast(float, (u).y), __builtin_bit_cast(float, (u).z), \
@@ -1027,10 +1053,25 @@ __device__ __forceinline__ void gemv_kq_body1(const gemv_mats &mats, int nb, con
 #undef KQ_F4
 #undef KQ_STAGE_GROUP
     } else {
-        KQ_ISSUE(bufA);
+        if constexpr (early)
+            KQ_ADVANCE(ci);
+        else
+            KQ_ISSUE(bufA);
         GSTAMP();
-        for (int b = wave; b < nb; b += NW)
-            stage_quantised_wave<TR::ACT>(lds + (size_t)b * XBLK, xrow, b, lane);
+        if constexpr (PRE1) {
+            if (wave < nb && lane < 32) {
+                uint8_t *dst = lds + (size_t)wave * XBLK;
+                const int hs = put_group(dst, lane, pq.x, pq.y);
+                const int other = (int)dpp_u32<DPP_XOR2>((uint32_t)hs);
+                if ((lane & 2) == 0)
+                    put_pair(dst, lane, hs + other);
+                if (lane == 0)
+                    *(uint32_t *)(dst + XBLK_D) = pd;
+            }
+        } else {
+            for (int b = wave; b < nb; b += NW)
+                stage_quantised_wave<TR::ACT>(lds + (size_t)b * XBLK, xrow, b, lane);
+        }
     }
     // the image blocks this wave reads are the ones it has just written: program order in the LDS queue is enough;
     // only the compiler must not move the reads above the (differently typed) writes
@@ -1057,12 +1098,15 @@ __device__ __forceinline__ void gemv_kq_body1(const gemv_mats &mats, int nb, con
 #undef KQ_CONSUME
 }
 
-template <typename TR, int NC, int BT, int NW, int GEMV_CH, bool IDS = false>
+template <typename TR, int NC, int BT, int NW, int GEMV_CH, bool IDS = false, bool EARLY = false>
 __global__ __launch_bounds__(NW * 64) void gemv_kq_kernel(const uint8_t *__restrict__ B, size_t b_row_bytes, long col0, int nb,
-                                                          int n_ht, int gdim, const gemv_mats mats) {
+                                                          int n_ht, int gdim, const uint8_t *__restrict__ A0, int cnt,
+                                                          const gemv_mats mats) {
+    // (A0 = mats.A[0], cnt = mats.count once more, among the PRELOADED leading arguments: a single-matrix launch issues its
+    // first weight loads without waiting for the argument table)
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     if constexpr (NC == 1)
-        gemv_kq_body1<TR, BT, NW, GEMV_CH, IDS>(mats, nb, B, b_row_bytes, col0, n_ht, (int)blockIdx.x, gdim, lds);
+        gemv_kq_body1<TR, BT, NW, GEMV_CH, IDS, EARLY>(mats, nb, B, b_row_bytes, col0, n_ht, (int)blockIdx.x, gdim, lds, A0, cnt);
     else
         gemv_kq_body<TR, NC, BT, NW, GEMV_CH, IDS>(mats, nb, B, b_row_bytes, col0, n_ht, (int)blockIdx.x, gdim, lds);
 }
@@ -1077,9 +1121,10 @@ __global__ __launch_bounds__(NW * 64) void gemv_kq_dual_kernel(const uint8_t *__
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     static_assert(TRA::ACT == TRB::ACT, "both types must share the activation image");
     if ((int)blockIdx.x < grid_a)
-        gemv_kq_body1<TRA, BT, NW, GEMV_CH, false>(mats_a, nb, B, b_row_bytes, 0, n_ht_a, (int)blockIdx.x, grid_a, lds);
+        gemv_kq_body1<TRA, BT, NW, GEMV_CH, false>(mats_a, nb, B, b_row_bytes, 0, n_ht_a, (int)blockIdx.x, grid_a, lds, nullptr, 0);
     else
-        gemv_kq_body1<TRB, BT, NW, GEMV_CH, false>(mats_b, nb, B, b_row_bytes, 0, n_ht_b, (int)blockIdx.x - grid_a, grid_b, lds);
+        gemv_kq_body1<TRB, BT, NW, GEMV_CH, false>(mats_b, nb, B, b_row_bytes, 0, n_ht_b, (int)blockIdx.x - grid_a, grid_b, lds, nullptr,
+                                                   0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1382,18 +1427,24 @@ template <typename TR, int NC, int BT, int NW, int CH>
 static hipError_t launch_kq(const gemv_mats &mats, int n_ht, long k, const void *B, size_t brb, long col0, hipStream_t s) {
     int nb = (int)(k / 256);
     size_t smem = (size_t)NC * nb * XBLK + 2 * NW * NC * 16 * sizeof(float) + (NC == 1 ? (size_t)NW * XBLK : 0); // (+ dummy slots)
-    auto kernel = gemv_kq_kernel<TR, NC, BT, NW, CH>;
-    if (smem > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess)
-            return e;
-    }
     // persistent grid: 16 waves per CU, every work-group the same number of half-tiles
     const int max_wg = (16 / NW) * num_cus();
     const int per_wg = (n_ht + max_wg - 1) / max_wg;
     const int grid = (n_ht + per_wg - 1) / per_wg;
-    kernel<<<grid, NW * 64, smem, s>>>((const uint8_t *)B, brb, col0, nb, n_ht, grid, mats);
-    return hipGetLastError();
+    auto go = [&](auto kernel) {
+        if (smem > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            if (e != hipSuccess)
+                return e;
+        }
+        kernel<<<grid, NW * 64, smem, s>>>((const uint8_t *)B, brb, col0, nb, n_ht, grid, mats.A[0], mats.count, mats);
+        return hipGetLastError();
+    };
+    if constexpr (NC == 1) {
+        if (mats.count == 1) // one matrix: the variant that issues its first weight loads from the preloaded arguments
+            return go(gemv_kq_kernel<TR, NC, BT, NW, CH, false, true>);
+    }
+    return go(gemv_kq_kernel<TR, NC, BT, NW, CH>);
 }
 
 template <typename TRA, typename TRB, int BT>
@@ -1431,7 +1482,7 @@ static hipError_t launch_kq_ids(const gemv_mats &mats, int n_ht, long k, const v
     const int grid = (n_ht + per_wg - 1) / per_wg;
     if (nb <= 16) {
         auto kernel = gemv_kq_kernel<TR, 1, BT, NW, 1, true>;
-        kernel<<<grid, NW * 64, smem, s>>>((const uint8_t *)B, brb, 0, nb, n_ht, grid, mats);
+        kernel<<<grid, NW * 64, smem, s>>>((const uint8_t *)B, brb, 0, nb, n_ht, grid, mats.A[0], 0 /* expert picked on the device: no early issue */, mats);
     } else {
         auto kernel = gemv_kq_kernel<TR, 1, BT, NW, 2, true>;
         if (smem > 64 * 1024) {
@@ -1439,7 +1490,7 @@ static hipError_t launch_kq_ids(const gemv_mats &mats, int n_ht, long k, const v
             if (e != hipSuccess)
                 return e;
         }
-        kernel<<<grid, NW * 64, smem, s>>>((const uint8_t *)B, brb, 0, nb, n_ht, grid, mats);
+        kernel<<<grid, NW * 64, smem, s>>>((const uint8_t *)B, brb, 0, nb, n_ht, grid, mats.A[0], 0 /* expert picked on the device: no early issue */, mats);
     }
     return hipGetLastError();
 }
