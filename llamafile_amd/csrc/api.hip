@@ -16,7 +16,7 @@ hipError_t lfamd_launch_prep80(int, const void *, size_t, long, long, long, void
 hipError_t lfamd_launch_wprep32(int, const void *, long, long, void *, hipStream_t);
 size_t lfamd_wprep32_bytes(long, long);
 hipError_t lfamd_launch_prep_float(int, int, const void *, size_t, long, long, long, void *, hipStream_t);
-hipError_t lfamd_launch_wprep8(int, const void *, long, long, void *, hipStream_t);
+hipError_t lfamd_launch_wprep8(int, const void *, size_t, long, long, void *, hipStream_t);
 size_t lfamd_wprep8_bytes(long, long);
 hipError_t lfamd_launch_pack_q5k(const void *, size_t, long, long, void *, hipStream_t);
 hipError_t lfamd_launch_pack_q6k(const void *, size_t, long, long, void *, hipStream_t);
@@ -24,7 +24,7 @@ hipError_t lfamd_launch_pack_q80(const void *, size_t, long, long, void *, hipSt
 hipError_t lfamd_launch_pack_raw(const void *, size_t, long, size_t, void *, hipStream_t);
 hipError_t lfamd_launch_prep_q8k(const void *, size_t, long, long, long, void *, void *, void *, int, const int32_t *, hipStream_t);
 hipError_t lfamd_launch_prep_f32(const void *, size_t, long, long, long, void *, void *, void *, int, const int32_t *, hipStream_t);
-hipError_t lfamd_launch_wprep16(int, const void *, long, long, void *, hipStream_t);
+hipError_t lfamd_launch_wprep16(int, const void *, size_t, long, long, void *, hipStream_t);
 size_t lfamd_wprep16_bytes(long, long);
 hipError_t lfamd_launch_generic(int, const void *, long, long, int, const void *, size_t, long, float *, long, hipStream_t);
 hipError_t lfamd_launch_gemv(int, const void *, long, long, int, const void *, size_t, long, float *, long, int, int,
@@ -183,6 +183,11 @@ size_t lfamd_packed_size(int type, long rows, long cols) {
         return (size_t)((rows + 31) / 32) * (size_t)(cols / 256) * P6K_TILE;
     case LFAMD_TYPE_Q8_0:
         return (size_t)((rows + 7) / 8) * (size_t)((cols / 32 + 3) / 4) * P80_TILE;
+    case LFAMD_TYPE_Q2_K:
+    case LFAMD_TYPE_Q3_K: // PCK: the image the MFMA GEMM and the decode GEMV both read
+        return lfamd_wprep16_bytes(rows, cols);
+    case LFAMD_TYPE_IQ4_XS: // PC8
+        return lfamd_wprep8_bytes(rows, cols);
     default:
         return (size_t)rows * lfamd_row_size(type, cols);
     }
@@ -217,6 +222,13 @@ int lfamd_pack_weights(int type, long rows, long cols, const void *d_raw, size_t
         break;
     case LFAMD_TYPE_Q8_0:
         HIPCHK(lfamd_launch_pack_q80(d_raw, raw_row_bytes, rows, cols, d_packed, s), "pack_q80");
+        break;
+    case LFAMD_TYPE_Q2_K:
+    case LFAMD_TYPE_Q3_K:
+        HIPCHK(lfamd_launch_wprep16(type, d_raw, raw_row_bytes, rows, cols, d_packed, s), "pack_pck");
+        break;
+    case LFAMD_TYPE_IQ4_XS:
+        HIPCHK(lfamd_launch_wprep8(type, d_raw, raw_row_bytes, rows, cols, d_packed, s), "pack_pc8");
         break;
     default:
         HIPCHK(lfamd_launch_pack_raw(d_raw, raw_row_bytes, rows, lfamd_row_size(type, cols), d_packed, s), "pack_raw");
@@ -272,7 +284,7 @@ static bool use_gemm(int Atype, long n, unsigned flags, long k) {
     return n > 8 && (Atype == LFAMD_TYPE_Q4_K || Atype == LFAMD_TYPE_Q5_K || Atype == LFAMD_TYPE_Q6_K || packed40(Atype, k));
 }
 
-// K-quants kept in RAW layout whose batches go through a per-call canonical image + the MFMA body (Q2_K, Q3_K)
+// K-quants whose resident layout is the canonical image the MFMA body reads (Q2_K, Q3_K: PCK; IQ4_XS: PC8)
 static bool use_gemm_canon(int Atype, long n, unsigned flags) {
     return !(flags & LFAMD_FLAG_FORCE_GENERIC) && n > 8 &&
            (Atype == LFAMD_TYPE_Q2_K || Atype == LFAMD_TYPE_Q3_K || Atype == LFAMD_TYPE_IQ4_XS);
@@ -313,7 +325,8 @@ static bool use_gemv(int Atype, long n, unsigned flags, long k) {
     if (flags & LFAMD_FLAG_FORCE_GENERIC)
         return false;
     return n <= 8 && (Atype == LFAMD_TYPE_Q4_K || Atype == LFAMD_TYPE_Q5_K || Atype == LFAMD_TYPE_Q6_K ||
-                      Atype == LFAMD_TYPE_Q8_0 || packed40(Atype, k));
+                      Atype == LFAMD_TYPE_Q8_0 || Atype == LFAMD_TYPE_Q2_K || Atype == LFAMD_TYPE_Q3_K ||
+                      Atype == LFAMD_TYPE_IQ4_XS || packed40(Atype, k));
 }
 
 static bool gemv_quantise_separately(int Atype, long m) {
@@ -338,7 +351,7 @@ size_t lfamd_mul_mat_workspace(int Atype, long m, long k, long n) {
     if (use_gemm_float(Atype, n, 0, k))
         return align_up(align_up((size_t)n, 128) * (size_t)k * 2, 256);
     if (use_gemm_canon(Atype, n, 0))
-        return gemm_act_ws(k, n) + align_up(Atype == LFAMD_TYPE_IQ4_XS ? lfamd_wprep8_bytes(m, k) : lfamd_wprep16_bytes(m, k), 256);
+        return gemm_act_ws(k, n);
     if (use_gemm_canon32(Atype, n, 0, k)) { // Xh, d8T [nb*8][n_pad], sT [nb*8][n_pad], image
         size_t n_pad = align_up((size_t)n, 128), nb = (size_t)(k / 256);
         return align_up(n_pad * (size_t)k * 2, 256) + 2 * align_up(nb * 8 * n_pad * 4, 256) + align_up(lfamd_wprep32_bytes(m, k), 256);
@@ -448,17 +461,12 @@ int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const v
         void *Xh = ws;
         void *d8T = ws + align_up(n_pad * (size_t)k * 2, 256);
         void *Xm = (uint8_t *)d8T + align_up(nb * n_pad * 4, 256);
-        void *img = ws + gemm_act_ws(k, n);
-        if (Atype == LFAMD_TYPE_IQ4_XS)
-            HIPCHK(lfamd_launch_wprep8(Atype, d_A, m, k, img, s), "wprep8");
-        else
-            HIPCHK(lfamd_launch_wprep16(Atype, d_A, m, k, img, s), "wprep16");
         const int mins16 = Atype == LFAMD_TYPE_Q2_K;
         if (Btype == LFAMD_TYPE_F32)
             HIPCHK(lfamd_launch_prep_f32(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, mins16, nullptr, s), "prep_f32");
         else
             HIPCHK(lfamd_launch_prep_q8k(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, mins16, nullptr, s), "prep_q8k");
-        HIPCHK(lfamd_launch_gemm_wide(Atype, img, m, k, Xh, d8T, Xm, n, (long)n_pad, d_C, ldc, plain, nullptr, 0, s), "gemm_wide");
+        HIPCHK(lfamd_launch_gemm_wide(Atype, d_A, m, k, Xh, d8T, Xm, n, (long)n_pad, d_C, ldc, plain, nullptr, 0, s), "gemm_wide");
         return LFAMD_OK;
     }
     if (use_gemm_q80_mfma(Atype, n, flags, k)) {
@@ -469,7 +477,7 @@ int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const v
         void *Xh = ws;
         void *d8T = ws + align_up(n_pad * (size_t)k * 2, 256);
         void *img = (uint8_t *)d8T + align_up(nb * 8 * n_pad * 4, 256);
-        HIPCHK(lfamd_launch_wprep8(Atype, d_A, m, k, img, s), "wprep8 (Q8_0)");
+        HIPCHK(lfamd_launch_wprep8(Atype, d_A, 0, m, k, img, s), "wprep8 (Q8_0)");
         HIPCHK(lfamd_launch_prep80(Btype, d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, nullptr, s), "prep80");
         HIPCHK(lfamd_launch_gemm_wide(Atype, img, m, k, Xh, d8T, nullptr, n, (long)n_pad, d_C, ldc, plain, nullptr, 0, s), "gemm_wide (Q8_0)");
         return LFAMD_OK;
@@ -496,7 +504,7 @@ int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const v
         return LFAMD_OK;
     }
     if (Atype == LFAMD_TYPE_Q4_K || Atype == LFAMD_TYPE_Q5_K || Atype == LFAMD_TYPE_Q6_K || Atype == LFAMD_TYPE_Q8_0 ||
-        packed40(Atype, k))
+        Atype == LFAMD_TYPE_Q2_K || Atype == LFAMD_TYPE_Q3_K || Atype == LFAMD_TYPE_IQ4_XS || packed40(Atype, k))
         return fail(LFAMD_ERR_UNSUPPORTED, "mul_mat: FORCE_GENERIC needs RAW-layout weights; this type is packed%s", "");
     if (!float_a && Btype == LFAMD_TYPE_F32) {
         size_t qrow = lfamd_row_size(vdt, k), need = align_up((size_t)n * qrow, 256);

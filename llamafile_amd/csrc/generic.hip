@@ -1,10 +1,9 @@
-// generic.hip — type-generic quantised mat-mul on RAW-layout weights (every ggml type of the path).
+// generic.hip — mat-mul on RAW-layout weights, and the upload-time / per-call canonical images.
 //
-// The untuned but complete kernel: it services every weight type iqk_mul_mat / tinyBLAS accept on
-// x86 (iqk_mul_mat.inc:1408-1463, tinyblas_cpu_sgemm.inc:45-240) for any n, with the reference's
-// arithmetic: exact integer block dot products, f32 scales.  Types with a
-// tuned kernel (Q4_K, Q6_K, Q8_0) use gemv.hip / gemm_mfma.hip instead; this one carries the rest
-// (Q4_0, Q4_1, Q5_0, Q5_1, Q2_K, Q3_K, Q5_K, IQ4_XS, F32/F16/BF16) until they get their own.
+// The untuned kernels serve what has no resident packed layout: the legacy 32-block types when a row is not a whole
+// number of 256-weight groups (Q4_0, Q4_1, Q5_0, Q5_1; tinyblas_cpu_sgemm.inc:45-240, iqk_mul_mat.inc:998-1349) and
+// float weights outside the MFMA body's shapes, with the reference's arithmetic: exact integer block dot products, f32
+// scales.  Every K-quant and IQ4_XS is packed (lfamd_device.h) and never comes here.
 //
 // One wave per (weight row, tile of up to 8 activation rows).  Lanes split the row into 16-weight
 // units (32 for the legacy 32-blocks), each lane unpacks its unit once and dots it against up to 8
@@ -18,37 +17,7 @@ __device__ static const int8_t kvalues_iq4nl_dev[16] = {-127, -104, -83, -65, -4
 // integer scale / min:  w = d*sc*q - dmin*mn.  Formulas: ggml-cuda.cu.patch:3217-3471, 3684-3699.
 template <int TYPE>
 __device__ static inline void unpack16(const uint8_t *blk, int s, int q[16], int &sc, int &mn, float &d, float &dmin) {
-    if constexpr (TYPE == LFAMD_TYPE_Q4_K || TYPE == LFAMD_TYPE_Q5_K) {
-        const uint8_t *scales = blk + 4;
-        d = h2f(*(const uint16_t *)blk);
-        dmin = h2f(*(const uint16_t *)(blk + 2));
-        int j = s >> 1; // 32-wide sub-block
-        scale_min_k4(j, scales, sc, mn);
-        const uint8_t *qs = blk + (TYPE == LFAMD_TYPE_Q4_K ? 16 : 48);
-        int c = j >> 1, hi = j & 1, l0 = (s & 1) * 16;
-        for (int l = 0; l < 16; l++) {
-            uint8_t byte = qs[32 * c + l0 + l];
-            q[l] = hi ? (byte >> 4) : (byte & 15);
-            if constexpr (TYPE == LFAMD_TYPE_Q5_K) {
-                const uint8_t *qh = blk + 16;
-                q[l] += ((qh[l0 + l] >> (2 * c + hi)) & 1) * 16;
-            }
-        }
-    } else if constexpr (TYPE == LFAMD_TYPE_Q6_K) {
-        const uint8_t *ql = blk, *qh = blk + 128;
-        const int8_t *scales = (const int8_t *)(blk + 192);
-        d = h2f(*(const uint16_t *)(blk + 208));
-        dmin = 0.0f;
-        sc = scales[s];
-        mn = 0;
-        int p = s >> 3, quarter = (s >> 1) & 3, l0 = (s & 1) * 16;
-        for (int l = 0; l < 16; l++) {
-            uint8_t qlb = ql[64 * p + (quarter & 1) * 32 + l0 + l];
-            int nib = quarter < 2 ? (qlb & 15) : (qlb >> 4);
-            int hb = (qh[32 * p + l0 + l] >> (2 * quarter)) & 3;
-            q[l] = (nib | (hb << 4)) - 32;
-        }
-    } else if constexpr (TYPE == LFAMD_TYPE_Q2_K) {
+    if constexpr (TYPE == LFAMD_TYPE_Q2_K) {
         const uint8_t *scales = blk, *qs = blk + 16;
         d = h2f(*(const uint16_t *)(blk + 80));
         dmin = h2f(*(const uint16_t *)(blk + 82));
@@ -74,60 +43,6 @@ __device__ static inline void unpack16(const uint8_t *blk, int s, int q[16], int
             int v = (qs[32 * n + l0 + l] >> (2 * j)) & 3;
             q[l] = v - ((hmask[l0 + l] & m) ? 0 : 4);
         }
-    } else if constexpr (TYPE == LFAMD_TYPE_IQ4_XS) {
-        d = h2f(*(const uint16_t *)blk);
-        dmin = 0.0f;
-        uint16_t scales_h = *(const uint16_t *)(blk + 2);
-        const uint8_t *scales_l = blk + 4, *qs = blk + 8;
-        int ib = s >> 1;
-        int ls = ((scales_l[ib / 2] >> (4 * (ib % 2))) & 0xf) | (((scales_h >> (2 * ib)) & 3) << 4);
-        sc = ls - 32;
-        mn = 0;
-        int hi = s & 1;
-        for (int l = 0; l < 16; l++) {
-            uint8_t byte = qs[16 * ib + l];
-            q[l] = kvalues_iq4nl_dev[hi ? (byte >> 4) : (byte & 15)];
-        }
-    }
-}
-
-// K-quants x Q8_K
-template <int TYPE, int TS>
-__global__ __launch_bounds__(256) void generic_kquant_kernel(const uint8_t *__restrict__ A, long m, int nb,
-                                                             const uint8_t *__restrict__ B, size_t b_row_bytes, long n,
-                                                             float *__restrict__ C, long ldc) {
-    const int lane = threadIdx.x & 63;
-    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const long col0 = (long)blockIdx.y * 8;
-    if (row >= m)
-        return;
-    const int nc = (int)((n - col0) < 8 ? (n - col0) : 8);
-    const uint8_t *arow = A + (size_t)row * nb * TS;
-    float accd[8], accm[8];
-    for (int c = 0; c < 8; c++)
-        accd[c] = accm[c] = 0.0f;
-    const int units = nb * 16;
-    for (int u = lane; u < units; u += 64) {
-        int b = u >> 4, s = u & 15;
-        int q[16], sc, mn;
-        float d, dmin;
-        unpack16<TYPE>(arow + (size_t)b * TS, s, q, sc, mn, d, dmin);
-        for (int c = 0; c < nc; c++) {
-            const lfamd_block_q8_K *y = (const lfamd_block_q8_K *)(B + (col0 + c) * b_row_bytes) + b;
-            int dot = 0;
-            for (int l = 0; l < 16; l++)
-                dot += q[l] * (int)y->qs[16 * s + l];
-            float d8 = y->d;
-            accd[c] = fmaf(d * d8, (float)(sc * dot), accd[c]);
-            accm[c] = fmaf(-dmin * d8, (float)(mn * (int)y->bsums[s]), accm[c]);
-        }
-    }
-    for (int c = 0; c < nc; c++) {
-        float v = accd[c] + accm[c];
-        for (int off = 32; off > 0; off >>= 1)
-            v += __shfl_xor(v, off, 64);
-        if (lane == 0)
-            C[(col0 + c) * ldc + row] = v;
     }
 }
 
@@ -240,29 +155,10 @@ extern "C" hipError_t lfamd_launch_generic(int Atype, const void *A, long m, lon
         return hipSuccess;
     dim3 grid((unsigned)((m + 3) / 4), (unsigned)((n + 7) / 8));
     const uint8_t *a = (const uint8_t *)A, *b = (const uint8_t *)B;
-    int nb256 = (int)(k / 256), nb32 = (int)(k / 32);
-#define KQ(T, TS) generic_kquant_kernel<T, TS><<<grid, 256, 0, s>>>(a, m, nb256, b, b_row_bytes, n, C, ldc)
+    int nb32 = (int)(k / 32);
 #define LG(T, TS, T1) generic_legacy_kernel<T, TS, T1><<<grid, 256, 0, s>>>(a, m, nb32, b, b_row_bytes, n, C, ldc)
 #define FL(TA, TB) generic_float_kernel<TA, TB><<<grid, 256, 0, s>>>(a, m, k, b, b_row_bytes, n, C, ldc)
     switch (Atype) {
-    case LFAMD_TYPE_Q2_K:
-        KQ(LFAMD_TYPE_Q2_K, 84);
-        break;
-    case LFAMD_TYPE_Q3_K:
-        KQ(LFAMD_TYPE_Q3_K, 110);
-        break;
-    case LFAMD_TYPE_Q4_K:
-        KQ(LFAMD_TYPE_Q4_K, 144);
-        break;
-    case LFAMD_TYPE_Q5_K:
-        KQ(LFAMD_TYPE_Q5_K, 176);
-        break;
-    case LFAMD_TYPE_Q6_K:
-        KQ(LFAMD_TYPE_Q6_K, 210);
-        break;
-    case LFAMD_TYPE_IQ4_XS:
-        KQ(LFAMD_TYPE_IQ4_XS, 136);
-        break;
     case LFAMD_TYPE_Q4_0:
         LG(LFAMD_TYPE_Q4_0, 18, false);
         break;
@@ -299,16 +195,15 @@ extern "C" hipError_t lfamd_launch_generic(int Atype, const void *A, long m, lon
     default:
         return hipErrorInvalidValue;
     }
-#undef KQ
 #undef LG
 #undef FL
     return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------
-// Per-call canonicalisation for the MFMA GEMM (n > 8) of K-quants that stay in RAW layout (Q2_K, Q3_K): RAW blocks ->
-// PCK tiles in the workspace (lfamd_device.h).  One thread per output dword; reads 84 / 110 bytes per 256 weights,
-// writes 164: a few microseconds beside a GEMM that is 20-30x faster than the one-wave-per-row kernel above.
+// Upload-time canonicalisation of Q2_K / Q3_K (lfamd_pack_weights): RAW blocks -> PCK tiles (lfamd_device.h), the
+// resident layout both the MFMA GEMM and the decode GEMV read.  One thread per output dword; reads 84 / 110 bytes per
+// 256 weights, writes 164.
 template <int TYPE>
 __global__ void wprep16_kernel(const uint8_t *__restrict__ raw, size_t raw_row_bytes, long rows, int nb, uint8_t *__restrict__ out,
                                long n_tiles) {
@@ -524,7 +419,8 @@ __global__ void wprep8_q80_kernel(const uint8_t *__restrict__ p80, long rows, in
     dst[w] = v;
 }
 
-extern "C" hipError_t lfamd_launch_wprep8(int type, const void *raw, long rows, long cols, void *out, hipStream_t s) {
+extern "C" hipError_t lfamd_launch_wprep8(int type, const void *raw, size_t raw_row_bytes, long rows, long cols, void *out,
+                                          hipStream_t s) {
     if (type == LFAMD_TYPE_Q8_0) { // `raw` is the P80-packed matrix here
         const int nb = (int)(cols / 256);
         const long n_tiles = ((rows + 31) / 32) * nb;
@@ -537,8 +433,8 @@ extern "C" hipError_t lfamd_launch_wprep8(int type, const void *raw, long rows, 
     const int nb = (int)(cols / 256);
     const long n_tiles = ((rows + 31) / 32) * nb;
     const long threads = n_tiles * 2176;
-    wprep8_iq4xs_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>((const uint8_t *)raw, lfamd_row_size(type, cols), rows, nb,
-                                                                        (uint8_t *)out, n_tiles);
+    wprep8_iq4xs_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>((const uint8_t *)raw, raw_row_bytes, rows, nb, (uint8_t *)out,
+                                                                        n_tiles);
     return hipGetLastError();
 }
 
@@ -546,11 +442,12 @@ extern "C" size_t lfamd_wprep16_bytes(long rows, long cols) {
     return (size_t)((rows + 31) / 32) * (size_t)(cols / 256) * PCK_TILE;
 }
 
-extern "C" hipError_t lfamd_launch_wprep16(int type, const void *raw, long rows, long cols, void *out, hipStream_t s) {
+extern "C" hipError_t lfamd_launch_wprep16(int type, const void *raw, size_t raw_row_bytes, long rows, long cols, void *out,
+                                           hipStream_t s) {
     const int nb = (int)(cols / 256);
     const long n_tiles = ((rows + 31) / 32) * nb;
     const long threads = n_tiles * 1312;
-    const size_t rrb = lfamd_row_size(type, cols);
+    const size_t rrb = raw_row_bytes;
     if (type == LFAMD_TYPE_Q2_K)
         wprep16_kernel<LFAMD_TYPE_Q2_K><<<(unsigned)((threads + 255) / 256), 256, 0, s>>>((const uint8_t *)raw, rrb, rows, nb,
                                                                                          (uint8_t *)out, n_tiles);

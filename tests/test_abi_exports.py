@@ -45,6 +45,9 @@ def test_packed_size_is_exactly_gguf_size_for_aligned_shapes():
     for t in (T.Q4_K, T.Q6_K, T.Q8_0):
         assert lib.lfamd_packed_size(t, 4096, 4096) == 4096 * T.row_size(t, 4096)
     assert lib.lfamd_packed_size(T.Q4_K, 33, 256) == 2 * 4608  # rows round up to 32
+    # resident canonical images (the layout GEMM and GEMV both read): PCK for Q2_K / Q3_K, PC8 for IQ4_XS
+    assert lib.lfamd_packed_size(T.Q2_K, 4096, 4096) == lib.lfamd_packed_size(T.Q3_K, 4096, 4096) == 128 * 16 * 5248
+    assert lib.lfamd_packed_size(T.IQ4_XS, 4096, 4096) == 128 * 16 * 8704
     assert lib.lfamd_packed_size(T.Q4_K, 32, 100) == 0  # cols not a block multiple
     assert lib.lfamd_packed_size(99, 32, 256) == 0  # unknown type
 

@@ -38,7 +38,8 @@ _Z4demov: ; @demo
     assert isa_hazards.check_asm(ok)["_Z4demov"] == []
 
 
-GEMV_TUS = ["gemv_q4k.hip", "gemv_q5k.hip", "gemv_q6k.hip", "gemv_q40.hip", "gemv_dual.hip"]
+GEMV_TUS = ["gemv_q4k.hip", "gemv_q5k.hip", "gemv_q6k.hip", "gemv_q40.hip", "gemv_q2k.hip", "gemv_q3k.hip", "gemv_iq4xs.hip",
+            "gemv_dual.hip"]
 
 
 @pytest.mark.skipif(not os.path.exists(isa_hazards.HIPCC), reason="needs hipcc")
