@@ -13,7 +13,7 @@ extern "C" {
 hipError_t lfamd_launch_pack_q4k(const void *, size_t, long, long, void *, hipStream_t);
 hipError_t lfamd_launch_pack_q40(const void *, size_t, long, long, void *, hipStream_t);
 hipError_t lfamd_launch_prep80(int, const void *, size_t, long, long, long, void *, void *, void *, hipStream_t);
-hipError_t lfamd_launch_wprep32(int, const void *, long, long, void *, hipStream_t);
+hipError_t lfamd_launch_wprep32(int, const void *, size_t, long, long, void *, hipStream_t);
 size_t lfamd_wprep32_bytes(long, long);
 hipError_t lfamd_launch_prep_float(int, int, const void *, size_t, long, long, long, void *, hipStream_t);
 hipError_t lfamd_launch_wprep8(int, const void *, size_t, long, long, void *, hipStream_t);
@@ -188,6 +188,12 @@ size_t lfamd_packed_size(int type, long rows, long cols) {
         return lfamd_wprep16_bytes(rows, cols);
     case LFAMD_TYPE_IQ4_XS: // PC8
         return lfamd_wprep8_bytes(rows, cols);
+    case LFAMD_TYPE_Q4_1:
+    case LFAMD_TYPE_Q5_0:
+    case LFAMD_TYPE_Q5_1:
+        if (cols % 256 == 0) // PCL; other row lengths stay RAW (generic kernels)
+            return lfamd_wprep32_bytes(rows, cols);
+        return (size_t)rows * lfamd_row_size(type, cols);
     default:
         return (size_t)rows * lfamd_row_size(type, cols);
     }
@@ -229,6 +235,15 @@ int lfamd_pack_weights(int type, long rows, long cols, const void *d_raw, size_t
         break;
     case LFAMD_TYPE_IQ4_XS:
         HIPCHK(lfamd_launch_wprep8(type, d_raw, raw_row_bytes, rows, cols, d_packed, s), "pack_pc8");
+        break;
+    case LFAMD_TYPE_Q4_1:
+    case LFAMD_TYPE_Q5_0:
+    case LFAMD_TYPE_Q5_1:
+        if (cols % 256 == 0) {
+            HIPCHK(lfamd_launch_wprep32(type, d_raw, raw_row_bytes, rows, cols, d_packed, s), "pack_pcl");
+        } else {
+            HIPCHK(lfamd_launch_pack_raw(d_raw, raw_row_bytes, rows, lfamd_row_size(type, cols), d_packed, s), "pack_raw");
+        }
         break;
     default:
         HIPCHK(lfamd_launch_pack_raw(d_raw, raw_row_bytes, rows, lfamd_row_size(type, cols), d_packed, s), "pack_raw");
@@ -295,10 +310,12 @@ static size_t gemm_act_ws(long k, long n) { // Xh + d8T + Xm of the K-quant GEMM
     return align_up(n_pad * (size_t)k * 2, 256) + align_up(nb * n_pad * 4, 256) + align_up(n_pad * nb * 32, 256);
 }
 
-// legacy 32-block types kept in RAW layout (Q4_1, Q5_0, Q5_1; rows of whole 256-weight groups): per-call PCL image
+// legacy 32-block types whose rows are whole 256-weight groups (Q4_1, Q5_0, Q5_1): resident PCL image
+static bool packed_pcl(int Atype, long k) {
+    return k % 256 == 0 && (Atype == LFAMD_TYPE_Q4_1 || Atype == LFAMD_TYPE_Q5_0 || Atype == LFAMD_TYPE_Q5_1);
+}
 static bool use_gemm_canon32(int Atype, long n, unsigned flags, long k) {
-    return !(flags & LFAMD_FLAG_FORCE_GENERIC) && n > 8 && k % 256 == 0 &&
-           (Atype == LFAMD_TYPE_Q4_1 || Atype == LFAMD_TYPE_Q5_0 || Atype == LFAMD_TYPE_Q5_1);
+    return !(flags & LFAMD_FLAG_FORCE_GENERIC) && n > 8 && packed_pcl(Atype, k);
 }
 
 // F16 / BF16 weights, batches, rows of whole 256-element groups: MFMA body straight on the RAW rows
@@ -326,7 +343,7 @@ static bool use_gemv(int Atype, long n, unsigned flags, long k) {
         return false;
     return n <= 8 && (Atype == LFAMD_TYPE_Q4_K || Atype == LFAMD_TYPE_Q5_K || Atype == LFAMD_TYPE_Q6_K ||
                       Atype == LFAMD_TYPE_Q8_0 || Atype == LFAMD_TYPE_Q2_K || Atype == LFAMD_TYPE_Q3_K ||
-                      Atype == LFAMD_TYPE_IQ4_XS || packed40(Atype, k));
+                      Atype == LFAMD_TYPE_IQ4_XS || packed40(Atype, k) || packed_pcl(Atype, k));
 }
 
 static bool gemv_quantise_separately(int Atype, long m) {
@@ -354,7 +371,7 @@ size_t lfamd_mul_mat_workspace(int Atype, long m, long k, long n) {
         return gemm_act_ws(k, n);
     if (use_gemm_canon32(Atype, n, 0, k)) { // Xh, d8T [nb*8][n_pad], sT [nb*8][n_pad], image
         size_t n_pad = align_up((size_t)n, 128), nb = (size_t)(k / 256);
-        return align_up(n_pad * (size_t)k * 2, 256) + 2 * align_up(nb * 8 * n_pad * 4, 256) + align_up(lfamd_wprep32_bytes(m, k), 256);
+        return align_up(n_pad * (size_t)k * 2, 256) + 2 * align_up(nb * 8 * n_pad * 4, 256);
     }
     if (use_gemv(Atype, n, 0, k) || !type_known(Atype) || lfamd_blck_size(Atype) == 1)
         return 0;
@@ -445,11 +462,9 @@ int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const v
         void *Xh = ws;
         void *d8T = ws + align_up(n_pad * (size_t)k * 2, 256);
         void *sT = (uint8_t *)d8T + align_up(nb * 8 * n_pad * 4, 256);
-        void *img = (uint8_t *)sT + align_up(nb * 8 * n_pad * 4, 256);
         const bool q81 = vdt == LFAMD_TYPE_Q8_1;
-        HIPCHK(lfamd_launch_wprep32(Atype, d_A, m, k, img, s), "wprep32");
         HIPCHK(lfamd_launch_prep80(Btype, d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, q81 ? sT : nullptr, s), "prep80");
-        HIPCHK(lfamd_launch_gemm_wide(Atype, img, m, k, Xh, d8T, q81 ? sT : nullptr, n, (long)n_pad, d_C, ldc, plain, nullptr, 0, s), "gemm_wide");
+        HIPCHK(lfamd_launch_gemm_wide(Atype, d_A, m, k, Xh, d8T, q81 ? sT : nullptr, n, (long)n_pad, d_C, ldc, plain, nullptr, 0, s), "gemm_wide");
         return LFAMD_OK;
     }
     if (use_gemm_canon(Atype, n, flags)) {
@@ -504,7 +519,7 @@ int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const v
         return LFAMD_OK;
     }
     if (Atype == LFAMD_TYPE_Q4_K || Atype == LFAMD_TYPE_Q5_K || Atype == LFAMD_TYPE_Q6_K || Atype == LFAMD_TYPE_Q8_0 ||
-        Atype == LFAMD_TYPE_Q2_K || Atype == LFAMD_TYPE_Q3_K || Atype == LFAMD_TYPE_IQ4_XS || packed40(Atype, k))
+        Atype == LFAMD_TYPE_Q2_K || Atype == LFAMD_TYPE_Q3_K || Atype == LFAMD_TYPE_IQ4_XS || packed40(Atype, k) || packed_pcl(Atype, k))
         return fail(LFAMD_ERR_UNSUPPORTED, "mul_mat: FORCE_GENERIC needs RAW-layout weights; this type is packed%s", "");
     if (!float_a && Btype == LFAMD_TYPE_F32) {
         size_t qrow = lfamd_row_size(vdt, k), need = align_up((size_t)n * qrow, 256);
@@ -648,10 +663,7 @@ int lfamd_mul_mat_multi(int Atype, int count, const void *const *d_A, const long
     if (count <= 0)
         return LFAMD_OK;
     // one fused launch when the GEMV path applies to every matrix; otherwise one mul_mat per matrix
-    bool fuse = count <= 4 && n <= 8 &&
-                (Atype == LFAMD_TYPE_Q4_K || Atype == LFAMD_TYPE_Q5_K || Atype == LFAMD_TYPE_Q6_K || Atype == LFAMD_TYPE_Q8_0 ||
-                 packed40(Atype, k)) &&
-                !(flags & LFAMD_FLAG_FORCE_GENERIC) && (Btype == LFAMD_TYPE_F32 || Btype == lfamd_vec_dot_type(Atype)) &&
+    bool fuse = count <= 4 && use_gemv(Atype, n, flags, k) && (Btype == LFAMD_TYPE_F32 || Btype == lfamd_vec_dot_type(Atype)) &&
                 k > 0 && k % lfamd_blck_size(Atype) == 0 && (Atype == LFAMD_TYPE_Q8_0 || k % 256 == 0) &&
                 b_row_bytes >= lfamd_row_size(Btype, k);
     for (int j = 0; j < count && fuse; j++)

@@ -1,4 +1,4 @@
-// gemv.hip — dispatch of the decode GEMVs (kernels: gemv_impl.h; instantiations: gemv_q4k / q5k / q6k / q40 / q2k / q3k / iq4xs / q80.hip)
+// gemv.hip — dispatch of the decode GEMVs (kernels: gemv_impl.h; instantiations: gemv_q4k / q5k / q6k / q40 / q41 / q50 / q51 / q2k / q3k / iq4xs / q80.hip)
 #include "gemv_impl.h"
 
 hipError_t lfamd_gemv_go_q4k(GEMV_GO_ARGS);
@@ -8,6 +8,9 @@ hipError_t lfamd_gemv_go_q40(GEMV_GO_ARGS);
 hipError_t lfamd_gemv_go_q2k(GEMV_GO_ARGS);
 hipError_t lfamd_gemv_go_q3k(GEMV_GO_ARGS);
 hipError_t lfamd_gemv_go_iq4xs(GEMV_GO_ARGS);
+hipError_t lfamd_gemv_go_q41(GEMV_GO_ARGS);
+hipError_t lfamd_gemv_go_q50(GEMV_GO_ARGS);
+hipError_t lfamd_gemv_go_q51(GEMV_GO_ARGS);
 hipError_t lfamd_gemv_ids_go_q4k(int, const gemv_mats &, int, long, const void *, size_t, hipStream_t);
 hipError_t lfamd_gemv_ids_go_q5k(int, const gemv_mats &, int, long, const void *, size_t, hipStream_t);
 hipError_t lfamd_gemv_ids_go_q6k(int, const gemv_mats &, int, long, const void *, size_t, hipStream_t);
@@ -69,7 +72,8 @@ extern "C" hipError_t lfamd_launch_gemv_multi(int Atype, int count, const void *
     }
     if (count > GEMV_MAX_MATS ||
         (Atype != LFAMD_TYPE_Q4_K && Atype != LFAMD_TYPE_Q5_K && Atype != LFAMD_TYPE_Q6_K && Atype != LFAMD_TYPE_Q4_0 &&
-         Atype != LFAMD_TYPE_Q2_K && Atype != LFAMD_TYPE_Q3_K && Atype != LFAMD_TYPE_IQ4_XS))
+         Atype != LFAMD_TYPE_Q2_K && Atype != LFAMD_TYPE_Q3_K && Atype != LFAMD_TYPE_IQ4_XS && Atype != LFAMD_TYPE_Q4_1 &&
+         Atype != LFAMD_TYPE_Q5_0 && Atype != LFAMD_TYPE_Q5_1))
         return hipErrorInvalidValue;
     gemv_mats mats;
     int n_ht = 0;
@@ -108,6 +112,12 @@ extern "C" hipError_t lfamd_launch_gemv_multi(int Atype, int count, const void *
             e = lfamd_gemv_go_q3k(nc, f, mats, n_ht, k, B, b_row_bytes, col0, s);
         else if (Atype == LFAMD_TYPE_IQ4_XS)
             e = lfamd_gemv_go_iq4xs(nc, f, mats, n_ht, k, B, b_row_bytes, col0, s);
+        else if (Atype == LFAMD_TYPE_Q4_1)
+            e = lfamd_gemv_go_q41(nc, f, mats, n_ht, k, B, b_row_bytes, col0, s);
+        else if (Atype == LFAMD_TYPE_Q5_0)
+            e = lfamd_gemv_go_q50(nc, f, mats, n_ht, k, B, b_row_bytes, col0, s);
+        else if (Atype == LFAMD_TYPE_Q5_1)
+            e = lfamd_gemv_go_q51(nc, f, mats, n_ht, k, B, b_row_bytes, col0, s);
         else
             e = lfamd_gemv_go_q6k(nc, f, mats, n_ht, k, B, b_row_bytes, col0, s);
     }

@@ -29,7 +29,8 @@
 //   [0,256)    codes: 8-byte groups at position pos = 16 gsel + 8 h + 4 gi + dd
 //   [256,320)  hb  : int16 sum of each 8-byte group, same position order
 //   [320,352)  ps  : int16 sum of K-step pairs (dd = 2e, 2e+1): position 8 gsel + 4 h + 2 gi + e
-//   [352,384)  d   : f32 block scale (Q8_K: one; Q8_0-quantised activations for the legacy 32-block types: eight)
+//   [352,384)  d   : f32 block scale (Q8_K: one; Q8_0-quantised activations for the legacy 32-block types: eight;
+//                    Q8_1: eight dwords {f16 d, f16 s = d * sum(q)} like the block_q8_1 header)
 #define XBLK 384
 #define XBLK_HB 256
 #define XBLK_PS 320
@@ -147,8 +148,19 @@ __device__ static inline void stage_f32_as_q8k(uint8_t *lds, const uint8_t *X, s
     }
 }
 
+// scale slot `blk` (0..7) of a Q8_0 / Q8_1 activation image: Q8_0 keeps the f16-rounded d as f32; Q8_1 keeps {d, s} as
+// the two f16 of block_q8_1, s = f16(d * sum) from the UNROUNDED d like upstream quantize_row_q8_1
+template <bool S1>
+__device__ static inline void put_scale_q80(uint8_t *dst, int blk, float d, int sum) {
+    if constexpr (S1)
+        *(uint32_t *)(dst + XBLK_D + 4 * blk) = (uint32_t)f2h_bits(d) | ((uint32_t)f2h_bits((float)sum * d) << 16);
+    else
+        *(float *)(dst + XBLK_D + 4 * blk) = h2f(f2h_bits(d));
+}
+
 // ---- activations of the legacy 32-block weight types (Q4_0 ...): Q8_0 quantisation (d = amax/127 per 32 values,
 // stored as f16; q = roundf(x/d): upstream quantize_row_q8_0), same code / group-sum / pair-sum image, eight scales.
+template <bool S1 = false>
 __device__ static inline void quantise_piece_q80(uint8_t *dst, const float (&v)[16], int l16) {
     float amax = 0.0f;
 #pragma unroll
@@ -169,10 +181,11 @@ __device__ static inline void quantise_piece_q80(uint8_t *dst, const float (&v)[
     if ((l16 & 1) == 0) {
         put_pair(dst, 2 * l16 + 0, hs0 + o0);
         put_pair(dst, 2 * l16 + 1, hs1 + o1);
-        *(float *)(dst + XBLK_D + 4 * (l16 >> 1)) = h2f(f2h_bits(d));
+        put_scale_q80<S1>(dst, l16 >> 1, d, hs0 + o0 + hs1 + o1);
     }
 }
 
+template <bool S1>
 __device__ static inline void stage_f32_as_q80(uint8_t *lds, const uint8_t *X, size_t x_row_bytes, long col0, int nc,
                                                int nb) {
     const int pieces = nb * 16;
@@ -182,27 +195,34 @@ __device__ static inline void stage_f32_as_q80(uint8_t *lds, const uint8_t *X, s
         for (int p = threadIdx.x; p < pieces; p += blockDim.x) {
             float v[16];
             load_piece(v, x, p);
-            quantise_piece_q80(lds + (size_t)(c * nb + (p >> 4)) * XBLK, v, l16);
+            quantise_piece_q80<S1>(lds + (size_t)(c * nb + (p >> 4)) * XBLK, v, l16);
         }
     }
 }
 
-// already-quantised Q8_0 rows (34-byte blocks): one 8-byte group per lane, 32 consecutive lanes per 256 codes
+// already-quantised Q8_0 (34-byte blocks) / Q8_1 (36-byte blocks {d, s, qs}) rows: one 8-byte group per lane, 32
+// consecutive lanes per 256 codes
+template <bool S1>
 __device__ static inline void stage_q80_blocks(uint8_t *lds, const uint8_t *B, size_t b_row_bytes, long col0, int nc, int nb) {
+    constexpr int BS = S1 ? 36 : 34, QS = S1 ? 4 : 2;
     const int groups = nc * nb * 32;
     for (int gidx = threadIdx.x; gidx < groups; gidx += blockDim.x) {
         int c = gidx / (nb * 32), r = gidx % (nb * 32);
         int b = r >> 5, grp = r & 31;
-        const uint8_t *blk = B + (col0 + c) * b_row_bytes + (size_t)(b * 8 + (grp >> 2)) * 34;
-        const uint16_t *src = (const uint16_t *)(blk + 2 + 8 * (grp & 3));
+        const uint8_t *blk = B + (col0 + c) * b_row_bytes + (size_t)(b * 8 + (grp >> 2)) * BS;
+        const uint16_t *src = (const uint16_t *)(blk + QS + 8 * (grp & 3));
         const uint32_t y0 = (uint32_t)src[0] | ((uint32_t)src[1] << 16), y1 = (uint32_t)src[2] | ((uint32_t)src[3] << 16);
         uint8_t *dst = lds + (size_t)(c * nb + b) * XBLK;
         const int hs = put_group(dst, grp, y0, y1);
         const int other = __shfl_xor(hs, 2, 64);
         if ((grp & 2) == 0)
             put_pair(dst, grp, hs + other);
-        if ((grp & 3) == 0)
-            *(float *)(dst + XBLK_D + 4 * (grp >> 2)) = h2f(*(const uint16_t *)blk);
+        if ((grp & 3) == 0) {
+            if constexpr (S1)
+                *(uint32_t *)(dst + XBLK_D + 4 * (grp >> 2)) = (uint32_t)((const uint16_t *)blk)[0] | ((uint32_t)((const uint16_t *)blk)[1] << 16);
+            else
+                *(float *)(dst + XBLK_D + 4 * (grp >> 2)) = h2f(*(const uint16_t *)blk);
+        }
     }
 }
 
@@ -215,9 +235,9 @@ __device__ static inline void stage_x(uint8_t *lds, const uint8_t *B, size_t b_r
             stage_q8k(lds, B, b_row_bytes, col0, nc, nb);
     } else {
         if constexpr (BT == LFAMD_TYPE_F32)
-            stage_f32_as_q80(lds, B, b_row_bytes, col0, nc, nb);
+            stage_f32_as_q80<ACT == LFAMD_TYPE_Q8_1>(lds, B, b_row_bytes, col0, nc, nb);
         else
-            stage_q80_blocks(lds, B, b_row_bytes, col0, nc, nb);
+            stage_q80_blocks<ACT == LFAMD_TYPE_Q8_1>(lds, B, b_row_bytes, col0, nc, nb);
     }
 }
 
@@ -429,6 +449,78 @@ struct q6k_traits {
         }
         const float d8 = *(const float *)(xb + XBLK_D);
         return (d * d8) * (float)sumi;
+    }
+};
+
+// Q4_1 / Q5_0 / Q5_1 on the PCL image (rows of whole 256-weight groups): the P4K nibble lattice, eight f16 d and eight
+// f16 m per row, fifth bits on the P5K lattice.  Per 32-block (iqk_mul_mat.inc:1241-1349, ggml_vec_dot_q5_0_q8_0):
+//   Q5_0: d*d8*(<q5, q8> - 16*sum(q8))          Q4_1 / Q5_1: d*d8*<q, q8> + m*s,  s = the activation block's d8*sum(q8)
+// A lane holds half of a block's weights (K-half h): the m*s term is added by the h = 0 lane.
+template <int TYPE>
+struct pcl_traits {
+    static constexpr bool HAS_M = TYPE == LFAMD_TYPE_Q4_1 || TYPE == LFAMD_TYPE_Q5_1;
+    static constexpr bool HAS_H = TYPE == LFAMD_TYPE_Q5_0 || TYPE == LFAMD_TYPE_Q5_1;
+    static constexpr int ACT = HAS_M ? LFAMD_TYPE_Q8_1 : LFAMD_TYPE_Q8_0;
+    static constexpr int TILE = PCL_TILE;
+    struct chunk {
+        uint4 q0[GEMV_CH_MAX], q1[GEMV_CH_MAX];
+        uint2 hd[GEMV_CH_MAX], hm[GEMV_CH_MAX], hq[GEMV_CH_MAX];
+    };
+    __device__ static inline void load(chunk &ch, int s, lfamd_rsrc r, uint32_t off, int gsel, int slot, int hrow) {
+        ch.q0[s] = buf_ld16_nt(r, off + (2 * gsel + 0) * 1024 + slot * 16);
+        ch.q1[s] = buf_ld16_nt(r, off + (2 * gsel + 1) * 1024 + slot * 16);
+        ch.hd[s] = buf_ld8(r, off + PCL_D + hrow * 16 + gsel * 8); // scales of blocks 4 gsel .. 4 gsel + 3
+        if constexpr (HAS_M)
+            ch.hm[s] = buf_ld8(r, off + PCL_M + hrow * 16 + gsel * 8);
+        if constexpr (HAS_H)
+            ch.hq[s] = buf_ld8(r, off + PCL_QH + slot * 16 + gsel * 8); // fifth bits of groups 2 gsel, 2 gsel + 1
+    }
+    __device__ static inline float dot(const chunk &ch, int s, const uint8_t *xb, int gsel, int h) {
+        const uint4 q0 = ch.q0[s], q1 = ch.q1[s];
+        const uint2 hd = ch.hd[s];
+        const uint32_t qw[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+        const uint4 *yq = (const uint4 *)(xb + 128 * gsel + 64 * h);
+        const uint4 ya = yq[0], yb = yq[1], yc = yq[2], yd = yq[3];
+        const uint32_t yw[16] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w,
+                                 yc.x, yc.y, yc.z, yc.w, yd.x, yd.y, yd.z, yd.w};
+        const uint4 dsw = *(const uint4 *)(xb + XBLK_D + 16 * gsel); // Q8_0: four f32 d8; Q8_1: four {f16 d8, f16 s}
+        const uint32_t dsv[4] = {dsw.x, dsw.y, dsw.z, dsw.w};
+        int ps[4] = {0, 0, 0, 0};
+        if constexpr (!HAS_M) {
+            const uint2 psw = *(const uint2 *)(xb + XBLK_PS + 16 * gsel + 8 * h);
+            ps[0] = (int)(int16_t)(psw.x & 0xffff), ps[1] = (int)(int16_t)(psw.x >> 16);
+            ps[2] = (int)(int16_t)(psw.y & 0xffff), ps[3] = (int)(int16_t)(psw.y >> 16);
+        }
+        float acc = 0.0f;
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) { // block 4 gsel + jj
+            int isum = 0;
+#pragma unroll
+            for (int d2 = 0; d2 < 2; d2++) {
+                const int t8 = 2 * jj + d2;
+                const uint32_t x = qw[t8];
+                uint32_t c0 = x & 0x0F0F0F0F, c1 = (x >> 4) & 0x0F0F0F0F;
+                if constexpr (HAS_H) {
+                    const uint32_t Hd = (t8 < 4 ? ch.hq[s].x : ch.hq[s].y) >> (t8 & 3);
+                    c0 |= Hd & 0x10101010;
+                    c1 |= ((Hd >> 4) & 0x00100010) | ((Hd << 12) & 0x10001000);
+                }
+                isum = sdot4(c0, yw[2 * t8], isum);
+                isum = sdot4(c1, yw[2 * t8 + 1], isum);
+            }
+            const uint32_t dw = jj < 2 ? hd.x : hd.y;
+            const float d = h2f((uint16_t)((jj & 1) ? (dw >> 16) : (dw & 0xffff)));
+            if constexpr (HAS_M) {
+                const uint32_t mw = jj < 2 ? ch.hm[s].x : ch.hm[s].y;
+                const float m = h2f((uint16_t)((jj & 1) ? (mw >> 16) : (mw & 0xffff)));
+                const float d8 = h2f((uint16_t)(dsv[jj] & 0xffff)), s8 = h2f((uint16_t)(dsv[jj] >> 16));
+                acc = fmaf(d * d8, (float)isum, acc);
+                acc = fmaf(m, h ? 0.0f : s8, acc);
+            } else {
+                acc = fmaf(d * __builtin_bit_cast(float, dsv[jj]), (float)(isum - 16 * ps[jj]), acc);
+            }
+        }
+        return acc;
     }
 };
 
@@ -701,7 +793,7 @@ __device__ __forceinline__ void gemv_kq_body(const gemv_mats &mats, int nb, cons
             if constexpr (TR::ACT == LFAMD_TYPE_Q8_K)
                 quantise_piece_q8k(lds + (size_t)(threadIdx.x >> 4) * XBLK, v, threadIdx.x & 15);
             else
-                quantise_piece_q80(lds + (size_t)(threadIdx.x >> 4) * XBLK, v, threadIdx.x & 15);
+                quantise_piece_q80<TR::ACT == LFAMD_TYPE_Q8_1>(lds + (size_t)(threadIdx.x >> 4) * XBLK, v, threadIdx.x & 15);
         }
         GSTAMP();
     } else {
@@ -788,6 +880,7 @@ __device__ static inline void stage_f32_q8k_wave(uint8_t *dst, const float4 v, i
 
 // quantize_row_q8_0 on eight 32-blocks held as a float4 per lane (8 lanes per block): d = amax/127 (stored as f16),
 // q = roundf(x / d).
+template <bool S1>
 __device__ static inline void stage_f32_q80_wave(uint8_t *dst, const float4 v, int lane) {
     float am = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
     am = fmaxf(am, dpp_f32<DPP_XOR1>(am));
@@ -798,8 +891,15 @@ __device__ static inline void stage_f32_q80_wave(uint8_t *dst, const float4 v, i
     const int q0 = (int)roundf(v.x * id), q1 = (int)roundf(v.y * id), q2 = (int)roundf(v.z * id), q3 = (int)roundf(v.w * id);
     const uint32_t y = (uint32_t)(q0 & 0xff) | ((uint32_t)(q1 & 0xff) << 8) | ((uint32_t)(q2 & 0xff) << 16) | ((uint32_t)(q3 & 0xff) << 24);
     put_codes_wave(dst, y, lane);
+    int sum = 0;
+    if constexpr (S1) { // the block's code sum over its eight lanes
+        sum = sdot4(y, 0x01010101u, 0);
+        sum += (int)dpp_u32<DPP_XOR1>((uint32_t)sum);
+        sum += (int)dpp_u32<DPP_XOR2>((uint32_t)sum);
+        sum += (int)dpp_u32<DPP_HALF_MIRROR>((uint32_t)sum);
+    }
     if ((lane & 7) == 0)
-        *(float *)(dst + XBLK_D + 4 * (lane >> 3)) = h2f(f2h_bits(d));
+        put_scale_q80<S1>(dst, lane >> 3, d, sum);
 }
 
 // Two blocks per pass (deep rows: a wave owns several super-blocks): lane l holds the EIGHT values 8 (l & 31) + e of
@@ -852,6 +952,7 @@ __device__ static inline void stage_f32_q8k_wave2(uint8_t *dst, const float4 va,
         *(float *)(dst + XBLK_D) = d;
 }
 
+template <bool S1>
 __device__ static inline void stage_f32_q80_wave2(uint8_t *dst, const float4 va, const float4 vb, int lane) {
     const float v[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
     float am = 0.0f;
@@ -873,8 +974,9 @@ __device__ static inline void stage_f32_q80_wave2(uint8_t *dst, const float4 va,
     const int other = (int)dpp_u32<DPP_XOR2>((uint32_t)hs);
     if ((grp & 2) == 0)
         put_pair(dst, grp, hs + other);
+    const int pair = hs + other; // groups grp, grp ^ 2; with the neighbour pair: the four groups of the 32-block
     if ((grp & 3) == 0)
-        *(float *)(dst + XBLK_D + 4 * (grp >> 2)) = h2f(f2h_bits(d));
+        put_scale_q80<S1>(dst, grp >> 2, d, pair + (int)dpp_u32<DPP_XOR1>((uint32_t)pair));
 }
 
 // one block of already-quantised activations, staged by one wave (lanes 0..31: one 8-code group each)
@@ -894,11 +996,17 @@ __device__ static inline void stage_quantised_wave(uint8_t *dst, const uint8_t *
             if (grp == 0)
                 *(float *)(dst + XBLK_D) = *(const __attribute__((address_space(1))) float *)y;
         } else {
-            const gptr blk = row + (size_t)(b * 8 + (grp >> 2)) * 34;
-            const __attribute__((address_space(1))) uint16_t *src = (const __attribute__((address_space(1))) uint16_t *)(blk + 2 + 8 * (grp & 3));
+            constexpr bool S1 = ACT == LFAMD_TYPE_Q8_1;
+            const gptr blk = row + (size_t)(b * 8 + (grp >> 2)) * (S1 ? 36 : 34);
+            const __attribute__((address_space(1))) uint16_t *src = (const __attribute__((address_space(1))) uint16_t *)(blk + (S1 ? 4 : 2) + 8 * (grp & 3));
             y0 = (uint32_t)src[0] | ((uint32_t)src[1] << 16), y1 = (uint32_t)src[2] | ((uint32_t)src[3] << 16);
-            if ((grp & 3) == 0)
-                *(float *)(dst + XBLK_D + 4 * (grp >> 2)) = h2f(*(const __attribute__((address_space(1))) uint16_t *)blk);
+            if ((grp & 3) == 0) {
+                const __attribute__((address_space(1))) uint16_t *hdr = (const __attribute__((address_space(1))) uint16_t *)blk;
+                if constexpr (S1)
+                    *(uint32_t *)(dst + XBLK_D + 4 * (grp >> 2)) = (uint32_t)hdr[0] | ((uint32_t)hdr[1] << 16);
+                else
+                    *(float *)(dst + XBLK_D + 4 * (grp >> 2)) = h2f(hdr[0]);
+            }
         }
         const int hs = put_group(dst, grp, y0, y1);
         const int other = (int)dpp_u32<DPP_XOR2>((uint32_t)hs); // group grp ^ 2
@@ -1132,7 +1240,7 @@ __device__ __forceinline__ void gemv_kq_body1(const gemv_mats &mats, int nb, con
         if constexpr (TR::ACT == LFAMD_TYPE_Q8_K)                                                                      \
             stage_f32_q8k_wave(dst, KQ_F4(xv[0]), lane);                                                               \
         else                                                                                                           \
-            stage_f32_q80_wave(dst, KQ_F4(xv[0]), lane);                                                               \
+            stage_f32_q80_wave<TR::ACT == LFAMD_TYPE_Q8_1>(dst, KQ_F4(xv[0]), lane);                                   \
     } else {                                                                                                           \
         _Pragma("unroll") for (int ps = 0; ps < 2; ps++) {                                                             \
             const int b = wave + NW * ((j0) + 2 * ps + (lane >> 5));                                                   \
@@ -1140,7 +1248,7 @@ __device__ __forceinline__ void gemv_kq_body1(const gemv_mats &mats, int nb, con
             if constexpr (TR::ACT == LFAMD_TYPE_Q8_K)                                                                  \
                 stage_f32_q8k_wave2(dst, KQ_F4(xv[2 * ps]), KQ_F4(xv[2 * ps + 1]), lane);                              \
             else                                                                                                       \
-                stage_f32_q80_wave2(dst, KQ_F4(xv[2 * ps]), KQ_F4(xv[2 * ps + 1]), lane);                              \
+                stage_f32_q80_wave2<TR::ACT == LFAMD_TYPE_Q8_1>(dst, KQ_F4(xv[2 * ps]), KQ_F4(xv[2 * ps + 1]), lane);  \
         }                                                                                                              \
     }
         KQ_STAGE_GROUP(0) // (peeled: inside the loop below the back edge would hide the weight loads from the wait counts)
@@ -1638,6 +1746,21 @@ static hipError_t launch_q2k(const gemv_mats &mats, int n_ht, long k, const void
 template <int NC, int BT>
 static hipError_t launch_q3k(const gemv_mats &mats, int n_ht, long k, const void *B, size_t brb, long col0, hipStream_t s) {
     return launch_kq_pick<pck_traits<LFAMD_TYPE_Q3_K>, NC, BT>(mats, n_ht, k, B, brb, col0, s);
+}
+
+template <int NC, int BT>
+static hipError_t launch_q41(const gemv_mats &mats, int n_ht, long k, const void *B, size_t brb, long col0, hipStream_t s) {
+    return launch_kq_pick<pcl_traits<LFAMD_TYPE_Q4_1>, NC, BT>(mats, n_ht, k, B, brb, col0, s);
+}
+
+template <int NC, int BT>
+static hipError_t launch_q50(const gemv_mats &mats, int n_ht, long k, const void *B, size_t brb, long col0, hipStream_t s) {
+    return launch_kq_pick<pcl_traits<LFAMD_TYPE_Q5_0>, NC, BT>(mats, n_ht, k, B, brb, col0, s);
+}
+
+template <int NC, int BT>
+static hipError_t launch_q51(const gemv_mats &mats, int n_ht, long k, const void *B, size_t brb, long col0, hipStream_t s) {
+    return launch_kq_pick<pcl_traits<LFAMD_TYPE_Q5_1>, NC, BT>(mats, n_ht, k, B, brb, col0, s);
 }
 
 template <int NC, int BT>

@@ -318,11 +318,12 @@ extern "C" size_t lfamd_wprep32_bytes(long rows, long cols) {
     return (size_t)((rows + 31) / 32) * (size_t)(cols / 256) * PCL_TILE;
 }
 
-extern "C" hipError_t lfamd_launch_wprep32(int type, const void *raw, long rows, long cols, void *out, hipStream_t s) {
+extern "C" hipError_t lfamd_launch_wprep32(int type, const void *raw, size_t raw_row_bytes, long rows, long cols, void *out,
+                                           hipStream_t s) {
     const int nb = (int)(cols / 256);
     const long n_tiles = ((rows + 31) / 32) * nb;
     const long threads = n_tiles * 1536;
-    const size_t rrb = lfamd_row_size(type, cols);
+    const size_t rrb = raw_row_bytes;
     const unsigned grid = (unsigned)((threads + 255) / 256);
     if (type == LFAMD_TYPE_Q4_1)
         wprep32_kernel<LFAMD_TYPE_Q4_1><<<grid, 256, 0, s>>>((const uint8_t *)raw, rrb, rows, nb, (uint8_t *)out, n_tiles);

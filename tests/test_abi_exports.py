@@ -48,6 +48,9 @@ def test_packed_size_is_exactly_gguf_size_for_aligned_shapes():
     # resident canonical images (the layout GEMM and GEMV both read): PCK for Q2_K / Q3_K, PC8 for IQ4_XS
     assert lib.lfamd_packed_size(T.Q2_K, 4096, 4096) == lib.lfamd_packed_size(T.Q3_K, 4096, 4096) == 128 * 16 * 5248
     assert lib.lfamd_packed_size(T.IQ4_XS, 4096, 4096) == 128 * 16 * 8704
+    for t in (T.Q4_1, T.Q5_0, T.Q5_1):  # PCL when rows are whole 256-weight groups, RAW otherwise (like Q4_0 / P40)
+        assert lib.lfamd_packed_size(t, 4096, 4096) == 128 * 16 * 6144
+        assert lib.lfamd_packed_size(t, 64, 96) == 64 * T.row_size(t, 96)
     assert lib.lfamd_packed_size(T.Q4_K, 32, 100) == 0  # cols not a block multiple
     assert lib.lfamd_packed_size(99, 32, 256) == 0  # unknown type
 

@@ -38,7 +38,7 @@ _Z4demov: ; @demo
     assert isa_hazards.check_asm(ok)["_Z4demov"] == []
 
 
-GEMV_TUS = ["gemv_q4k.hip", "gemv_q5k.hip", "gemv_q6k.hip", "gemv_q40.hip", "gemv_q2k.hip", "gemv_q3k.hip", "gemv_iq4xs.hip",
+GEMV_TUS = ["gemv_q4k.hip", "gemv_q5k.hip", "gemv_q6k.hip", "gemv_q40.hip", "gemv_q41.hip", "gemv_q50.hip", "gemv_q51.hip", "gemv_q2k.hip", "gemv_q3k.hip", "gemv_iq4xs.hip",
             "gemv_dual.hip"]
 
 
