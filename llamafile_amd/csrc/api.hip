@@ -27,6 +27,8 @@ hipError_t lfamd_launch_prep_f32(const void *, size_t, long, long, long, void *,
 hipError_t lfamd_launch_wprep16(int, const void *, size_t, long, long, void *, hipStream_t);
 size_t lfamd_wprep16_bytes(long, long);
 hipError_t lfamd_launch_generic(int, const void *, long, long, int, const void *, size_t, long, float *, long, hipStream_t);
+hipError_t lfamd_launch_gemv_float(int, const void *, long, long, int, const void *, size_t, long, float *, long, hipStream_t);
+int lfamd_gemv_float_ok(int, long, long);
 hipError_t lfamd_launch_gemv(int, const void *, long, long, int, const void *, size_t, long, float *, long, int, int,
                              hipStream_t);
 hipError_t lfamd_launch_gemv_multi(int, int, const void *const *, const long *, long, int, const void *, size_t, long,
@@ -451,6 +453,10 @@ int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const v
         size_t n_pad = align_up((size_t)n, 128);
         HIPCHK(lfamd_launch_prep_float(Atype, Btype, d_B, b_row_bytes, n, (long)n_pad, k, d_ws, s), "prep_float");
         HIPCHK(lfamd_launch_gemm_wide(Atype, d_A, m, k, d_ws, d_ws, d_ws, n, (long)n_pad, d_C, ldc, plain, nullptr, 0, s), "gemm_wide");
+        return LFAMD_OK;
+    }
+    if (float_a && n <= 8 && !(flags & LFAMD_FLAG_FORCE_GENERIC) && lfamd_gemv_float_ok(Atype, k, n)) { // decode on float weights
+        HIPCHK(lfamd_launch_gemv_float(Atype, d_A, m, k, Btype, d_B, b_row_bytes, n, d_C, ldc, s), "gemv_float");
         return LFAMD_OK;
     }
     if (use_gemm_canon32(Atype, n, flags, k)) {

@@ -167,6 +167,10 @@ def random_weights_torch(t: int, rows: int, cols: int, seed: int, device="cuda")
 
     g = torch.Generator(device=device)
     g.manual_seed(seed)
+    if t in (T.F32, T.F16, T.BF16):  # float weights: uniform in [-1, 1)
+        w = torch.rand((rows, cols), device=device, generator=g) * 2.0 - 1.0
+        w = w.to({T.F32: torch.float32, T.F16: torch.float16, T.BF16: torch.bfloat16}[t])
+        return w.view(torch.uint8).reshape(rows, -1)
     nb = cols // T.BLCK[t]
     ts = T.TYPE_SIZE[t]
     raw = torch.randint(0, 256, (rows, nb, ts), dtype=torch.uint8, device=device, generator=g)
