@@ -649,6 +649,20 @@ static __device__ unsigned long long g_gemv_stamps[4 * 16 * 16];
 extern "C" __attribute__((weak)) int lfamd_debug_gemv_stamps(unsigned long long *dst) { // per TU; dev only
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_gemv_stamps), sizeof(g_gemv_stamps));
 }
+// entry / exit time and placement (HW_ID, XCC_ID) of wave 0 of every work-group
+static __device__ unsigned long long g_gemv_wg[512 * 4];
+extern "C" __attribute__((weak)) int lfamd_debug_gemv_wgs(unsigned long long *dst) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_gemv_wg), sizeof(g_gemv_wg));
+}
+#define GWG(slot)                                                                                                \
+    do {                                                                                                         \
+        if (blockIdx.x < 512 && threadIdx.x == 0) {                                                              \
+            g_gemv_wg[blockIdx.x * 4 + (slot)] = __builtin_amdgcn_s_memrealtime();                               \
+            if ((slot) == 0)                                                                                     \
+                g_gemv_wg[blockIdx.x * 4 + 2] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) |  \
+                                                ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32); \
+        }                                                                                                        \
+    } while (0)
 #define GSTAMP()                                                                                                 \
     do {                                                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                                       \
@@ -665,6 +679,7 @@ extern "C" __attribute__((weak)) int lfamd_debug_gemv_stamps(unsigned long long 
 #else
 #define GSTAMP()
 #define GSTAMP_ARRIVAL()
+#define GWG(slot)
 #endif
 
 // The body of a GEMV work-group: work-group `bid` of `gdim` over the half-tiles of `mats` (the plain kernel passes its
@@ -975,8 +990,9 @@ __device__ static inline void stage_f32_q80_wave2(uint8_t *dst, const float4 va,
     if ((grp & 2) == 0)
         put_pair(dst, grp, hs + other);
     const int pair = hs + other; // groups grp, grp ^ 2; with the neighbour pair: the four groups of the 32-block
+    const int sum = pair + (int)dpp_u32<DPP_XOR1>((uint32_t)pair); // (all lanes active: a DPP source lane must be)
     if ((grp & 3) == 0)
-        put_scale_q80<S1>(dst, grp >> 2, d, pair + (int)dpp_u32<DPP_XOR1>((uint32_t)pair));
+        put_scale_q80<S1>(dst, grp >> 2, d, sum);
 }
 
 // one block of already-quantised activations, staged by one wave (lanes 0..31: one 8-code group each)
@@ -1113,12 +1129,13 @@ __device__ __forceinline__ void gemv_kq_body1(const gemv_mats &mats, int nb, con
 #if GEMV_DIAG
     int stamp_n = 0;
 #endif
+    GWG(0);
     GSTAMP();
     // the activation loads need only the leading (preloaded) kernel arguments: they go out before the rest of the
     // arguments has even arrived (-amdgpu-kernarg-preload-count, Makefile)
     // GEMV_CH == 1 (launched for nb <= NW only): ONE block per wave, a float4 per lane.  Deeper rows: FOUR blocks per
     // group as two passes of two (lane l: eight values of block (l >> 5) of the pass), four loads per lane.
-    constexpr int JX = GEMV_CH == 1 ? 1 : 4;
+    constexpr int JX = GEMV_CH == 1 ? 1 : (NW == 8 ? 2 : 4);
     const uint8_t *xrow = B + col0 * b_row_bytes;
     const lfamd_rsrc rx = make_rsrc(xrow, (uint32_t)nb * 1024u);
     uint4 xv[JX];
@@ -1242,7 +1259,7 @@ __device__ __forceinline__ void gemv_kq_body1(const gemv_mats &mats, int nb, con
         else                                                                                                           \
             stage_f32_q80_wave<TR::ACT == LFAMD_TYPE_Q8_1>(dst, KQ_F4(xv[0]), lane);                                   \
     } else {                                                                                                           \
-        _Pragma("unroll") for (int ps = 0; ps < 2; ps++) {                                                             \
+        _Pragma("unroll") for (int ps = 0; ps < JX / 2; ps++) {                                                        \
             const int b = wave + NW * ((j0) + 2 * ps + (lane >> 5));                                                   \
             uint8_t *dst = b < nb ? lds + (size_t)b * XBLK : dummy;                                                    \
             if constexpr (TR::ACT == LFAMD_TYPE_Q8_K)                                                                  \
@@ -1286,6 +1303,9 @@ __device__ __forceinline__ void gemv_kq_body1(const gemv_mats &mats, int nb, con
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     GSTAMP();
 
+    // (measured and rejected, round 2: TWO items ahead for deep rows — both buffers issued before the staging so that all of
+    // a wave's weights of a k = 14336 row are in flight while the row is quantised: 9.5 -> 10.5 us Q4_K, 14.9 -> 16.4 Q6_K;
+    // the younger waves' activation loads then queue behind twice as many weight loads of the older waves)
     // pairs of items without a branch inside (a conditionally skipped consume leaves its buffer's loads "pending" at
     // the loop header for hipcc's wait-count pass, which then drains vmcnt(0) before every issue), then the odd one
     for (;;) {
@@ -1301,6 +1321,7 @@ __device__ __forceinline__ void gemv_kq_body1(const gemv_mats &mats, int nb, con
     }
     if (cc.ht < n_ht)
         KQ_CONSUME(bufA);
+    GWG(1);
 #undef KQ_ADVANCE
 #undef KQ_ISSUE
 #undef KQ_CONSUME
@@ -1655,29 +1676,31 @@ static hipError_t launch_kq(const gemv_mats &mats, int n_ht, long k, const void 
     return go(gemv_kq_kernel<TR, NC, BT, NW, CH>);
 }
 
-template <typename TRA, typename TRB, int BT>
-static hipError_t launch_kq_dual(const gemv_mats &ma, int n_ht_a, const gemv_mats &mb, int n_ht_b, long k, const void *B,
-                                 size_t brb, hipStream_t s) {
-    const int nb = (int)(k / 256);
-    constexpr int NW = 16;
+template <typename TRA, typename TRB, int BT, int NW, int CH>
+static hipError_t launch_kq_dual_nw(const gemv_mats &ma, int n_ht_a, const gemv_mats &mb, int n_ht_b, int nb, const void *B,
+                                    size_t brb, hipStream_t s) {
     const size_t smem = (size_t)nb * XBLK + 2 * NW * 16 * sizeof(float) + (size_t)NW * XBLK; // (+ dummy slots)
     // one persistent grid shared in proportion to the half-tile counts (cf. launch_kq)
     const int max_wg = num_cus();
     const int per_wg = (n_ht_a + n_ht_b + max_wg - 1) / max_wg;
     const int grid_a = (n_ht_a + per_wg - 1) / per_wg, grid_b = (n_ht_b + per_wg - 1) / per_wg;
-    if (nb <= 16) {
-        auto kernel = gemv_kq_dual_kernel<TRA, TRB, BT, NW, 1>;
-        kernel<<<grid_a + grid_b, NW * 64, smem, s>>>((const uint8_t *)B, brb, nb, n_ht_a, n_ht_b, grid_a, grid_b, ma, mb);
-    } else {
-        auto kernel = gemv_kq_dual_kernel<TRA, TRB, BT, NW, 2>;
-        if (smem > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-            if (e != hipSuccess)
-                return e;
-        }
-        kernel<<<grid_a + grid_b, NW * 64, smem, s>>>((const uint8_t *)B, brb, nb, n_ht_a, n_ht_b, grid_a, grid_b, ma, mb);
+    auto kernel = gemv_kq_dual_kernel<TRA, TRB, BT, NW, CH>;
+    if (smem > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess)
+            return e;
     }
+    kernel<<<grid_a + grid_b, NW * 64, smem, s>>>((const uint8_t *)B, brb, nb, n_ht_a, n_ht_b, grid_a, grid_b, ma, mb);
     return hipGetLastError();
+}
+
+template <typename TRA, typename TRB, int BT>
+static hipError_t launch_kq_dual(const gemv_mats &ma, int n_ht_a, const gemv_mats &mb, int n_ht_b, long k, const void *B,
+                                 size_t brb, hipStream_t s) {
+    const int nb = (int)(k / 256);
+    if (nb <= 16)
+        return launch_kq_dual_nw<TRA, TRB, BT, 16, 1>(ma, n_ht_a, mb, n_ht_b, nb, B, brb, s);
+    return launch_kq_dual_nw<TRA, TRB, BT, 16, 2>(ma, n_ht_a, mb, n_ht_b, nb, B, brb, s);
 }
 
 template <typename TR, int BT>
@@ -1708,6 +1731,13 @@ static hipError_t launch_kq_pick(const gemv_mats &mats, int n_ht, long k, const 
                                  hipStream_t s) {
     const long nb = k / 256;
     if constexpr (NC == 1) {
+        // a launch of at most one half-tile per CU (attn_output, attn_k/v alone: the whole kernel is one prologue + one
+        // item) runs 8 waves of two super-blocks each: half as many waves contend for a SIMD while the row is quantised
+        // (two blocks per pass cost 140 VALU against 2 x 120) — 4096 x 4096: 4.35 -> 3.88 us, 1024 x 4096: 3.65 -> 3.27,
+        // 4096 x 8192: 6.83 -> 6.49.  With more tiles per work-group the 16-wave form streams better (14336 x 4096:
+        // 8.4 vs 9.1 us), and rows of 56 super-blocks lose too (9.4 vs 10.3).
+        if (n_ht <= num_cus() && nb <= 32)
+            return launch_kq<TR, NC, BT, 8, 2>(mats, n_ht, k, B, brb, col0, s);
         if (nb <= 16)
             return launch_kq<TR, NC, BT, 16, 1>(mats, n_ht, k, B, brb, col0, s);
         return launch_kq<TR, NC, BT, 16, 2>(mats, n_ht, k, B, brb, col0, s);
