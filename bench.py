@@ -583,7 +583,7 @@ def run():
                 tj = None
         except (KeyError, ValueError, OSError):
             tj = None
-    kname = "gemv_kq_kernel<q4k_traits, 1, F32, 16, {1,2}>" if dom_type == T.Q4_K else "gemv_q80_kernel<1, F32, mode>"
+    kname = "gemv_kq_kernel<q4k_traits, 1, F32, {16 | 8 waves}, {1,2}> (all Q4_K decode launches of a pass)" if dom_type == T.Q4_K else "gemv_q80_kernel<1, F32, mode>"
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": kname, "launches_per_pass": launches_per_pass, "mat_muls_per_pass": len(dom_ops),

@@ -1153,13 +1153,15 @@ __device__ __forceinline__ void gemv_kq_body1(const gemv_mats &mats, int nb, con
     }
     // pre-quantised Q8_K rows, one block per wave: the block's codes (8 bytes per lane of the lower half-wave) and its scale
     // are fetched here too, ahead of the weights
-    constexpr bool PRE1 = BT == LFAMD_TYPE_Q8_K && TR::ACT == LFAMD_TYPE_Q8_K && JX == 1;
+    // (two blocks per wave in the 8-wave form: the upper half-wave fetches block wave + NW)
+    constexpr bool PRE1 = BT == LFAMD_TYPE_Q8_K && TR::ACT == LFAMD_TYPE_Q8_K && JX <= 2;
     uint2 pq = make_uint2(0, 0);
     uint32_t pd = 0;
+    const int pre_b = JX == 1 ? wave : wave + NW * (lane >> 5);
     if constexpr (PRE1) {
         const lfamd_rsrc rq = make_rsrc(xrow, (uint32_t)nb * 292u);
-        pq = buf_ld8(rq, (uint32_t)wave * 292u + 36u + (uint32_t)(lane & 31) * 8u);
-        pd = __builtin_amdgcn_raw_buffer_load_b32(rq, (uint32_t)wave * 292u, 0, 0);
+        pq = buf_ld8(rq, (uint32_t)pre_b * 292u + 36u + (uint32_t)(lane & 31) * 8u);
+        pd = __builtin_amdgcn_raw_buffer_load_b32(rq, (uint32_t)pre_b * 292u, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     }
     // a single-matrix launch (attn_output, ffn_down) knows its weights from the preloaded arguments: its first item goes
@@ -1283,7 +1285,7 @@ __device__ __forceinline__ void gemv_kq_body1(const gemv_mats &mats, int nb, con
         else
             KQ_ISSUE(bufA);
         GSTAMP();
-        if constexpr (PRE1) {
+        if constexpr (PRE1 && JX == 1) {
             if (wave < nb && lane < 32) {
                 uint8_t *dst = lds + (size_t)wave * XBLK;
                 const int hs = put_group(dst, lane, pq.x, pq.y);
@@ -1293,6 +1295,20 @@ __device__ __forceinline__ void gemv_kq_body1(const gemv_mats &mats, int nb, con
                 if (lane == 0)
                     *(uint32_t *)(dst + XBLK_D) = pd;
             }
+        } else if constexpr (PRE1) {
+            { // both half-waves, straight-line (a block past the row was fetched as zeros and lands in the dummy slot)
+                uint8_t *dummy = (uint8_t *)(red + 2 * NW * 16) + (size_t)wave * XBLK;
+                uint8_t *dst = pre_b < nb ? lds + (size_t)pre_b * XBLK : dummy;
+                const int grp = lane & 31;
+                const int hs = put_group(dst, grp, pq.x, pq.y);
+                const int other = (int)dpp_u32<DPP_XOR2>((uint32_t)hs);
+                if ((grp & 2) == 0)
+                    put_pair(dst, grp, hs + other);
+                if (grp == 0)
+                    *(uint32_t *)(dst + XBLK_D) = pd;
+            }
+            for (int b = wave + 2 * NW; b < nb; b += NW)
+                stage_quantised_wave<TR::ACT>(lds + (size_t)b * XBLK, xrow, b, lane);
         } else {
             for (int b = wave; b < nb; b += NW)
                 stage_quantised_wave<TR::ACT>(lds + (size_t)b * XBLK, xrow, b, lane);
@@ -1736,6 +1752,7 @@ static hipError_t launch_kq_pick(const gemv_mats &mats, int n_ht, long k, const 
         // (two blocks per pass cost 140 VALU against 2 x 120) — 4096 x 4096: 4.35 -> 3.88 us, 1024 x 4096: 3.65 -> 3.27,
         // 4096 x 8192: 6.83 -> 6.49.  With more tiles per work-group the 16-wave form streams better (14336 x 4096:
         // 8.4 vs 9.1 us), and rows of 56 super-blocks lose too (9.4 vs 10.3).
+        // (the same form for f32 and pre-quantised rows: the two launches stay bit-identical)
         if (n_ht <= num_cus() && nb <= 32)
             return launch_kq<TR, NC, BT, 8, 2>(mats, n_ht, k, B, brb, col0, s);
         if (nb <= 16)
