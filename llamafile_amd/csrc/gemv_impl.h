@@ -1696,10 +1696,25 @@ template <typename TRA, typename TRB, int BT, int NW, int CH>
 static hipError_t launch_kq_dual_nw(const gemv_mats &ma, int n_ht_a, const gemv_mats &mb, int n_ht_b, int nb, const void *B,
                                     size_t brb, hipStream_t s) {
     const size_t smem = (size_t)nb * XBLK + 2 * NW * 16 * sizeof(float) + (size_t)NW * XBLK; // (+ dummy slots)
-    // one persistent grid shared in proportion to the half-tile counts (cf. launch_kq)
+    // one persistent grid of at most one work-group per CU, split between the types so that the slower side finishes
+    // first: a Q6_K half-tile costs about 1.35 Q4_K / Q5_K ones (dot instructions and bytes), and with equal tiles per
+    // work-group the few Q6_K work-groups of attn_v set the launch's length (7.06 -> see DESIGN §4)
     const int max_wg = num_cus();
-    const int per_wg = (n_ht_a + n_ht_b + max_wg - 1) / max_wg;
-    const int grid_a = (n_ht_a + per_wg - 1) / per_wg, grid_b = (n_ht_b + per_wg - 1) / per_wg;
+    int grid_a = 0, grid_b = 0;
+    long best = -1;
+    for (int pb = 1; pb <= n_ht_b; pb++) {
+        const int gb = (n_ht_b + pb - 1) / pb;
+        if (gb >= max_wg)
+            continue;
+        const int pa = (n_ht_a + (max_wg - gb) - 1) / (max_wg - gb);
+        const long cost = (long)pa * 100 > (long)pb * 135 ? (long)pa * 100 : (long)pb * 135;
+        if (best < 0 || cost < best)
+            best = cost, grid_b = gb, grid_a = (n_ht_a + pa - 1) / pa;
+    }
+    if (best < 0) { // (more Q6_K half-tiles than CUs can never be one per work-group: equal shares)
+        const int per_wg = (n_ht_a + n_ht_b + max_wg - 1) / max_wg;
+        grid_a = (n_ht_a + per_wg - 1) / per_wg, grid_b = (n_ht_b + per_wg - 1) / per_wg;
+    }
     auto kernel = gemv_kq_dual_kernel<TRA, TRB, BT, NW, CH>;
     if (smem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
