@@ -1319,9 +1319,12 @@ __device__ __forceinline__ void gemv_kq_body1(const gemv_mats &mats, int nb, con
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     GSTAMP();
 
-    // (measured and rejected, round 2: TWO items ahead for deep rows — both buffers issued before the staging so that all of
-    // a wave's weights of a k = 14336 row are in flight while the row is quantised: 9.5 -> 10.5 us Q4_K, 14.9 -> 16.4 Q6_K;
-    // the younger waves' activation loads then queue behind twice as many weight loads of the older waves)
+    // (measured and rejected, round 2, twice: TWO items ahead for deep rows — the second buffer issued before the staging, or
+    // right after this wave's activations have landed and before the quantisation arithmetic; pre-quantised rows with both
+    // up front: 9.5 -> 10.5 us Q4_K, 14.9 -> 16.4 Q6_K, 11.0 / 17.6 pre-quantised.  A CU's loads return in issue order and
+    // the 256 CUs together already take what HBM gives (33 MB in ~5.2 us of a ~6.8 us kernel body): putting wave w's second
+    // item ahead of wave w+1's first only delays the moment the LAST wave can start its first dot, and both its dots
+    // then run after the stream has ended)
     // pairs of items without a branch inside (a conditionally skipped consume leaves its buffer's loads "pending" at
     // the loop header for hipcc's wait-count pass, which then drains vmcnt(0) before every issue), then the odd one
     for (;;) {
