@@ -43,7 +43,9 @@ enum lfamd_status {
 #define LFAMD_FLAG_Q0_VREGS32 1u /* restate the reference's 32-vector-register (AVX512) build of
                                     tinyBLAS_Q0: Kahan on 2x1/1x2/1x1 edge tiles (tinyblas_cpu.h:797-830) */
 #define LFAMD_FLAG_PRECISE 2u    /* FLAG_precise (--precise): Kahan everywhere in the Q0 kernels */
-#define LFAMD_FLAG_FORCE_GENERIC 4u /* debugging: route through the generic (untuned) kernel */
+#define LFAMD_FLAG_FORCE_GENERIC 4u /* debugging: the generic one-wave-per-row kernel — only for tensors kept as GGUF rows
+                                       (floats, legacy 32-block rows that are not whole 256-weight groups); packed types
+                                       answer LFAMD_ERR_UNSUPPORTED */
 #define LFAMD_FLAG_GEMM_NARROW 8u   /* testing: force the 128x64 split-K MFMA body (default: chosen by grid size) */
 #define LFAMD_FLAG_GEMM_WIDE 16u    /* testing: force the 128x128 MFMA body */
 #define LFAMD_FLAG_GEMM_PLAIN 32u   /* testing: the 128x128 body without loader waves (Q4_K / Q5_K default to them) */
@@ -73,7 +75,10 @@ int lfamd_stream_sync(void *stream);
  * them with coalesced 16-byte-per-lane loads (DESIGN.md "Data layout in HBM").  `raw` is the
  * tensor exactly as GGUF/ggml stores it: `rows` rows, `raw_row_bytes` apart, each a sequence of
  * blocks (include/lfamd_blocks.h).  Packing is a device kernel: raw and packed are device
- * pointers. */
+ * pointers.  lfamd_packed_size is the ONLY source of the packed byte count: Q4_K / Q5_K / Q6_K / Q8_0 / Q4_0 images are
+ * the GGUF size (+ tile round-up); Q2_K / Q3_K / IQ4_XS / Q4_1 / Q5_0 / Q5_1 are kept as the canonical image their MFMA
+ * and decode kernels read (164 / 164 / 272 / 192 / 192 / 192 bytes per 256 weights: up to 2x the file size, DESIGN.md
+ * section 3); legacy 32-block rows that are not whole 256-weight groups and float tensors stay as GGUF rows. */
 size_t lfamd_packed_size(int type, long rows, long cols);
 int lfamd_pack_weights(int type, long rows, long cols, const void *d_raw, size_t raw_row_bytes,
                        void *d_packed, void *stream);
