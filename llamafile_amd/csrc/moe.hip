@@ -57,10 +57,11 @@ static inline size_t align_up_(size_t x, size_t a) {
 __global__ __launch_bounds__(256) void moe_route_kernel(const int32_t *__restrict__ plan, long tokens, int thinkers, int tasks,
                                                         int experts, int n_slots, int *__restrict__ cnt, int *__restrict__ poff,
                                                         int *__restrict__ slot_row, int *__restrict__ src_row) {
-    __shared__ int s_cnt[256], s_off[256];
-    extern __shared__ uint8_t s_plan[]; // expert id per row (0xFF: none): the ordered fill below scans LDS, not global memory
+    __shared__ int s_cnt[256], s_run[256]; // rows per expert; next free slot of every expert during the ordered fill
+    __shared__ int s_wave[4][256];         // rows of expert e held by wave w in the current block of 256 rows
+    extern __shared__ uint8_t s_plan[];    // expert id per row (0xFF: none)
     const long R = tokens * thinkers;
-    const int t = threadIdx.x;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     s_cnt[t] = 0;
     for (int sl = t; sl < n_slots; sl += 256)
         slot_row[sl] = -1, src_row[sl] = -1;
@@ -76,26 +77,43 @@ __global__ __launch_bounds__(256) void moe_route_kernel(const int32_t *__restric
     if (t == 0) {
         int off = 0;
         for (int e = 0; e < experts; e++) {
-            s_off[e] = off;
+            s_run[e] = off;
             off += (s_cnt[e] + 127) / 128 * 128;
         }
     }
     __syncthreads();
     if (t < experts) {
         cnt[t] = s_cnt[t];
-        poff[t] = s_off[t];
-        int sl = s_off[t];
-        long tok = 0;
-        int th = 0;
-        for (long r = 0; r < R; r++) { // stable: (token, thinker) order
-            if (s_plan[r] == t) {
-                slot_row[sl] = (int)r;
-                src_row[sl] = (int)(tok * tasks + th % tasks);
-                sl++;
-            }
-            if (++th == thinkers)
-                th = 0, tok++;
+        poff[t] = s_run[t];
+    }
+    // Ordered fill, 256 rows at a time: a row's slot = its expert's running base + the rows of that expert in earlier
+    // waves of the block + those in lower lanes of its own wave (one ballot per expert) — the stable (token, thinker)
+    // order of build_row_pointers without a serial scan (the scan by `experts` threads took 109 us for 1024 rows).
+    for (long base = 0; base < R; base += 256) {
+        const long r = base + t;
+        const int e = r < R ? (int)s_plan[r] : 0xFF;
+        int rank = 0;
+        for (int ex = 0; ex < experts; ex++) {
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(e == ex);
+            if (e == ex)
+                rank = __builtin_popcountll(m & ((1ull << lane) - 1ull));
+            if (lane == 0)
+                s_wave[wave][ex] = __builtin_popcountll(m);
         }
+        __syncthreads();
+        if (e != 0xFF) {
+            int sl = s_run[e] + rank;
+            for (int w = 0; w < wave; w++)
+                sl += s_wave[w][e];
+            const long tok = r / thinkers;
+            const int th = (int)(r - tok * thinkers);
+            slot_row[sl] = (int)r;
+            src_row[sl] = (int)(tok * tasks + th % tasks);
+        }
+        __syncthreads();
+        if (t < experts)
+            s_run[t] += s_wave[0][t] + s_wave[1][t] + s_wave[2][t] + s_wave[3][t];
+        __syncthreads();
     }
 }
 

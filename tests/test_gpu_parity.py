@@ -565,3 +565,31 @@ def test_mul_mat_id_batches_grouped_on_device(gpu, oracle, t, tokens, tasks, f32
             got = np.stack([res[tok, th] for tok, th in sel])
             assert rel_err(got, golden[ex]) <= tol, (ex, flags, rel_err(got, golden[ex]))
         assert (res[-1, -1] == -7.0).all()
+
+
+def test_mul_mat_id_routing_many_experts(gpu):
+    """Device-side routing with many experts and a ragged row count (40 experts, 171 tokens x 3 thinkers = 513 rows: three
+    blocks of the ordered fill, the last with one row): every result row equals its expert's row for its
+    activation row in the plain batch mat-mul of that expert (exact integer codes on both sides: LFAMD_FLAG_PRECISE), rows with an out-of-range id stay untouched."""
+    from llamafile_amd import synth, _hip
+    t, rows, cols, experts, thinkers, tokens, tasks = T.Q4_K, 64, 512, 40, 3, 171, 3
+    Ws = [gpu.upload_weights(t, synth.random_weights(t, rows, cols, 1200 + e), rows, cols) for e in range(experts)]
+    packed = torch.cat([W.data for W in Ws])
+    x = synth.random_activations(tokens * tasks, cols, 79)
+    xq = torch.from_numpy(synth.quantize_activations(T.Q8_K, x)).cuda()
+    rng = np.random.default_rng(8)
+    plan = rng.integers(0, experts, size=(tokens, thinkers)).astype(np.int32)
+    plan[5, 1] = -1
+    plan[170, 2] = experts
+    res = gpu.mul_mat_id(packed, t, rows, cols, experts, xq, T.Q8_K, tasks, tokens, torch.from_numpy(plan).cuda(), thinkers,
+                         flags=gpu.host_variant_flags() | _hip.FLAG_PRECISE, prefill=-7.0).cpu().numpy()
+    assert (res[5, 1] == -7.0).all() and (res[170, 2] == -7.0).all()
+    fl = gpu.host_variant_flags() | _hip.FLAG_PRECISE
+    per_expert = {e: gpu.mul_mat(Ws[e], xq, T.Q8_K, flags=fl).cpu().numpy() for e in range(experts)}  # [tokens*tasks, rows]
+    worst = 0.0
+    for tok in range(tokens):
+        for th in range(thinkers):
+            e = int(plan[tok, th])
+            if 0 <= e < experts:
+                worst = max(worst, rel_err(res[tok, th], per_expert[e][tok * tasks + th % tasks]))
+    assert worst <= GEMM_TOL[t], worst
