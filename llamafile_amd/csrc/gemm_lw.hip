@@ -53,7 +53,7 @@ __device__ __forceinline__ void gemm_lw_body(const gemm_mats &mats, int nb, cons
                                              const float *__restrict__ d8T, const _Float16 *__restrict__ Xm, long n, long n_pad,
                                              int n_rb, int n_ct, int ks, float *__restrict__ P, const int bid, const int gdim,
                                              uint8_t *lds) {
-    static_assert(TYPE == LFAMD_TYPE_Q4_K || TYPE == LFAMD_TYPE_Q5_K || (TYPE == LFAMD_TYPE_Q6_K && FAST && !MOE),
+    static_assert(TYPE == LFAMD_TYPE_Q4_K || TYPE == LFAMD_TYPE_Q5_K || (TYPE == LFAMD_TYPE_Q6_K && FAST),
                   "resident K-quant layouts; Q6_K on the scaled-operand body only");
     static_assert(NT == 4 || (NT == 2 && FAST && !MOE), "the 64-token tile exists for the scaled-operand body only");
     constexpr int COLS = 32 * NT;
@@ -713,8 +713,10 @@ hipError_t lfamd_lw_go(int Atype, const gemm_mats &mats, int nb, const void *Xh,
         LW_GO2(LFAMD_TYPE_Q4_K);
     } else if (Atype == LFAMD_TYPE_Q5_K) {
         LW_GO2(LFAMD_TYPE_Q5_K);
-    } else if (Atype == LFAMD_TYPE_Q6_K && fast && !moe) { // scaled-operand body only
-        if (nt == 2)
+    } else if (Atype == LFAMD_TYPE_Q6_K && fast) { // scaled-operand body only
+        if (moe)
+            LW_GO(LFAMD_TYPE_Q6_K, true, true, 4);
+        else if (nt == 2)
             LW_GO(LFAMD_TYPE_Q6_K, false, true, 2);
         else
             LW_GO(LFAMD_TYPE_Q6_K, false, true, 4);

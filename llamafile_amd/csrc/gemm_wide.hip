@@ -83,7 +83,7 @@ static void split_mats(const gemm_mats &mats, int rb_cut, size_t row_tile_bytes,
 static hipError_t wide_go(int Atype, int mode, float *P, size_t P_bytes, WIDE_ARGS) {
     const int g_scaled = (mode >> 1) & 1;
     const bool q45 = Atype == LFAMD_TYPE_Q4_K || Atype == LFAMD_TYPE_Q5_K;
-    if ((q45 || (Atype == LFAMD_TYPE_Q6_K && g_scaled && !moe)) && lw_allowed(mode)) {
+    if ((q45 || (Atype == LFAMD_TYPE_Q6_K && g_scaled)) && lw_allowed(mode)) {
         if (g_scaled && !moe) {
             // scaled operands: 128 x 128 tiles when they fill the chip, else 128 x 64 (twice the work-groups, no K split)
             static const int full_grid = getenv("LFAMD_LW_FULL_GRID") ? atoi(getenv("LFAMD_LW_FULL_GRID")) : LW_FULL_GRID; // (tuning)
@@ -118,7 +118,7 @@ static hipError_t wide_go(int Atype, int mode, float *P, size_t P_bytes, WIDE_AR
             }
             return lfamd_lw_go(Atype, mats, nb, Xh, d8T, Xm, n, n_pad, n_rb, n_ct2, (unsigned)(n_rb * n_ct2), 0, 1, 2, 1, nullptr, s);
         }
-        if (ks == 1 && q45) // exact codes; the grouped MUL_MAT_ID launch also on scaled operands
+        if (ks == 1 && (q45 || (moe && g_scaled))) // exact codes; the grouped MUL_MAT_ID launch also on scaled operands (Q6_K: only)
             return lfamd_lw_go(Atype, mats, nb, Xh, d8T, Xm, n, n_pad, n_rb, n_ct, n_wg, moe, moe ? g_scaled : 0, 4, 1, nullptr, s);
     }
     if (g_scaled)

@@ -207,9 +207,9 @@ extern "C" hipError_t lfamd_launch_moe(int type, const void *W, long rows, long 
         hipError_t e2 = hipGetLastError();
         if (e2 != hipSuccess)
             return e2;
-        // Q4_K / Q5_K experts: scaled operands like lfamd_mul_mat's batches, unless LFAMD_FLAG_PRECISE
+        // scaled operands like lfamd_mul_mat's batches, unless LFAMD_FLAG_PRECISE
         const int plain = (flags & LFAMD_FLAG_GEMM_PLAIN) ? 1 : 0;
-        const int scaled = ((flags & LFAMD_FLAG_PRECISE) || type == LFAMD_TYPE_Q6_K) ? 0 : lfamd_gemm_wide_scaled_ok(type, plain);
+        const int scaled = (flags & LFAMD_FLAG_PRECISE) ? 0 : lfamd_gemm_wide_scaled_ok(type, plain);
         const int pmode = scaled ? 2 : 0;
         e2 = Btype == LFAMD_TYPE_F32
                  ? lfamd_launch_prep_f32(thought, b_row_bytes, (long)n_pad, (long)n_pad, cols, Xh, d8T, Xm, pmode, src_row, s)

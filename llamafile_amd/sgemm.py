@@ -201,7 +201,7 @@ def mul_mat_id(Ws: torch.Tensor, wtype: int, rows: int, cols: int, experts: int,
     [tokens*tasks, row_bytes]; plan int32 [tokens, thinkers].  Returns f32 [tokens, thinkers, rows]."""
     L = _hip.lib()
     flags = host_variant_flags() if flags is None else flags
-    if wtype in (T.Q4_K, T.Q5_K) and tokens > 4:
+    if wtype in (T.Q4_K, T.Q5_K, T.Q6_K) and tokens > 4:
         # batches run on scaled operands: check the stack's block scales once (cf. upload_weights)
         key = (Ws.data_ptr(), Ws.numel(), wtype)
         if key not in _moe_scaled_ok:

@@ -548,8 +548,8 @@ def test_mul_mat_id_batches_grouped_on_device(gpu, oracle, t, tokens, tasks, f32
         bt = T.Q8_K
     from llamafile_amd import _hip
     golden = {}
-    # batches of Q4_K / Q5_K experts: scaled operands by default, exact integer codes with LFAMD_FLAG_PRECISE
-    for flags, tol in ((0, SCALED_TOL if t in (T.Q4_K, T.Q5_K) and tokens > 4 else GEMM_TOL[t]), (_hip.FLAG_PRECISE, GEMM_TOL[t])):
+    # batches of K-quant experts: scaled operands by default, exact integer codes with LFAMD_FLAG_PRECISE
+    for flags, tol in ((0, SCALED_TOL if tokens > 4 else GEMM_TOL[t]), (_hip.FLAG_PRECISE, GEMM_TOL[t])):
         res = gpu.mul_mat_id(packed, t, rows, cols, experts, thought, bt, tasks, tokens, torch.from_numpy(plan).cuda(), thinkers,
                              flags=gpu.host_variant_flags() | flags, prefill=-7.0)
         torch.cuda.synchronize()
