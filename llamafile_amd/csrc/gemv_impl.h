@@ -658,9 +658,13 @@ extern "C" __attribute__((weak)) int lfamd_debug_gemv_wgs(unsigned long long *ds
     do {                                                                                                         \
         if (blockIdx.x < 512 && threadIdx.x == 0) {                                                              \
             g_gemv_wg[blockIdx.x * 4 + (slot)] = __builtin_amdgcn_s_memrealtime();                               \
-            if ((slot) == 0)                                                                                     \
+            if ((slot) == 0) {                                                                                   \
                 g_gemv_wg[blockIdx.x * 4 + 2] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) |  \
                                                 ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32); \
+                gwg_clk0 = __builtin_amdgcn_s_memtime();                                                         \
+            } else { /* shader-clock cycles of this work-group's life: with the 100 MHz stamps, the clock it ran at */ \
+                g_gemv_wg[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memtime() - gwg_clk0;                         \
+            }                                                                                                    \
         }                                                                                                        \
     } while (0)
 #define GSTAMP()                                                                                                 \
@@ -1128,6 +1132,7 @@ __device__ __forceinline__ void gemv_kq_body1(const gemv_mats &mats, int nb, con
     float *red = (float *)(lds + (size_t)nb * XBLK); // [2][NW][16]
 #if GEMV_DIAG
     int stamp_n = 0;
+    unsigned long long gwg_clk0 = 0;
 #endif
     GWG(0);
     GSTAMP();

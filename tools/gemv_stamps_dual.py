@@ -40,4 +40,6 @@ import collections
 place = collections.Counter((r[3], r[4], r[5], r[6]) for r in rows)
 print("distinct CUs", len(place), "max WGs on one CU", max(place.values()))
 ent = np.array([r[1] for r in rows]); ex = np.array([r[2] for r in rows])
+clk = np.array([w[b, 3] / max(1, (w[b, 1] - w[b, 0])) * 100.0 for b in np.nonzero(live)[0]])  # MHz
+print("shader clock MHz over the work-groups: min/median/max", int(clk.min()), int(np.median(clk)), int(clk.max()))
 print("entry: min/median/max", ent.min(), int(np.median(ent)), ent.max(), " exit: min/median/max", ex.min(), int(np.median(ex)), ex.max())
