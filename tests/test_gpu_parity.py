@@ -593,3 +593,32 @@ def test_mul_mat_id_routing_many_experts(gpu):
             if 0 <= e < experts:
                 worst = max(worst, rel_err(res[tok, th], per_expert[e][tok * tasks + th % tasks]))
     assert worst <= GEMM_TOL[t], worst
+
+
+@pytest.mark.parametrize("t", [T.Q2_K, T.Q3_K, T.IQ4_XS, T.Q5_1, T.Q4_0, T.Q8_0], ids=lambda t: T.NAMES[t])
+@pytest.mark.parametrize("tokens", [1, 19])
+def test_mul_mat_id_other_expert_types(gpu, oracle, t, tokens):
+    """Expert stacks of the types without a grouped kernel (gather + one mat-mul per expert, like the reference's GPU path,
+    ggml-cuda.cu.patch:18499-18635): the stack is the experts' PACKED images back to back (lfamd_packed_size apart — since
+    round 2 that is not the GGUF size for Q2_K / Q3_K / IQ4_XS / Q4_1 / Q5_0 / Q5_1); every row against the oracle."""
+    from llamafile_amd import synth
+    rows, cols, experts, thinkers, tasks = 72, 512, 5, 2, 1
+    raws = [synth.random_weights(t, rows, cols, 1300 + e) for e in range(experts)]
+    packed = torch.cat([gpu.upload_weights(t, W, rows, cols).data for W in raws])
+    x = synth.random_activations(tokens * tasks, cols, 81)
+    vdt = T.VEC_DOT[t]
+    xq = synth.quantize_activations(vdt, x)
+    rng = np.random.default_rng(9)
+    plan = np.stack([rng.permutation(experts)[:thinkers] for _ in range(tokens)]).astype(np.int32)
+    res = gpu.mul_mat_id(packed, t, rows, cols, experts, torch.from_numpy(xq).cuda(), vdt, tasks, tokens,
+                         torch.from_numpy(plan).cuda(), thinkers, prefill=-7.0).cpu().numpy()
+    for tok in range(tokens):
+        for th in range(thinkers):
+            e = int(plan[tok, th])
+            ok, G = oracle.sgemm(t, raws[e], vdt, xq[tok * tasks + th % tasks:tok * tasks + th % tasks + 1], rows, 1, cols, nth=1)
+            assert ok == 1
+            if t == T.Q8_0:
+                assert rel_err(res[tok, th], G[0]) <= 2e-6
+            else:  # (an expert with more than 8 rows runs the MFMA body: IQ4_XS rounds |sc * v| above 2048 to f16 there)
+                tol = 1e-3 if t == T.IQ4_XS and tokens > 1 else TOL.get(t, DEFAULT_TOL)
+                assert rel_err(res[tok, th], G[0]) <= tol, (T.NAMES[t], tok, th)
