@@ -57,4 +57,7 @@ dp = (pert - exact).abs()
 res["exact_path_input_perturbed_3e-4"] = {"rms_err_over_rms": float(dp.pow(2).mean().sqrt() / rms),
                                           "normwise": float(dp.max() / exact.abs().max()),
                                           "argmax_agreement": float((pert.argmax(dim=1) == exact.argmax(dim=1)).double().mean())}
+pert2 = run(base | _hip.FLAG_PRECISE, x0 * (1.0 + 3e-6 * noise)).double()
+dp2 = (pert2 - exact).abs()
+res["exact_path_input_perturbed_3e-6"] = {"rms_err_over_rms": float(dp2.pow(2).mean().sqrt() / rms)}
 print(json.dumps(res))
