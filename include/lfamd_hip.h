@@ -165,6 +165,11 @@ int lfamd_mul_mat_id(int type, const void *d_W_packed, long rows, long cols, int
 int lfamd_rms_norm_quantize(const float *d_x, size_t x_row_bytes, const float *d_weight, float eps, long nrows, long k,
                             int vec_dot_type, void *d_yq, size_t yq_row_bytes, float *d_yf, size_t yf_row_bytes, void *stream);
 
+/* The step in front of ffn_down, fused the same way: y = silu(gate) * up, silu(x) = x / (1 + expf(-x)) (silu_f32,
+ * ggml-cuda.cu.patch:16172-16179, + the MUL node), written as Q8_K blocks to d_yq and / or f32 to d_yf.  k % 256 == 0. */
+int lfamd_swiglu_quantize(const float *d_gate, size_t gate_row_bytes, const float *d_up, size_t up_row_bytes, long nrows, long k,
+                          int vec_dot_type, void *d_yq, size_t yq_row_bytes, float *d_yf, size_t yf_row_bytes, void *stream);
+
 /* ---- F16 batched GEMM (attention KQ / KQV) ------------------------------------------------------
  * The interface of tinyblasGemmStridedBatchedEx / tinyblasGemmBatchedEx (llamafile/tinyblas.h:59-71, tinyblas.cu:652-857)
  * for the operand arrangement ggml calls them with (ggml_cuda_mul_mat_batched_cublas, ggml-cuda.cu.patch:18231-18376):

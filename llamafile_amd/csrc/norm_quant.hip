@@ -1,5 +1,5 @@
-// norm_quant.hip — the step in front of the path, fused: RMS-norm x weight -> the reference's
-// Q8_K activation blocks in ONE kernel, so that the mat-muls behind a norm (attn_q/k/v, ffn_gate/up, output) receive
+// norm_quant.hip — the steps in front of the path, fused: RMS-norm x weight, and silu(gate) * up, ->
+// the reference's Q8_K activation blocks in ONE kernel each, so that the mat-muls behind a norm (attn_q/k/v, ffn_gate/up, output) receive
 // Btype = Q8_K and their prologue is a copy instead of a quantisation.
 //
 // Reference counterparts: ggml_compute_forward_rms_norm_f32 + the MUL by the norm weight (upstream ggml.c; GPU:
@@ -24,6 +24,34 @@ __device__ static inline double wave_sum_f64(double v) {
     for (int off = 32; off > 0; off >>= 1)
         v += __shfl_xor(v, off, 64);
     return v;
+}
+
+// quantize_row_q8_K on one 256-block held as four values per lane (element 4 lane + e), written in the reference's block
+// format {d, bsums[16], qs[256]} (cf. gemv_impl.h stage_f32_q8k_wave: same arithmetic)
+__device__ static inline void put_q8k_block(uint8_t *blk, const float (&y)[4], int lane) {
+    const float a0 = fabsf(y[0]), a1 = fabsf(y[1]), a2 = fabsf(y[2]), a3 = fabsf(y[3]);
+    const float amax = wave_max_f32(fmaxf(fmaxf(a0, a1), fmaxf(a2, a3)));
+    const bool m0 = a0 == amax, m1 = a1 == amax, m2 = a2 == amax, m3 = a3 == amax;
+    const unsigned long long ball = __builtin_amdgcn_ballot_w64(m0 || m1 || m2 || m3);
+    const float cand = m0 ? y[0] : (m1 ? y[1] : (m2 ? y[2] : y[3]));
+    const bool nz = amax != 0.0f;
+    const float val = nz ? readlane_f32(cand, ball ? __builtin_ctzll(ball) : 0) : 1.0f;
+    const float iscale = -128.0f / val;
+    int q[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const int c = (int)rintf(iscale * y[e]);
+        q[e] = nz ? (c > 127 ? 127 : c) : 0;
+    }
+    *(uint32_t *)(blk + 36 + 4 * lane) = (uint32_t)(q[0] & 0xff) | ((uint32_t)(q[1] & 0xff) << 8) | ((uint32_t)(q[2] & 0xff) << 16) |
+                                        ((uint32_t)(q[3] & 0xff) << 24);
+    int bs = q[0] + q[1] + q[2] + q[3];
+    bs += (int)dpp_u32<DPP_XOR1>((uint32_t)bs);
+    bs += (int)dpp_u32<DPP_XOR2>((uint32_t)bs);
+    if ((lane & 3) == 0)
+        *(int16_t *)(blk + 4 + 2 * (lane >> 2)) = (int16_t)bs;
+    if (lane == 0)
+        *(float *)blk = nz ? 1.0f / iscale : 0.0f;
 }
 
 // one work-group (4 waves) per row; wave w owns the 256-blocks w, w + 4, ...
@@ -59,32 +87,31 @@ __global__ __launch_bounds__(256) void rms_norm_q8k_kernel(const float *__restri
             *(float4 *)(frow + (size_t)b * 256 + 4 * lane) = make_float4(y[0], y[1], y[2], y[3]);
         if (!qrow)
             continue;
-        // quantize_row_q8_K on the block (cf. gemv_impl.h stage_f32_q8k_wave: same arithmetic, reference block format out)
-        const float a0 = fabsf(y[0]), a1 = fabsf(y[1]), a2 = fabsf(y[2]), a3 = fabsf(y[3]);
-        const float amax = wave_max_f32(fmaxf(fmaxf(a0, a1), fmaxf(a2, a3)));
-        const bool m0 = a0 == amax, m1 = a1 == amax, m2 = a2 == amax, m3 = a3 == amax;
-        const unsigned long long ball = __builtin_amdgcn_ballot_w64(m0 || m1 || m2 || m3);
-        const float cand = m0 ? y[0] : (m1 ? y[1] : (m2 ? y[2] : y[3]));
-        const bool nz = amax != 0.0f;
-        const float val = nz ? readlane_f32(cand, ball ? __builtin_ctzll(ball) : 0) : 1.0f;
-        const float iscale = -128.0f / val;
-        int q[4];
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            const int c = (int)rintf(iscale * y[e]);
-            q[e] = nz ? (c > 127 ? 127 : c) : 0;
-        }
-        uint8_t *blk = qrow + (size_t)b * 292;
-        *(uint32_t *)(blk + 36 + 4 * lane) = (uint32_t)(q[0] & 0xff) | ((uint32_t)(q[1] & 0xff) << 8) | ((uint32_t)(q[2] & 0xff) << 16) |
-                                            ((uint32_t)(q[3] & 0xff) << 24);
-        int bs = q[0] + q[1] + q[2] + q[3];
-        bs += (int)dpp_u32<DPP_XOR1>((uint32_t)bs);
-        bs += (int)dpp_u32<DPP_XOR2>((uint32_t)bs);
-        if ((lane & 3) == 0)
-            *(int16_t *)(blk + 4 + 2 * (lane >> 2)) = (int16_t)bs;
-        if (lane == 0)
-            *(float *)blk = nz ? 1.0f / iscale : 0.0f;
+        put_q8k_block(qrow + (size_t)b * 292, y, lane);
     }
+}
+
+// SwiGLU in front of ffn_down: y = silu(gate) * up with silu(x) = x / (1 + expf(-x)) (silu_f32, ggml-cuda.cu.patch:16172-16179;
+// ggml_silu_f32, ggml-vector.inc:1662-1664) and the MUL node, then Q8_K.  One wave per 256-block.
+__global__ __launch_bounds__(256) void swiglu_q8k_kernel(const float *__restrict__ gate, size_t gate_row_bytes, const float *__restrict__ up,
+                                                         size_t up_row_bytes, long k, uint8_t *__restrict__ yq, size_t yq_row_bytes,
+                                                         float *__restrict__ yf, size_t yf_row_bytes) {
+    const long row = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x * 4 + wave;
+    if (b >= (int)(k / 256))
+        return;
+    const float4 g = *(const float4 *)((const float *)((const uint8_t *)gate + row * gate_row_bytes) + (size_t)b * 256 + 4 * lane);
+    const float4 u = *(const float4 *)((const float *)((const uint8_t *)up + row * up_row_bytes) + (size_t)b * 256 + 4 * lane);
+    const float gv[4] = {g.x, g.y, g.z, g.w}, uv[4] = {u.x, u.y, u.z, u.w};
+    float y[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++)
+        y[e] = (gv[e] / (1.0f + expf(-gv[e]))) * uv[e];
+    if (yf)
+        *(float4 *)((float *)((uint8_t *)yf + row * yf_row_bytes) + (size_t)b * 256 + 4 * lane) = make_float4(y[0], y[1], y[2], y[3]);
+    if (yq)
+        put_q8k_block(yq + row * yq_row_bytes + (size_t)b * 292, y, lane);
 }
 
 } // namespace
@@ -102,6 +129,28 @@ extern "C" int lfamd_rms_norm_quantize(const float *d_x, size_t x_row_bytes, con
         return LFAMD_OK;
     rms_norm_q8k_kernel<<<(unsigned)nrows, 256, 0, (hipStream_t)stream>>>(d_x, x_row_bytes, d_weight, eps, k, (uint8_t *)d_yq, yq_row_bytes,
                                                                             d_yf, yf_row_bytes);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        lfamd_set_error(hipGetErrorString(e));
+        return LFAMD_ERR_HIP;
+    }
+    return LFAMD_OK;
+}
+
+extern "C" int lfamd_swiglu_quantize(const float *d_gate, size_t gate_row_bytes, const float *d_up, size_t up_row_bytes, long nrows,
+                                     long k, int vec_dot_type, void *d_yq, size_t yq_row_bytes, float *d_yf, size_t yf_row_bytes,
+                                     void *stream) {
+    if (nrows < 0 || k <= 0 || k % 256 || (d_yq && vec_dot_type != LFAMD_TYPE_Q8_K) || (!d_yq && !d_yf) || !d_gate || !d_up ||
+        ((uintptr_t)d_gate & 15) || (gate_row_bytes & 15) || ((uintptr_t)d_up & 15) || (up_row_bytes & 15) || ((uintptr_t)d_yf & 15) ||
+        (yf_row_bytes & 15) || ((uintptr_t)d_yq & 3) || (yq_row_bytes & 3) || nrows > 65535) {
+        lfamd_set_error("lfamd_swiglu_quantize: k must be a multiple of 256, output format Q8_K, 16-byte aligned f32 rows, <= 65535 rows");
+        return LFAMD_ERR_INVALID;
+    }
+    if (nrows == 0)
+        return LFAMD_OK;
+    const dim3 grid((unsigned)((k / 256 + 3) / 4), (unsigned)nrows);
+    swiglu_q8k_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(d_gate, gate_row_bytes, d_up, up_row_bytes, k, (uint8_t *)d_yq, yq_row_bytes,
+                                                            d_yf, yf_row_bytes);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         lfamd_set_error(hipGetErrorString(e));
