@@ -455,7 +455,8 @@ int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const v
         HIPCHK(lfamd_launch_gemm_wide(Atype, d_A, m, k, d_ws, d_ws, d_ws, n, (long)n_pad, d_C, ldc, plain, nullptr, 0, s), "gemm_wide");
         return LFAMD_OK;
     }
-    if (float_a && n <= 8 && !(flags & LFAMD_FLAG_FORCE_GENERIC) && lfamd_gemv_float_ok(Atype, k, n)) { // decode on float weights
+    if (float_a && n <= 8 && !(flags & LFAMD_FLAG_FORCE_GENERIC) && lfamd_gemv_float_ok(Atype, k, n) &&
+        ((uintptr_t)d_A & 15) == 0 && ((uintptr_t)d_B & 15) == 0 && (b_row_bytes & 15) == 0) { // decode on float weights (16-byte loads)
         HIPCHK(lfamd_launch_gemv_float(Atype, d_A, m, k, Btype, d_B, b_row_bytes, n, d_C, ldc, s), "gemv_float");
         return LFAMD_OK;
     }

@@ -37,3 +37,19 @@ def test_float_decode_matches_f64_product(gpu, t, m, k, n, same_type_b):
     # every output, not just the largest: |err| <= 1e-5 * sum |w x| bound
     bound = (xb.double().abs() @ w.double().abs().T).cpu().numpy()
     assert np.all(np.abs(out - ref) <= 1e-5 * bound + 1e-30)
+
+
+def test_float_decode_unaligned_activation_stride_falls_back(gpu):
+    """Activation rows whose stride is not a 16-byte multiple cannot take the 16-byte loads of gemv_float: the dispatcher
+    hands them to the generic kernel — same result."""
+    m, k, n = 40, 512, 3
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    w = (torch.rand((m, k), device="cuda", generator=g) * 2 - 1).to(torch.float16)
+    x = torch.rand((n, k), device="cuda", generator=g) * 2 - 1
+    W = gpu.upload_weights(T.F16, w.view(torch.uint8).reshape(m, -1), m, k)
+    buf = torch.zeros((n, k * 4 + 4), dtype=torch.uint8, device="cuda")
+    buf[:, :k * 4] = x.view(torch.uint8).reshape(n, k * 4)
+    out = gpu.mul_mat(W, buf, T.F32, n=n).cpu().numpy()
+    ref = (x.double() @ w.double().T).cpu().numpy()
+    assert rel_err(out, ref) <= 2e-6
