@@ -1782,6 +1782,11 @@ static hipError_t launch_kq_pick(const gemv_mats &mats, int n_ht, long k, const 
             return launch_kq<TR, NC, BT, 16, 1>(mats, n_ht, k, B, brb, col0, s);
         return launch_kq<TR, NC, BT, 16, 2>(mats, n_ht, k, B, brb, col0, s);
     } else {
+        // several columns (n = 2..8): 16 waves when a work-group walks several half-tiles (14336 x 4096, n = 4: 24.0 ->
+        // 17.5 us), 8 waves of two blocks for single-tile launches (4096 x 4096: the same either way) and for deep rows
+        // (4096 x 14336, n = 4: 22.6 vs 23.7 us with 16)
+        if (nb <= 16 && n_ht > num_cus())
+            return launch_kq<TR, NC, BT, 16, 1>(mats, n_ht, k, B, brb, col0, s);
         if (nb <= 16)
             return launch_kq<TR, NC, BT, 8, 2>(mats, n_ht, k, B, brb, col0, s);
         return launch_kq<TR, NC, BT, 8, 4>(mats, n_ht, k, B, brb, col0, s);
