@@ -686,156 +686,6 @@ extern "C" __attribute__((weak)) int lfamd_debug_gemv_wgs(unsigned long long *ds
 #define GWG(slot)
 #endif
 
-// The body of a GEMV work-group: work-group `bid` of `gdim` over the half-tiles of `mats` (the plain kernel passes its
-// block index and grid size; the two-type kernel gives each type its own sub-grid).
-template <typename TR, int NC, int BT, int NW, int GEMV_CH, bool IDS>
-__device__ __forceinline__ void gemv_kq_body(const gemv_mats &mats, int nb, const uint8_t *__restrict__ B, size_t b_row_bytes,
-                                             long col0, int n_ht, const int bid, const int gdim, uint8_t *lds) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i16 = lane & 15, h = (lane >> 4) & 1, gsel = lane >> 5;
-    float *red = (float *)(lds + (size_t)NC * nb * XBLK); // [2][NW][NC][16]
-#if GEMV_DIAG
-    int stamp_n = 0;
-#endif
-    GSTAMP();
-
-    const int sb_per_wave = (nb + NW - 1) / NW;
-    const int cpt = (sb_per_wave + GEMV_CH - 1) / GEMV_CH; // chunks per tile
-    const int ntile = (n_ht - bid + gdim - 1) / gdim;
-    const int total = ntile * cpt;
-
-    // Loads are issued UNCONDITIONALLY through a bounds-checked buffer descriptor: a branch around a load
-    // makes hipcc fall back to s_waitcnt vmcnt(0) (the prefetch of the next item is lost), whereas a
-    // descriptor with zero records ("no item f") or an offset past the row-tile ("no super-block b")
-    // returns zeros without touching memory and keeps the counted waits exact.
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const uint32_t rt_bytes = (uint32_t)nb * TR::TILE;
-    auto issue = [&](typename TR::chunk &ch, int f) {
-        const int tile_i = f / cpt, chunk_i = f - tile_i * cpt;
-        long ht = (long)bid + (long)tile_i * gdim;
-        int j = 0;
-#pragma unroll
-        for (int jj = 1; jj < GEMV_MAX_MATS; jj++)
-            if (jj < mats.count && ht >= mats.ht_end[jj - 1])
-                j = jj;
-        const uint8_t *A = mats.A[j];
-        bool have = f < total;
-        if constexpr (IDS) { // expert picked on the device: no routing-table read-back, graph-capturable
-            const int ex = mats.ids[mats.id_idx[j]];
-            const bool ok = ex >= 0 && ex < mats.experts;
-            A += (size_t)(ok ? ex : 0) * mats.expert_bytes;
-            have = have && ok;
-        }
-        if (j > 0)
-            ht -= mats.ht_end[j - 1];
-        const int hh = (int)(ht & 1);
-        const lfamd_rsrc r = make_rsrc(A + (size_t)(ht >> 1) * rt_bytes, have ? rt_bytes : 0u);
-        const int slot = h * 32 + hh * 16 + i16, hrow = hh * 16 + i16;
-#pragma unroll
-        for (int s = 0; s < GEMV_CH; s++) {
-            const int b = wave_u + NW * (chunk_i * GEMV_CH + s); // b >= nb lands past the descriptor: zeros
-            TR::load(ch, s, r, (uint32_t)b * TR::TILE, gsel, slot, hrow);
-        }
-    };
-
-    float acc[NC];
-#pragma unroll
-    for (int c = 0; c < NC; c++)
-        acc[c] = 0.0f;
-
-    auto consume = [&](const typename TR::chunk &ch, int f) {
-        const int tile_i = f / cpt, chunk_i = f - tile_i * cpt;
-#pragma unroll
-        for (int s = 0; s < GEMV_CH; s++) {
-            const int b = wave + NW * (chunk_i * GEMV_CH + s);
-            const int bc = b < nb ? b : nb - 1;
-#pragma unroll
-            for (int c = 0; c < NC; c++) {
-                // a super-block beyond the row was loaded as zeros (d = 0): contributes exactly 0
-                acc[c] += TR::dot(ch, s, lds + (size_t)(c * nb + bc) * XBLK, gsel, h);
-            }
-        }
-        if (chunk_i == cpt - 1) { // tile finished: 4 lanes per row (h, gsel), then the waves through LDS
-            float *rb = red + (tile_i & 1) * (NW * NC * 16);
-#pragma unroll
-            for (int c = 0; c < NC; c++) {
-                float v = acc[c];
-                v += __shfl_xor(v, 16, 64);
-                v += __shfl_xor(v, 32, 64);
-                if (lane < 16)
-                    rb[(wave * NC + c) * 16 + lane] = v;
-                acc[c] = 0.0f;
-            }
-            GSTAMP();
-            __syncthreads();
-            GSTAMP();
-            if (threadIdx.x < 16 * NC) {
-                const int c = threadIdx.x >> 4, i = threadIdx.x & 15;
-                float v = 0.0f;
-#pragma unroll
-                for (int w = 0; w < NW; w++)
-                    v += rb[(w * NC + c) * 16 + i];
-                long ht = (long)bid + (long)tile_i * gdim;
-                int j = 0;
-#pragma unroll
-                for (int jj = 1; jj < GEMV_MAX_MATS; jj++)
-                    if (jj < mats.count && ht >= mats.ht_end[jj - 1])
-                        j = jj;
-                if (j > 0)
-                    ht -= mats.ht_end[j - 1];
-                const long row = (ht >> 1) * 32 + (ht & 1) * 16 + i;
-                bool ok = true;
-                if constexpr (IDS) { // an out-of-range expert id leaves its result row untouched (the host path skips it)
-                    const int ex = mats.ids[mats.id_idx[j]];
-                    ok = ex >= 0 && ex < mats.experts;
-                }
-                if (row < mats.m[j] && ok)
-                    mats.C[j][(col0 + c) * mats.ldc[j] + row] = v;
-            }
-        }
-    };
-
-    typename TR::chunk bufA, bufB;
-    if (total <= 0)
-        return; // (whole work-group: total is uniform)
-    // vmcnt retires in order: whatever is loaded first is waited for first.  In the decode case (one f32
-    // row, at most one piece per thread) fetch the activations BEFORE the first weight chunk, so the
-    // quantisation below only waits for them and the weights keep flying.
-    if (BT == LFAMD_TYPE_F32 && NC == 1 && nb * 16 <= NW * 64) {
-        float v[16];
-        const bool mine = (int)threadIdx.x < nb * 16;
-        if (mine)
-            load_piece(v, (const float *)(B + col0 * b_row_bytes), threadIdx.x);
-        issue(bufA, 0);
-        GSTAMP();
-        if (mine) {
-            if constexpr (TR::ACT == LFAMD_TYPE_Q8_K)
-                quantise_piece_q8k(lds + (size_t)(threadIdx.x >> 4) * XBLK, v, threadIdx.x & 15);
-            else
-                quantise_piece_q80<TR::ACT == LFAMD_TYPE_Q8_1>(lds + (size_t)(threadIdx.x >> 4) * XBLK, v, threadIdx.x & 15);
-        }
-        GSTAMP();
-    } else {
-        issue(bufA, 0); // in flight during the staging below
-        stage_x<BT, TR::ACT>(lds, B, b_row_bytes, col0, NC, nb);
-    }
-    __syncthreads();
-    GSTAMP();
-
-    // (issuing bufB before the staging as well, and re-issuing each buffer right after its consume, measured
-    // 10-25 % SLOWER on every decode shape: the counted waits degrade and the activation loads queue behind more
-    // weight traffic)
-    for (int f = 0; f < total; f += 2) {
-        issue(bufB, f + 1);
-        consume(bufA, f);
-        GSTAMP();
-        issue(bufA, f + 2);
-        if (f + 1 < total)
-            consume(bufB, f + 1);
-    }
-}
-
-
 // ---------------------------------------------------------------------------------------------
 // Decode body (ONE activation row).  What the stamps of the body above showed on 4096 x 4096 (tools/gemv_stamps.py):
 // 0.8 us of dependent kernel-argument rounds before the first load, then 1.4 us in which four of the sixteen waves
@@ -1034,6 +884,186 @@ __device__ static inline void stage_quantised_wave(uint8_t *dst, const uint8_t *
             put_pair(dst, grp, hs + other);
     }
 }
+
+// The body of a GEMV work-group: work-group `bid` of `gdim` over the half-tiles of `mats` (the plain kernel passes its
+// block index and grid size; the two-type kernel gives each type its own sub-grid).
+template <typename TR, int NC, int BT, int NW, int GEMV_CH, bool IDS>
+__device__ __forceinline__ void gemv_kq_body(const gemv_mats &mats, int nb, const uint8_t *__restrict__ B, size_t b_row_bytes,
+                                             long col0, int n_ht, const int bid, const int gdim, uint8_t *lds) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i16 = lane & 15, h = (lane >> 4) & 1, gsel = lane >> 5;
+    float *red = (float *)(lds + (size_t)NC * nb * XBLK); // [2][NW][NC][16]
+#if GEMV_DIAG
+    int stamp_n = 0;
+#endif
+    GSTAMP();
+
+    const int sb_per_wave = (nb + NW - 1) / NW;
+    const int cpt = (sb_per_wave + GEMV_CH - 1) / GEMV_CH; // chunks per tile
+    const int ntile = (n_ht - bid + gdim - 1) / gdim;
+    const int total = ntile * cpt;
+
+    // Loads are issued UNCONDITIONALLY through a bounds-checked buffer descriptor: a branch around a load
+    // makes hipcc fall back to s_waitcnt vmcnt(0) (the prefetch of the next item is lost), whereas a
+    // descriptor with zero records ("no item f") or an offset past the row-tile ("no super-block b")
+    // returns zeros without touching memory and keeps the counted waits exact.
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const uint32_t rt_bytes = (uint32_t)nb * TR::TILE;
+    auto issue = [&](typename TR::chunk &ch, int f) {
+        const int tile_i = f / cpt, chunk_i = f - tile_i * cpt;
+        long ht = (long)bid + (long)tile_i * gdim;
+        int j = 0;
+#pragma unroll
+        for (int jj = 1; jj < GEMV_MAX_MATS; jj++)
+            if (jj < mats.count && ht >= mats.ht_end[jj - 1])
+                j = jj;
+        const uint8_t *A = mats.A[j];
+        bool have = f < total;
+        if constexpr (IDS) { // expert picked on the device: no routing-table read-back, graph-capturable
+            const int ex = mats.ids[mats.id_idx[j]];
+            const bool ok = ex >= 0 && ex < mats.experts;
+            A += (size_t)(ok ? ex : 0) * mats.expert_bytes;
+            have = have && ok;
+        }
+        if (j > 0)
+            ht -= mats.ht_end[j - 1];
+        const int hh = (int)(ht & 1);
+        const lfamd_rsrc r = make_rsrc(A + (size_t)(ht >> 1) * rt_bytes, have ? rt_bytes : 0u);
+        const int slot = h * 32 + hh * 16 + i16, hrow = hh * 16 + i16;
+#pragma unroll
+        for (int s = 0; s < GEMV_CH; s++) {
+            const int b = wave_u + NW * (chunk_i * GEMV_CH + s); // b >= nb lands past the descriptor: zeros
+            TR::load(ch, s, r, (uint32_t)b * TR::TILE, gsel, slot, hrow);
+        }
+    };
+
+    float acc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++)
+        acc[c] = 0.0f;
+
+    auto consume = [&](const typename TR::chunk &ch, int f) {
+        const int tile_i = f / cpt, chunk_i = f - tile_i * cpt;
+#pragma unroll
+        for (int s = 0; s < GEMV_CH; s++) {
+            const int b = wave + NW * (chunk_i * GEMV_CH + s);
+            const int bc = b < nb ? b : nb - 1;
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                // a super-block beyond the row was loaded as zeros (d = 0): contributes exactly 0
+                acc[c] += TR::dot(ch, s, lds + (size_t)(c * nb + bc) * XBLK, gsel, h);
+            }
+        }
+        if (chunk_i == cpt - 1) { // tile finished: 4 lanes per row (h, gsel), then the waves through LDS
+            float *rb = red + (tile_i & 1) * (NW * NC * 16);
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                float v = acc[c];
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 32, 64);
+                if (lane < 16)
+                    rb[(wave * NC + c) * 16 + lane] = v;
+                acc[c] = 0.0f;
+            }
+            GSTAMP();
+            __syncthreads();
+            GSTAMP();
+            if (threadIdx.x < 16 * NC) {
+                const int c = threadIdx.x >> 4, i = threadIdx.x & 15;
+                float v = 0.0f;
+#pragma unroll
+                for (int w = 0; w < NW; w++)
+                    v += rb[(w * NC + c) * 16 + i];
+                long ht = (long)bid + (long)tile_i * gdim;
+                int j = 0;
+#pragma unroll
+                for (int jj = 1; jj < GEMV_MAX_MATS; jj++)
+                    if (jj < mats.count && ht >= mats.ht_end[jj - 1])
+                        j = jj;
+                if (j > 0)
+                    ht -= mats.ht_end[j - 1];
+                const long row = (ht >> 1) * 32 + (ht & 1) * 16 + i;
+                bool ok = true;
+                if constexpr (IDS) { // an out-of-range expert id leaves its result row untouched (the host path skips it)
+                    const int ex = mats.ids[mats.id_idx[j]];
+                    ok = ex >= 0 && ex < mats.experts;
+                }
+                if (row < mats.m[j] && ok)
+                    mats.C[j][(col0 + c) * mats.ldc[j] + row] = v;
+            }
+        }
+    };
+
+    typename TR::chunk bufA, bufB;
+    if (total <= 0)
+        return; // (whole work-group: total is uniform)
+    // vmcnt retires in order: whatever is loaded first is waited for first.  In the decode case (one f32
+    // row, at most one piece per thread) fetch the activations BEFORE the first weight chunk, so the
+    // quantisation below only waits for them and the weights keep flying.
+    if (BT == LFAMD_TYPE_F32 && NC == 1 && nb * 16 <= NW * 64) {
+        float v[16];
+        const bool mine = (int)threadIdx.x < nb * 16;
+        if (mine)
+            load_piece(v, (const float *)(B + col0 * b_row_bytes), threadIdx.x);
+        issue(bufA, 0);
+        GSTAMP();
+        if (mine) {
+            if constexpr (TR::ACT == LFAMD_TYPE_Q8_K)
+                quantise_piece_q8k(lds + (size_t)(threadIdx.x >> 4) * XBLK, v, threadIdx.x & 15);
+            else
+                quantise_piece_q80<TR::ACT == LFAMD_TYPE_Q8_1>(lds + (size_t)(threadIdx.x >> 4) * XBLK, v, threadIdx.x & 15);
+        }
+        GSTAMP();
+    } else if (BT == LFAMD_TYPE_F32 && GEMV_CH <= 2 && nb <= GEMV_CH * NW) {
+        // several f32 rows, shallow: wave w quantises the blocks it consumes (w, w + NW) of every column from one
+        // coalesced float4 per lane and block (the per-thread 64-byte pieces of stage_x cost 32 cache-line lookups per
+        // wave instruction); the loads go out before the weights, blocks past the row arrive as zeros and land in the
+        // wave's dummy slot
+        uint4 xv[NC][GEMV_CH];
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            const lfamd_rsrc rx = make_rsrc(B + (col0 + c) * b_row_bytes, (uint32_t)nb * 1024u);
+#pragma unroll
+            for (int u = 0; u < GEMV_CH; u++)
+                xv[c][u] = buf_ld16(rx, (uint32_t)(wave_u + NW * u) * 1024u + (uint32_t)lane * 16u);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        issue(bufA, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        uint8_t *dummy = (uint8_t *)(red + 2 * NW * NC * 16) + (size_t)wave * XBLK;
+#pragma unroll
+        for (int c = 0; c < NC; c++)
+#pragma unroll
+            for (int u = 0; u < GEMV_CH; u++) {
+                const int b = wave + NW * u;
+                uint8_t *dst = b < nb ? lds + (size_t)(c * nb + b) * XBLK : dummy;
+                const float4 v = make_float4(__builtin_bit_cast(float, xv[c][u].x), __builtin_bit_cast(float, xv[c][u].y),
+                                             __builtin_bit_cast(float, xv[c][u].z), __builtin_bit_cast(float, xv[c][u].w));
+                if constexpr (TR::ACT == LFAMD_TYPE_Q8_K)
+                    stage_f32_q8k_wave(dst, v, lane);
+                else
+                    stage_f32_q80_wave<TR::ACT == LFAMD_TYPE_Q8_1>(dst, v, lane);
+            }
+    } else {
+        issue(bufA, 0); // in flight during the staging below
+        stage_x<BT, TR::ACT>(lds, B, b_row_bytes, col0, NC, nb);
+    }
+    __syncthreads();
+    GSTAMP();
+
+    // (issuing bufB before the staging as well, and re-issuing each buffer right after its consume, measured
+    // 10-25 % SLOWER on every decode shape: the counted waits degrade and the activation loads queue behind more
+    // weight traffic)
+    for (int f = 0; f < total; f += 2) {
+        issue(bufB, f + 1);
+        consume(bufA, f);
+        GSTAMP();
+        issue(bufA, f + 2);
+        if (f + 1 < total)
+            consume(bufB, f + 1);
+    }
+}
+
 
 // the matrices of a launch as SSA values: every kernel argument is fetched in ONE round of scalar loads at the top of
 // the kernel (the empty asm pins each value in SGPRs there: left alone, hipcc turns a select of two kernel arguments
@@ -1679,7 +1709,7 @@ static int num_cus() {
 template <typename TR, int NC, int BT, int NW, int CH>
 static hipError_t launch_kq(const gemv_mats &mats, int n_ht, long k, const void *B, size_t brb, long col0, hipStream_t s) {
     int nb = (int)(k / 256);
-    size_t smem = (size_t)NC * nb * XBLK + 2 * NW * NC * 16 * sizeof(float) + (NC == 1 ? (size_t)NW * XBLK : 0); // (+ dummy slots)
+    size_t smem = (size_t)NC * nb * XBLK + 2 * NW * NC * 16 * sizeof(float) + (size_t)NW * XBLK; // (+ dummy slots)
     // persistent grid: 16 waves per CU, every work-group the same number of half-tiles
     const int max_wg = (16 / NW) * num_cus();
     const int per_wg = (n_ht + max_wg - 1) / max_wg;
