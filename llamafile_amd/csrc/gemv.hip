@@ -42,6 +42,11 @@ extern "C" hipError_t lfamd_launch_gemv_multi(int Atype, int count, const void *
     int step = max_cols_for(per_col);
     if (step == 0)
         return hipErrorInvalidValue;
+    // deep rows on the 8-wave x 4-block kernels: six and more columns per launch spill registers (256 VGPRs + 29..53
+    // spilled).  Past 32 super-blocks two passes of at most five columns are faster (4096 x 14336, n = 8: Q4_K 47.9 -> 45.8
+    // us, Q6_K 79.9 -> 67.0); at 32 the second pass costs more than the spills (4096 x 8192: 24.5 vs 29.7 us)
+    if (Atype != LFAMD_TYPE_Q8_0 && k / 256 > 32 && step > 5)
+        step = 5;
     const bool f32in = Btype == LFAMD_TYPE_F32;
     hipError_t e = hipSuccess;
     if (Atype == LFAMD_TYPE_Q8_0) {
