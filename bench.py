@@ -582,7 +582,7 @@ def run():
     # under profiles/ — counters cannot be read from inside this process
     traffic, traffic_src, tj = None, None, None
     tfile = newest_traffic_profile()
-    if tfile and dom_type == T.Q4_K and world == 1:
+    if tfile and dom_type == T.Q4_K and world == 1 and a.model == "llama3-8b-q4_k_m":  # (the profile is of THIS workload)
         try:
             tj = json.load(open(tfile))
             rel = os.path.relpath(tfile, ROOT)
