@@ -195,17 +195,23 @@ int lfamd_gemm_batched_f16(long m, long n, long k, float alpha, const void *cons
  * communicator that only ever uses the one-shot path.  RCCL (librccl.so.1) is dlopen()ed at that point, not before.
  *
  * One-shot all-reduce for decode-sized messages (n_embd * 4 bytes = 16-32 KB): every rank allocates an exchange block of
- * lfamd_oneshot_bytes(max_message_bytes) device bytes (lfamd_malloc), exports it (64-byte IPC handle), the host gathers
+ * lfamd_oneshot_bytes(max_message_bytes) bytes with lfamd_oneshot_alloc — FINE-GRAINED (uncached) device memory: ordinary
+ * hipMalloc memory is coherent between GPUs only at kernel boundaries, and attach refuses it —, exports it (64-byte IPC
+ * handle), the host gathers
  * the world's handles in rank order and every rank attaches them (the host must barrier between attach and the first
  * all-reduce).  lfamd_comm_allreduce_add_f32 then runs ONE kernel per call for messages that fit: publish (write-through),
  * flag every peer, wait (bounded), sum the world's partials in rank order — bit-identical on every rank — and add the
  * residual in the same pass.  Larger messages (the 8-16 MB prefill tensors) go through ncclAllReduce.
- * lfamd_comm_check() != 0 reports a peer that never arrived (the kernels do not hang). */
+ * A peer is waited for up to LFAMD_ONESHOT_TIMEOUT_S (default 4) seconds of wall time; then the error is latched (later
+ * calls do not wait again, their results are void) until lfamd_comm_clear_error.  lfamd_comm_check() != 0 reports it
+ * (1 + the rank that never arrived): a host must call it before trusting results — bench.py does after every timed region. */
 typedef struct lfamd_comm lfamd_comm;
 int lfamd_comm_unique_id(void *id128);
 int lfamd_comm_init(lfamd_comm **comm, int rank, int world, const void *id128);
 int lfamd_comm_destroy(lfamd_comm *comm);
 size_t lfamd_oneshot_bytes(size_t max_message_bytes);
+int lfamd_oneshot_alloc(void **d_block, size_t bytes);
+int lfamd_oneshot_free(void *d_block);
 int lfamd_oneshot_export(void *d_block, void *handle64);
 int lfamd_oneshot_attach(lfamd_comm *comm, void *d_local_block, size_t block_bytes, const void *handles_world_x_64,
                          size_t max_message_bytes);
@@ -215,6 +221,7 @@ int lfamd_comm_allreduce_add_f32(lfamd_comm *comm, const float *d_partial, const
 int lfamd_comm_allreduce_sum_f32(lfamd_comm *comm, float *d_inout, long count, void *stream);
 int lfamd_comm_allgather(lfamd_comm *comm, const void *d_send, void *d_recv, size_t bytes_per_rank, void *stream);
 int lfamd_comm_check(lfamd_comm *comm);
+int lfamd_comm_clear_error(lfamd_comm *comm);
 
 /* ---- instrumentation ------------------------------------------------------------------------
  * Average device time (microseconds, HIP events on `stream`) of `iters` back-to-back launches of

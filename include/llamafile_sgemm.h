@@ -109,6 +109,11 @@ size_t llamafile_sgemm_amd_cached_bytes(void);
 /* Drop one tensor's device copy / everything (e.g. before unmapping a model). */
 void llamafile_sgemm_amd_forget(const void *A);
 void llamafile_sgemm_amd_reset(void);
+/* A kept copy is re-validated on every use: the mapping's identity (device, inode, file offset of the tensor's first byte)
+ * and a fingerprint of sampled bytes must still match, so a model that was unmapped and whose address range now holds
+ * other bytes is packed again without the host calling _forget / _reset.  The /proc/self/maps snapshot is parsed again
+ * when an address is unknown to it or it is older than 200 ms; this counts the parses (diagnostic, tests). */
+unsigned long llamafile_sgemm_amd_maps_reads(void);
 /* FLAG_precise of the reference (--precise): Kahan summation in the Q8_0/Q4_0 kernels. */
 void llamafile_sgemm_amd_set_precise(int precise);
 

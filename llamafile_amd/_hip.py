@@ -61,12 +61,15 @@ _SIGS = {
     "lfamd_comm_init": (_i, [C.POINTER(_vp), _i, _i, _vp]),
     "lfamd_comm_destroy": (_i, [_vp]),
     "lfamd_oneshot_bytes": (_sz, [_sz]),
+    "lfamd_oneshot_alloc": (_i, [C.POINTER(_vp), _sz]),
+    "lfamd_oneshot_free": (_i, [_vp]),
     "lfamd_oneshot_export": (_i, [_vp, _vp]),
     "lfamd_oneshot_attach": (_i, [_vp, _vp, _sz, _vp, _sz]),
     "lfamd_comm_allreduce_add_f32": (_i, [_vp, _vp, _vp, _vp, _l, _vp]),
     "lfamd_comm_allreduce_sum_f32": (_i, [_vp, _vp, _l, _vp]),
     "lfamd_comm_allgather": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "lfamd_comm_check": (_i, [_vp]),
+    "lfamd_comm_clear_error": (_i, [_vp]),
     "lfamd_time_mul_mat": (_i, [_i, _vp, _l, _l, _i, _vp, _sz, _l, _vp, _l, _vp, _sz, _u, _vp, _i, _i,
                                 C.POINTER(C.c_float)]),
 }

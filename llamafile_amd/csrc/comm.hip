@@ -16,7 +16,11 @@
 
 #include <dlfcn.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+
+#include <mutex>
+#include <unordered_map>
 
 extern "C" void lfamd_set_error(const char *msg);
 hipError_t lfamd_launch_add_f32(float *y, const float *r, long n, hipStream_t s);
@@ -82,6 +86,10 @@ int nccl_fail(int rc, const char *where) {
 #define ONESHOT_WGS 8      // work-groups per launch; WG w owns chunk w of the message and flag column w
 #define ONESHOT_THREADS 256
 
+// exchange blocks handed out by lfamd_oneshot_alloc (fine-grained / uncached device memory): attach accepts no other
+static std::mutex g_blocks_mu;
+static std::unordered_map<void *, size_t> g_blocks;
+
 struct lfamd_comm {
     ncclComm_t nccl = nullptr;
     int rank = 0, world = 1;
@@ -90,6 +98,7 @@ struct lfamd_comm {
     uint8_t *peer[ONESHOT_MAX_WORLD] = {};  // every rank's block in this process' address space (peer[rank] == local)
     size_t slot_bytes = 0;                  // one message slot (two slots: consecutive calls alternate)
     int *d_state = nullptr;                 // [0] error flag, [1 .. ONESHOT_WGS] per-work-group call counters
+    long timeout_ticks = 400000000;         // 4 s of the 100 MHz wall clock (LFAMD_ONESHOT_TIMEOUT_S)
 };
 
 // exchange block: [flags: ONESHOT_MAX_WORLD x ONESHOT_WGS x 64 B][slot 0][slot 1]
@@ -100,6 +109,7 @@ struct oneshot_args {
     int rank, world;
     size_t slot_bytes;
     long count; // floats
+    long timeout_ticks; // of the 100 MHz wall clock
     int *state; // [0] error flag, [1 + w] the number of calls work-group w has served: the call's sequence number lives on
                 // the DEVICE, so a captured launch advances it on every graph replay (every rank issues the same calls)
 };
@@ -150,13 +160,16 @@ __global__ __launch_bounds__(ONESHOT_THREADS) void oneshot_allreduce_kernel(cons
     __syncthreads();
     if ((int)threadIdx.x < a.world)
         st_sys4(a.peer[threadIdx.x] + ((size_t)a.rank * ONESHOT_WGS + w) * 64, seq);
-    // 2. wait for chunk w of every rank (bounded: ~0.2 s)
+    // 2. wait for chunk w of every rank.  Bounded by WALL time (s_memrealtime, 100 MHz): a rank may be late by seconds
+    // (first-touch page-in, a slow host thread) without being lost; only after ONESHOT_TIMEOUT_S is the peer declared lost,
+    // the error latched (later calls do not wait again: results are void until lfamd_comm_clear_error) and reported by
+    // lfamd_comm_check.
     if ((int)threadIdx.x < a.world && !s_dead) {
         const uint8_t *f = mine + ((size_t)threadIdx.x * ONESHOT_WGS + w) * 64;
-        int spins = 0;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         while ((int)(ld_sys4(f) - seq) < 0) { // (sequence numbers wrap: compare as a signed difference)
             __builtin_amdgcn_s_sleep(8);
-            if (++spins > 400000) {
+            if (__builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)a.timeout_ticks) {
                 atomicExch(a.state, 1 + (int)threadIdx.x);
                 break;
             }
@@ -231,6 +244,44 @@ size_t lfamd_oneshot_bytes(size_t max_message_bytes) {
     return ONESHOT_FLAGS_BYTES + 2 * slot;
 }
 
+// The exchange block must be memory whose stores another GPU observes INSIDE a running kernel and whose loads are not
+// served from a stale local cache: fine-grained (uncached) device memory.  Ordinary hipMalloc memory is coarse-grained —
+// coherent only at kernel boundaries — and the protocol's write-through / cache-bypassing accesses alone are not a
+// documented guarantee on it across xGMI.  LFAMD_ONESHOT_ANY_MEMORY=1 lifts the check in attach (single-GPU rehearsals
+// with framework-owned buffers).
+int lfamd_oneshot_alloc(void **d_block, size_t bytes) {
+    if (!d_block || !bytes) {
+        lfamd_set_error("lfamd_oneshot_alloc: bad arguments");
+        return LFAMD_ERR_INVALID;
+    }
+    void *p = nullptr;
+    hipError_t e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained);
+    }
+    if (e != hipSuccess) {
+        lfamd_set_error(hipGetErrorString(e));
+        return LFAMD_ERR_HIP;
+    }
+    {
+        std::lock_guard<std::mutex> lk(g_blocks_mu);
+        g_blocks[p] = bytes;
+    }
+    *d_block = p;
+    return LFAMD_OK;
+}
+
+int lfamd_oneshot_free(void *d_block) {
+    if (!d_block)
+        return LFAMD_OK;
+    {
+        std::lock_guard<std::mutex> lk(g_blocks_mu);
+        g_blocks.erase(d_block);
+    }
+    return hipFree(d_block) == hipSuccess ? LFAMD_OK : LFAMD_ERR_HIP;
+}
+
 int lfamd_oneshot_export(void *d_block, void *handle64) {
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
     hipIpcMemHandle_t h;
@@ -247,6 +298,20 @@ int lfamd_oneshot_attach(lfamd_comm *c, void *d_local_block, size_t block_bytes,
     if (!c || c->world > ONESHOT_MAX_WORLD || block_bytes < lfamd_oneshot_bytes(max_message_bytes)) {
         lfamd_set_error("lfamd_oneshot_attach: bad communicator / block too small / world > 8");
         return LFAMD_ERR_INVALID;
+    }
+    {
+        static const bool any_memory = getenv("LFAMD_ONESHOT_ANY_MEMORY") && atoi(getenv("LFAMD_ONESHOT_ANY_MEMORY"));
+        std::lock_guard<std::mutex> lk(g_blocks_mu);
+        auto it = g_blocks.find(d_local_block);
+        if (!any_memory && (it == g_blocks.end() || it->second < block_bytes)) {
+            lfamd_set_error("lfamd_oneshot_attach: the exchange block must come from lfamd_oneshot_alloc (fine-grained memory)");
+            return LFAMD_ERR_INVALID;
+        }
+    }
+    if (const char *t = getenv("LFAMD_ONESHOT_TIMEOUT_S")) {
+        const double sec = atof(t);
+        if (sec > 0.0 && sec < 3600.0)
+            c->timeout_ticks = (long)(sec * 1e8);
     }
     hipError_t e = hipMemset(d_local_block, 0, ONESHOT_FLAGS_BYTES); // (the host barriers between this and the first all-reduce)
     if (e == hipSuccess)
@@ -292,6 +357,7 @@ int lfamd_comm_allreduce_add_f32(lfamd_comm *c, const float *d_partial, const fl
         a.rank = c->rank, a.world = c->world;
         a.slot_bytes = c->slot_bytes;
         a.count = count;
+        a.timeout_ticks = c->timeout_ticks;
         a.state = c->d_state;
         oneshot_allreduce_kernel<false><<<ONESHOT_WGS, ONESHOT_THREADS, 0, s>>>(a, d_partial, d_residual, d_out);
         hipError_t e = hipGetLastError();
@@ -358,6 +424,7 @@ int lfamd_comm_allgather(lfamd_comm *c, const void *d_send, void *d_recv, size_t
             a.rank = c->rank, a.world = c->world;
             a.slot_bytes = c->slot_bytes;
             a.count = (long)(bytes_per_rank / 4);
+            a.timeout_ticks = c->timeout_ticks;
             a.state = c->d_state;
             oneshot_allreduce_kernel<true><<<ONESHOT_WGS, ONESHOT_THREADS, 0, (hipStream_t)stream>>>(a, (const float *)d_send, nullptr,
                                                                                                     (float *)d_recv);
@@ -373,6 +440,13 @@ int lfamd_comm_allgather(lfamd_comm *c, const void *d_send, void *d_recv, size_t
     }
     int rc = R.AllGather(d_send, d_recv, bytes_per_rank, NCCL_INT8, c->nccl, (hipStream_t)stream);
     return rc ? nccl_fail(rc, "ncclAllGather") : LFAMD_OK;
+}
+
+// forget a latched peer-lost error (after the host has dealt with it): the next one-shot calls wait for their peers again
+int lfamd_comm_clear_error(lfamd_comm *c) {
+    if (!c || !c->d_state)
+        return LFAMD_OK;
+    return hipMemset(c->d_state, 0, sizeof(int)) == hipSuccess ? LFAMD_OK : LFAMD_ERR_HIP;
 }
 
 // 0 = no one-shot all-reduce has timed out waiting for a peer; else 1 + the rank that never arrived (synchronises)

@@ -18,6 +18,9 @@ hipError_t lfamd_wide_go_q80(WIDE_ARGS);
 
 hipError_t lfamd_lw_go(int Atype, const gemm_mats &mats, int nb, const void *Xh, const void *d8T, const void *Xm, long n, long n_pad,
                        int n_rb, int n_ct, unsigned n_wg, int moe, int fast, int nt, int ks, float *P, hipStream_t s);
+bool lfamd_ks_ok(int Atype);
+hipError_t lfamd_ks_go(int Atype, const gemm_mats &mats, int nb, const void *Xh, const void *d8T, const void *Xm, long n, long n_pad,
+                       int n_rb, int n_ct, hipStream_t s);
 hipError_t lfamd_lw_ksplit_reduce(const float *P, int ks, long n, long n_pad, long ldp, long m, float *C, long ldc,
                                   const float *tok_scale, hipStream_t s);
 
@@ -102,6 +105,8 @@ static hipError_t wide_go(int Atype, int mode, float *P, size_t P_bytes, WIDE_AR
                     if (e != hipSuccess)
                         return e;
                     const int n_ct2 = (int)((n + 63) / 64), rb_hi = n_rb - rb_cut;
+                    if (lfamd_ks_ok(Atype))
+                        return lfamd_ks_go(Atype, hi, nb, Xh, d8T, Xm, n, n_pad, rb_hi, n_ct2, s);
                     return lfamd_lw_go(Atype, hi, nb, Xh, d8T, Xm, n, n_pad, rb_hi, n_ct2, (unsigned)(rb_hi * n_ct2), 0, 1, 2, 1, nullptr, s);
                 }
                 return lfamd_lw_go(Atype, mats, nb, Xh, d8T, Xm, n, n_pad, n_rb, n_ct, (unsigned)(n_rb * n_ct), 0, 1, 4, 1, nullptr, s);
@@ -116,6 +121,8 @@ static hipError_t wide_go(int Atype, int mode, float *P, size_t P_bytes, WIDE_AR
                 return lfamd_lw_ksplit_reduce(P, ksp, n, n_pad, (long)n_rb * 128, mats.m[0], mats.C[0], mats.ldc[0],
                                               (const float *)d8T, s);
             }
+            if (lfamd_ks_ok(Atype)) // 128 x 64 tiles on the K-split-waves body (gemm_ks.hip)
+                return lfamd_ks_go(Atype, mats, nb, Xh, d8T, Xm, n, n_pad, n_rb, n_ct2, s);
             return lfamd_lw_go(Atype, mats, nb, Xh, d8T, Xm, n, n_pad, n_rb, n_ct2, (unsigned)(n_rb * n_ct2), 0, 1, 2, 1, nullptr, s);
         }
         if (ks == 1 && (q45 || (moe && g_scaled))) // exact codes; the grouped MUL_MAT_ID launch also on scaled operands (Q6_K: only)

@@ -212,14 +212,22 @@ lfamd_gguf *lfamd_gguf_open(const char *path, char *err, size_t errlen) {
         } else {
             if (t.ne[0] % blck)
                 return fail("tensor row length is not a multiple of the type's block size");
-            t.nbytes = (size_t)(ne / blck) * ts;
+            // ne / blck blocks of ts bytes each: checked, a crafted header must not wrap the byte count
+            unsigned long long nbytes = 0;
+            if (__builtin_mul_overflow((unsigned long long)(ne / blck), (unsigned long long)ts, &nbytes) || nbytes > (unsigned long long)SIZE_MAX)
+                return fail("tensor byte size overflows");
+            t.nbytes = (size_t)nbytes;
         }
         g->tensors.push_back(std::move(t));
     }
     const size_t pos = (size_t)(c.p - g->map);
     g->data_offset = (pos + g->alignment - 1) / g->alignment * g->alignment;
+    if (g->data_offset > g->size)
+        return fail("tensor data lies outside the file (or is misaligned)");
+    // t.offset is an unvalidated u64 from the file: compare without forming sums that can wrap
+    const uint64_t room = (uint64_t)(g->size - g->data_offset);
     for (const tensor_entry &t : g->tensors)
-        if (t.offset % g->alignment || g->data_offset + t.offset + t.nbytes > g->size)
+        if (t.offset % g->alignment || t.offset > room || (uint64_t)t.nbytes > room - t.offset)
             return fail("tensor data lies outside the file (or is misaligned)");
     return g;
 }

@@ -539,15 +539,16 @@ __global__ __launch_bounds__(NW * 64) void prep_scaled_kernel(const uint8_t *__r
             val = readlane_f32(val, holders ? __builtin_ctzll(holders) : 0);
             amax = bmax;
             (void)idx;
-            if (amax != 0.0f) {
-                const float iscale = -128.0f / val;
+            // (branch-free: an all-zero block gives iscale = 0 -> codes 0, d = 0, like the reference's early return; with a
+            // branch per block the four blocks of a wave cannot be scheduled into each other)
+            const bool nz = amax != 0.0f;
+            const float iscale = nz ? -128.0f / val : 0.0f;
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const int c = (int)rintf(iscale * v[e]);
-                    q[e] = c > 127 ? 127 : c;
-                }
-                d = 1.0f / iscale;
+            for (int e = 0; e < 4; e++) {
+                const int c = (int)rintf(iscale * v[e]);
+                q[e] = c > 127 ? 127 : c;
             }
+            d = nz ? 1.0f / iscale : 0.0f;
         } else {
 #pragma unroll
             for (int e = 0; e < 4; e++)
@@ -568,10 +569,16 @@ __global__ __launch_bounds__(NW * 64) void prep_scaled_kernel(const uint8_t *__r
         }
     };
     if constexpr (MAXJ > 0) {
+        if (nb == NW * NJ) { // every wave has all NJ blocks: straight-line code, the blocks' dependent chains interleave
 #pragma unroll
-        for (int j = 0; j < NJ; j++)
-            if (wave + NW * j < nb) // (wave-uniform)
+            for (int j = 0; j < NJ; j++)
                 emit(wave + NW * j, fv[j], qv[j], dv[j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < NJ; j++)
+                if (wave + NW * j < nb) // (wave-uniform)
+                    emit(wave + NW * j, fv[j], qv[j], dv[j]);
+        }
     } else {
         for (int b = wave; b < nb; b += NW) {
             load(b, fv[0], qv[0], dv[0]);

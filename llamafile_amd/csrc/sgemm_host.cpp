@@ -17,6 +17,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <atomic>
 #include <list>
@@ -55,6 +56,17 @@ struct DevBuf { // grow-only device scratch
     size_t cap = 0;
 };
 
+// Where cached host bytes came from, re-checked on every cache hit: the mapping's identity (device, inode and file offset of
+// the first byte, from /proc/self/maps; all zero for a registered range or anonymous memory) and a fingerprint of sampled
+// bytes.  A model that was munmap()ed and whose address range now holds another file, another part of the same file or
+// writable memory no longer matches and is packed again.
+struct Origin {
+    bool registered = false;
+    uint64_t dev = 0, ino = 0, off = 0;
+    uint64_t fp = 0;
+    bool same(const Origin &o) const { return registered == o.registered && dev == o.dev && ino == o.ino && off == o.off && fp == o.fp; }
+};
+
 struct CachedWeights {
     int type;
     long rows, cols;
@@ -63,16 +75,23 @@ struct CachedWeights {
     size_t bytes;
     bool exact_only = false; // block scales outside the scaled-operand GEMM's range (lfamd_scaled_gemm_ok)
     std::list<const void *>::iterator lru;
+    Origin origin;
 };
 
 // Which host bytes may be kept on the device across calls?  Only bytes the host cannot change behind our back:
 //   * ranges the host registered with llamafile_sgemm_amd_register_weights (it promises they stay put), and
 //   * addresses inside a mapping WITHOUT write permission (an mmap'd GGUF: llama.cpp maps model files PROT_READ),
-//     read from /proc/self/maps (re-read when an address is not covered by the snapshot).
-// Everything else — ggml calls llamafile_sgemm with the KV cache as `A` for KQ / KQV — is uploaded on every call.
+//     read from /proc/self/maps.  The snapshot holds EVERY mapping with its permissions and file identity; it is read again
+//     when an address is not covered by it or when it is older than MAPS_MAX_AGE_NS, so a writable address (ggml calls
+//     llamafile_sgemm with the KV cache as `A` for KQ / KQV) is answered from the snapshot instead of re-parsing the file on
+//     every call, and a read-only answer is never older than that age (the Origin check covers the window).
+// Everything else is uploaded on every call.
 struct Range {
     uintptr_t lo, hi;
+    bool ro;
+    uint64_t dev, ino, off;
 };
+constexpr int64_t MAPS_MAX_AGE_NS = 200 * 1000 * 1000;
 
 struct State {
     std::once_flag once;
@@ -84,7 +103,9 @@ struct State {
     std::list<const void *> lru; // front = most recently used
     size_t cache_bytes = 0, cache_budget = (size_t)200 << 30;
     std::map<uintptr_t, uintptr_t> registered; // lo -> hi
-    std::vector<Range> ro_maps;                // read-only mappings of /proc/self/maps, sorted
+    std::vector<Range> ro_maps;                // every mapping of /proc/self/maps, sorted by address
+    int64_t maps_time = 0;                     // CLOCK_MONOTONIC of the snapshot (0: none)
+    unsigned long maps_reads = 0;              // how often the file was parsed (tests)
     DevBuf raw, b, c, ws, plan, x, a_scratch;
     std::vector<uint8_t> h_gather; // host staging reused across MoE calls
     std::vector<float> h_out;
@@ -191,47 +212,95 @@ unsigned flags_now() {
     return g.flags | (g.precise.load(std::memory_order_relaxed) ? LFAMD_FLAG_PRECISE : 0u);
 }
 
+int64_t now_ns() {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (int64_t)ts.tv_sec * 1000000000 + ts.tv_nsec;
+}
+
 void read_ro_maps() {
     g.ro_maps.clear();
+    g.maps_time = now_ns();
+    g.maps_reads++;
     FILE *f = fopen("/proc/self/maps", "r");
     if (!f)
         return;
     char line[512];
     while (fgets(line, sizeof line, f)) {
-        unsigned long lo, hi;
+        unsigned long lo, hi, off, ino;
+        unsigned maj, mnr;
         char perms[8];
-        if (sscanf(line, "%lx-%lx %7s", &lo, &hi, perms) == 3 && perms[0] == 'r' && perms[1] == '-')
-            g.ro_maps.push_back({(uintptr_t)lo, (uintptr_t)hi});
+        if (sscanf(line, "%lx-%lx %7s %lx %x:%x %lu", &lo, &hi, perms, &off, &maj, &mnr, &ino) == 7)
+            g.ro_maps.push_back({(uintptr_t)lo, (uintptr_t)hi, perms[0] == 'r' && perms[1] == '-',
+                                 ((uint64_t)maj << 32) | mnr, (uint64_t)ino, (uint64_t)off});
     }
     fclose(f);
 }
 
-bool in_ro_map(uintptr_t lo, uintptr_t hi) {
+// 1 = [lo, hi) lies in read-only mappings (o = identity of its first byte), 0 = part of it is writable or unmapped in the
+// snapshot, -1 = the snapshot does not know the first address at all
+int lookup_maps(uintptr_t lo, uintptr_t hi, Origin *o) {
     // adjacent read-only mappings of one file may be split: walk them
     uintptr_t at = lo;
+    bool first = true;
     for (const Range &r : g.ro_maps) {
         if (r.lo <= at && at < r.hi) {
+            if (!r.ro)
+                return 0;
+            if (first) {
+                o->dev = r.dev, o->ino = r.ino, o->off = r.off + (at - r.lo);
+                first = false;
+            }
             at = r.hi;
             if (at >= hi)
-                return true;
+                return 1;
         }
     }
-    return false;
+    return first ? -1 : 0;
 }
 
-// may [p, p + bytes) be cached on the device?  Caller holds g.mu.
-bool is_immutable(const void *p, size_t bytes) {
+// sampled bytes of [p, p + bytes): 64 words spread over the range (first and last included)
+uint64_t fingerprint(const void *p, size_t bytes) {
+    uint64_t h = 0xcbf29ce484222325ull ^ bytes;
+    if (bytes < 8) {
+        for (size_t i = 0; i < bytes; i++)
+            h = (h ^ ((const uint8_t *)p)[i]) * 0x100000001b3ull;
+        return h;
+    }
+    const size_t last = bytes - 8, steps = 63;
+    for (size_t i = 0; i <= steps; i++) {
+        uint64_t w;
+        memcpy(&w, (const uint8_t *)p + (size_t)((unsigned __int128)last * i / steps), 8);
+        h = (h ^ w) * 0x100000001b3ull;
+        h ^= h >> 29;
+    }
+    return h;
+}
+
+// may [p, p + bytes) be cached on the device?  Fills *o for the answer "yes".  Caller holds g.mu.
+bool is_immutable(const void *p, size_t bytes, Origin *o) {
     const uintptr_t lo = (uintptr_t)p, hi = lo + bytes;
+    *o = Origin{};
     auto it = g.registered.upper_bound(lo);
     if (it != g.registered.begin()) {
         --it;
-        if (it->first <= lo && hi <= it->second)
+        if (it->first <= lo && hi <= it->second) {
+            o->registered = true;
+            o->fp = fingerprint(p, bytes);
             return true;
+        }
     }
-    if (in_ro_map(lo, hi))
-        return true;
-    read_ro_maps(); // the snapshot may predate the mapping
-    return in_ro_map(lo, hi);
+    int r = -1;
+    if (g.maps_time != 0 && now_ns() - g.maps_time <= MAPS_MAX_AGE_NS)
+        r = lookup_maps(lo, hi, o);
+    if (r < 0) { // no snapshot, an old one, or one that predates the mapping
+        read_ro_maps();
+        r = lookup_maps(lo, hi, o);
+    }
+    if (r != 1)
+        return false;
+    o->fp = fingerprint(p, bytes);
+    return true;
 }
 
 void drop(std::unordered_map<const void *, CachedWeights>::iterator it) {
@@ -265,7 +334,8 @@ struct DevWeights {
 bool get_weights(int type, const void *A, long rows, long cols, size_t row_bytes, DevWeights *out) {
     const size_t total = (size_t)rows * row_bytes;
     const size_t packed = g.api.packed_size(type, rows, cols);
-    if (!is_immutable(A, total)) {
+    Origin origin;
+    if (!is_immutable(A, total, &origin)) {
         auto stale = g.cache.find(A); // (a range that was unregistered or remapped writable since)
         if (stale != g.cache.end())
             drop(stale);
@@ -278,16 +348,17 @@ bool get_weights(int type, const void *A, long rows, long cols, size_t row_bytes
     auto it = g.cache.find(A);
     if (it != g.cache.end()) {
         CachedWeights &w = it->second;
-        if (w.type == type && w.rows == rows && w.cols == cols && w.row_bytes == row_bytes) {
+        if (w.type == type && w.rows == rows && w.cols == cols && w.row_bytes == row_bytes && w.origin.same(origin)) {
             g.lru.splice(g.lru.begin(), g.lru, w.lru);
             *out = {w.d_packed, w.exact_only};
             return true;
         }
-        drop(it); // same address, another view of it
+        drop(it); // same address, another view of it — or other bytes behind it (remapped since)
     }
     while (!g.lru.empty() && g.cache_bytes + packed > g.cache_budget)
         drop(g.cache.find(g.lru.back()));
     CachedWeights w{type, rows, cols, row_bytes, nullptr, packed};
+    w.origin = origin;
     while (g.api.malloc_(&w.d_packed, w.bytes) != LFAMD_OK) { // device full: evict and retry
         if (g.lru.empty())
             return false;
@@ -436,6 +507,12 @@ void llamafile_sgemm_amd_reset(void) {
     while (!g.cache.empty())
         drop(g.cache.begin());
     g.ro_maps.clear();
+    g.maps_time = 0;
+}
+
+unsigned long llamafile_sgemm_amd_maps_reads(void) {
+    std::lock_guard<std::mutex> lk(g.mu);
+    return g.maps_reads;
 }
 
 bool llamafile_sgemm(long m, long n, long k, const void *A, long lda, const void *B, long ldb, void *C, long ldc,
@@ -550,10 +627,11 @@ bool llamafile_mixmul(const struct ggml_compute_params *params, const struct ggm
     DevWeights w{nullptr, false};
     {
         const size_t span = (size_t)(experts - 1) * weights->nb[2] + (size_t)rows * weights->nb[1];
-        const bool keep = is_immutable(weights->data, span);
+        Origin origin;
+        const bool keep = is_immutable(weights->data, span, &origin);
         auto it = g.cache.find(weights->data);
         if (it != g.cache.end() && !(keep && it->second.type == wt && it->second.rows == rows * experts && it->second.cols == cols &&
-                                     it->second.row_bytes == weights->nb[1])) {
+                                     it->second.row_bytes == weights->nb[1] && it->second.origin.same(origin))) {
             drop(it);
             it = g.cache.end();
         }
@@ -590,6 +668,7 @@ bool llamafile_mixmul(const struct ggml_compute_params *params, const struct ggm
             w = {dst, in_range == 0};
             if (keep) {
                 CachedWeights nw{wt, rows * experts, cols, weights->nb[1], dst, bytes, in_range == 0};
+                nw.origin = origin;
                 g.lru.push_front(weights->data);
                 nw.lru = g.lru.begin();
                 g.cache_bytes += bytes;

@@ -83,15 +83,16 @@ class Comm:
         self.block = None
         if oneshot_bytes and world > 1:
             nbytes = int(self.L.lfamd_oneshot_bytes(oneshot_bytes))
-            self.block = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+            # fine-grained (uncached) device memory from the module: peers must see these stores inside a running kernel
+            self.block = C.c_void_p()
+            _hip.check(self.L.lfamd_oneshot_alloc(C.byref(self.block), nbytes), "lfamd_oneshot_alloc")
             hb = (C.c_char * 64)()
-            _hip.check(self.L.lfamd_oneshot_export(C.c_void_p(self.block.data_ptr()), hb), "lfamd_oneshot_export")
+            _hip.check(self.L.lfamd_oneshot_export(self.block, hb), "lfamd_oneshot_export")
             mine = torch.frombuffer(bytearray(bytes(hb)), dtype=torch.uint8).clone()
             handles = [torch.empty(64, dtype=torch.uint8) for _ in range(world)]
             dist.all_gather(handles, mine, group=group)
             allh = C.create_string_buffer(b"".join(h.numpy().tobytes() for h in handles), 64 * world)
-            _hip.check(self.L.lfamd_oneshot_attach(self.h, C.c_void_p(self.block.data_ptr()), nbytes, allh, oneshot_bytes),
-                       "lfamd_oneshot_attach")
+            _hip.check(self.L.lfamd_oneshot_attach(self.h, self.block, nbytes, allh, oneshot_bytes), "lfamd_oneshot_attach")
             dist.all_reduce(torch.zeros(1), group=group)  # (a barrier on the CPU side) every rank's flag block is zeroed and
             # mapped before the first all-reduce
 
@@ -124,7 +125,14 @@ class Comm:
     def check(self) -> int:
         return int(self.L.lfamd_comm_check(self.h))
 
+    def clear_error(self):
+        from . import _hip
+        _hip.check(self.L.lfamd_comm_clear_error(self.h), "lfamd_comm_clear_error")
+
     def close(self):
         if self.h:
             self.L.lfamd_comm_destroy(self.h)
             self.h = None
+        if self.block:
+            self.L.lfamd_oneshot_free(self.block)
+            self.block = None

@@ -57,6 +57,30 @@ def test_rejects_malformed_files(tmp_path):
         gguf.GGUFFile(q)
 
 
+def test_rejects_wrapping_offsets_and_sizes(tmp_path):
+    """A crafted tensor directory must not wrap the bounds arithmetic: an aligned offset near 2^64 (offset + nbytes wraps to a
+    small sum) and dimensions whose byte count overflows are both refused at open."""
+    q = tmp_path / "one.gguf"
+    gguf.write_gguf(q, {}, [("w", T.F32, (64, 4), np.zeros(64 * 4 * 4, dtype=np.uint8))])
+    good = bytearray(q.read_bytes())
+    # tensor info = name (u64 len + bytes), n_dims u32, ne[2] u64, type u32, offset u64 — the last 8 + 4 + 16 bytes before the
+    # aligned data section
+    info_end = good.index(b"w", 24) + 1 + 4 + 16 + 4 + 8
+    off_pos, ne_pos = info_end - 8, info_end - 8 - 4 - 16
+    assert struct.unpack_from("<Q", good, off_pos)[0] == 0 and struct.unpack_from("<QQ", good, ne_pos) == (64, 4)
+    gguf.GGUFFile(q).close()
+    for name, pos, val in [("offset near 2^64", off_pos, struct.pack("<Q", 2 ** 64 - 32)),
+                           ("offset past the end", off_pos, struct.pack("<Q", 1 << 40)),
+                           ("dims overflow bytes", ne_pos, struct.pack("<QQ", 2 ** 62, 1)),
+                           ("dims overflow product", ne_pos, struct.pack("<QQ", 2 ** 40, 2 ** 40))]:
+        bad = bytearray(good)
+        bad[pos:pos + len(val)] = val
+        b = tmp_path / ("bad_" + name.replace(" ", "_").replace("^", "") + ".gguf")
+        b.write_bytes(bytes(bad))
+        with pytest.raises(ValueError):
+            gguf.GGUFFile(b)
+
+
 @pytest.mark.gpu
 def test_sgemm_straight_from_the_mapped_file(gpu, oracle, tmp_path):
     p, ts = _model(tmp_path)

@@ -133,8 +133,11 @@ def test_prefill_gemm_full_size_properties(gpu, t, m, k):
 
 def test_gate_up_fused_launch_tail_split(gpu):
     """ffn_gate + ffn_up at 512 tokens as ONE call: 896 tiles of 128 x 128 = three full rounds + 128, whose last round runs
-    as 128 x 64 tiles (the second matrix is split at a row-block boundary).  Bit-identical to the two separate calls, which
-    run 128 x 128 tiles only (448 tiles each: no such tail) — i.e. the tile shape does not change a single bit."""
+    as 128 x 64 tiles (the second matrix is split at a row-block boundary).  Against the two separate calls, which run
+    128 x 128 tiles only (448 tiles each: no such tail): the rows that keep their tile shape are bit-identical; the Q4_K
+    128 x 64 tail runs the K-split-waves body (gemm_ks.hip) since round 3, whose two wave groups sum their K halves
+    separately — the same products in another f32 order (<= 4e-6 of the output scale; it was bit-identical on the
+    loader-wave body, which LFAMD_GEMM_NO_KS=1 still selects)."""
     from llamafile_amd import synth
     t, m, k = T.Q4_K, 14336, 4096
     Ws = [gpu.upload_weights(t, synth.random_weights_torch(t, m, k, 31 + i), m, k) for i in range(2)]
@@ -144,14 +147,18 @@ def test_gate_up_fused_launch_tail_split(gpu):
     for W, f in zip(Ws, fused):
         sep = gpu.mul_mat(W, xb, T.F32)
         assert torch.isfinite(f).all()
-        assert torch.equal(_bits(f), _bits(sep))
+        same = (_bits(f) == _bits(sep)).all(dim=0)  # per weight row
+        assert float((f - sep).abs().max()) / float(sep.abs().max()) <= 4e-6
+        # the tail = 128 tiles of 128 x 128 = 32 row blocks of the SECOND matrix
+        assert int(same.sum()) >= m - (4096 if W is Ws[1] else 0), "rows outside the 128 x 64 tail changed"
 
 
 @pytest.mark.parametrize("ta", [T.Q4_K, T.Q5_K], ids=lambda t: T.NAMES[t])
 def test_qkv_two_types_one_gemm_launch(gpu, ta):
     """attn_q / attn_k (Q4_K or Q5_K) and attn_v (Q6_K) at 512 tokens through lfamd_mul_mat_multi_types: 192 tiles of
-    128 x 128 in ONE launch whose work-groups run their own type's body.  Bit-identical to the three separate calls (which run
-    128 x 64 tiles), in the caller's node order q, v, k as well."""
+    128 x 128 in ONE launch whose work-groups run their own type's body.  Against the three separate calls (which run
+    128 x 64 tiles): bit-identical where both run the loader-wave body (Q5_K, Q6_K); the separate Q4_K calls run the
+    K-split-waves body (gemm_ks.hip, another f32 order of the same products: <= 4e-6 of the output scale)."""
     from llamafile_amd import synth
     k = 4096
     specs = [(ta, 4096), (T.Q6_K, 1024), (ta, 1024)]
@@ -162,4 +169,7 @@ def test_qkv_two_types_one_gemm_launch(gpu, ta):
     for W, f in zip(Ws, fused):
         sep = gpu.mul_mat(W, xb, T.F32)
         assert torch.isfinite(f).all()
-        assert torch.equal(_bits(f), _bits(sep)), (T.NAMES[W.type], W.rows)
+        if W.type == T.Q4_K:
+            assert float((f - sep).abs().max()) / float(sep.abs().max()) <= 4e-6, (T.NAMES[W.type], W.rows)
+        else:
+            assert torch.equal(_bits(f), _bits(sep)), (T.NAMES[W.type], W.rows)

@@ -244,6 +244,73 @@ def test_registered_and_readonly_weights_are_kept(host, oracle, tmp_path):
     assert host.llamafile_sgemm_amd_cached_bytes() == base
 
 
+def test_remapped_address_is_not_served_from_the_kept_copy(host, oracle, tmp_path):
+    """a model is munmap()ed and ANOTHER file lands at the same address (same shape, same type).  The host never
+    calls _forget / _reset; the kept copy must not be served (mapping identity + fingerprint are re-checked on a hit)."""
+    import mmap
+    t, m, n, k = T.Q4_K, 64, 1, 1024
+    A1, B, bt = make_case(t, m, n, k, seed=31)
+    A2 = synth.random_weights(t, m, k, 32)
+    kb = k // 256
+    G1 = oracle.sgemm(t, A1, bt, B, m, n, k)[1]
+    G2 = oracle.sgemm(t, A2, bt, B, m, n, k)[1]
+    assert rel_err(G1, G2) > 0.1
+    f1, f2 = tmp_path / "w1.bin", tmp_path / "w2.bin"
+    A1.tofile(f1)
+    A2.tofile(f2)
+    libc = C.CDLL(None, use_errno=True)
+    libc.mmap.restype = C.c_void_p
+    libc.mmap.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_long]
+    libc.munmap.argtypes = [C.c_void_p, C.c_size_t]
+    size = (A1.nbytes + 4095) // 4096 * 4096
+
+    def map_at(path, addr):
+        import os
+        fd = os.open(path, os.O_RDONLY)
+        flags = mmap.MAP_SHARED | (0x10 if addr else 0)  # MAP_FIXED: replaces what is mapped there
+        p = libc.mmap(addr, size, mmap.PROT_READ, flags, fd, 0)
+        os.close(fd)
+        assert p not in (None, C.c_void_p(-1).value)
+        return p
+
+    def call(addr):
+        out = np.zeros((n, m), dtype=np.float32)
+        assert host.llamafile_sgemm(m, n, kb, addr, kb, B.ctypes.data, kb, out.ctypes.data, m, 0, 1, t, bt, T.F32)
+        return out
+
+    base = host.llamafile_sgemm_amd_cached_bytes()
+    p = map_at(str(f1), None)
+    assert rel_err(call(p), G1) <= 2e-6
+    kept = host.llamafile_sgemm_amd_cached_bytes() - base
+    assert kept > 0
+    assert rel_err(call(p), G1) <= 2e-6  # (a hit)
+    assert map_at(str(f2), p) == p  # the other file, same address, no unmap seen by the library
+    got = call(p)
+    assert rel_err(got, G2) <= 2e-6, ("stale packed weights served for a remapped address", rel_err(got, G1),
+                                      host.llamafile_sgemm_amd_cached_bytes() - base, kept)
+    assert host.llamafile_sgemm_amd_cached_bytes() - base == kept
+    host.llamafile_sgemm_amd_forget(p)
+    libc.munmap(p, size)
+
+
+def test_mutable_A_does_not_reparse_maps_every_call(host):
+    """KQ / KQV enter with writable memory as A on every call: that answer comes from the snapshot (re-read at most every 200 ms)."""
+    m, n, k = 32, 1, 256
+    A = np.ones((m, k), dtype=np.float16)
+    B = np.ones((n, k), dtype=np.float32)
+    Cm = np.zeros((n, m), dtype=np.float32)
+    host.llamafile_sgemm_amd_maps_reads.restype = C.c_ulong
+    assert host.llamafile_sgemm(m, n, k, A.ctypes.data, k, B.ctypes.data, k, Cm.ctypes.data, m, 0, 1, T.F16, T.F32, T.F32)
+    r0 = host.llamafile_sgemm_amd_maps_reads()
+    import time
+    t0 = time.monotonic()
+    for _ in range(50):
+        assert host.llamafile_sgemm(m, n, k, A.ctypes.data, k, B.ctypes.data, k, Cm.ctypes.data, m, 0, 1, T.F16, T.F32, T.F32)
+    dt = time.monotonic() - t0
+    assert host.llamafile_sgemm_amd_maps_reads() - r0 <= 1 + int(dt / 0.2) + 1
+    assert np.allclose(Cm, k)
+
+
 def test_mixmul_mutated_experts(host, oracle):
     """llamafile_mixmul with writable expert weights changed in place between two calls."""
     wt, cols, rows, experts, thinkers, tokens, tasks = T.Q8_0, 512, 64, 4, 2, 3, 1
