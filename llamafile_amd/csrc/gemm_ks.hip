@@ -144,6 +144,9 @@ __global__ __launch_bounds__(512) void gemm_ks_kernel(const gemm_mats mats, int 
     const uint8_t *xs_n = uniform_ptr((const uint8_t *)Xh + (size_t)n0 * 512);
     const uint8_t *xm_n = uniform_ptr((const uint8_t *)Xm + (size_t)n0 * 32);
     const uint8_t *wt_n = uniform_ptr(A + (size_t)(active ? rt : 0) * nb * P4K_TILE + (size_t)kh * 2048);
+    // five wait states between the VALU writes of those SGPRs (v_readfirstlane) and the first vector-memory instruction that
+    // reads them: hipcc pads such hazards itself, but not in front of an asm statement (tools/isa_hazards.py checks the ISA)
+    asm volatile("s_nop 4" ::"s"(xs_n), "s"(xm_n), "s"(wt_n));
     int bx_n = 0, bw_n = 0; // the super-blocks those pointers are at
     auto advance_x = [&]() {
         if (bx_n + 1 < nb) // (uniform)

@@ -19,6 +19,9 @@ hipError_t lfamd_wide_go_q80(WIDE_ARGS);
 hipError_t lfamd_lw_go(int Atype, const gemm_mats &mats, int nb, const void *Xh, const void *d8T, const void *Xm, long n, long n_pad,
                        int n_rb, int n_ct, unsigned n_wg, int moe, int fast, int nt, int ks, float *P, hipStream_t s);
 bool lfamd_ks_ok(int Atype);
+bool lfamd_kr_ok(int Atype);
+hipError_t lfamd_kr_go(int Atype, const gemm_mats &mats128, int nb, const void *Xh, const void *d8T, const void *Xm, long n, long n_pad,
+                       int n_ct, hipStream_t s);
 hipError_t lfamd_ks_go(int Atype, const gemm_mats &mats, int nb, const void *Xh, const void *d8T, const void *Xm, long n, long n_pad,
                        int n_rb, int n_ct, hipStream_t s);
 hipError_t lfamd_lw_ksplit_reduce(const float *P, int ks, long n, long n_pad, long ldp, long m, float *C, long ldc,
@@ -90,6 +93,8 @@ static hipError_t wide_go(int Atype, int mode, float *P, size_t P_bytes, WIDE_AR
         if (g_scaled && !moe) {
             // scaled operands: 128 x 128 tiles when they fill the chip, else 128 x 64 (twice the work-groups, no K split)
             static const int full_grid = getenv("LFAMD_LW_FULL_GRID") ? atoi(getenv("LFAMD_LW_FULL_GRID")) : LW_FULL_GRID; // (tuning)
+            if (n_rb * n_ct >= full_grid && lfamd_kr_ok(Atype)) // 256 x 128 tiles on the row-split body (gemm_kr.hip)
+                return lfamd_kr_go(Atype, mats, nb, Xh, d8T, Xm, n, n_pad, n_ct, s);
             if (n_rb * n_ct >= full_grid) {
                 // full rounds of 128 x 128 tiles; a last round of at most 128 of them (half the CUs idle) runs as one round of
                 // 128 x 64 tiles instead (0.73 of the time): ffn_gate + ffn_up at 512 tokens = 896 tiles = 3 rounds + 128

@@ -24,6 +24,49 @@ def test_no_register_is_touched_before_its_load_is_waited_for():
             assert not bad, (f, kernel, bad[:3])
 
 
+KS_TUS = [("gemm_ks.hip", nb) for nb in (1, 5, 8)] + [("gemm_kr.hip", nb) for nb in (1, 3, 4)]
+
+
+@pytest.mark.skipif(not os.path.exists(isa_hazards.HIPCC), reason="needs hipcc")
+def test_k_split_and_row_split_bodies():
+    """gemm_ks / gemm_kr keep loads in flight across several periods of a rolled loop whose blocks hipcc lays out out of
+    execution order; the linear walk needs straight-line code, which a fixed trip count (-DKS_CHECK_NB) gives.  The
+    VALU-written-SGPR rule is position-local and runs on the shipped (rolled) build as well."""
+    def one(arg):
+        f, nb = arg
+        return isa_hazards.check_file(os.path.join(ROOT, "llamafile_amd", "csrc", f), (f"-DKS_CHECK_NB={nb}",))
+    with ThreadPoolExecutor(max_workers=3) as ex:
+        results = list(ex.map(one, KS_TUS))
+    for (f, nb), res in zip(KS_TUS, results):
+        assert res, f
+        for kernel, bad in res.items():
+            assert not bad, (f, nb, kernel, bad[:3])
+    import subprocess
+    import tempfile
+    for f in ("gemm_ks.hip", "gemm_kr.hip"):
+        with tempfile.NamedTemporaryFile(suffix=".s") as t:
+            subprocess.run([isa_hazards.HIPCC, *isa_hazards.FLAGS, os.path.join(ROOT, "llamafile_amd", "csrc", f), "-o", t.name],
+                           check=True, stderr=subprocess.DEVNULL)
+            for kernel, bad in isa_hazards.check_sgpr_vmem(open(t.name).read()).items():
+                assert not bad, (f, kernel, bad[:3])
+
+
+def test_checker_flags_a_valu_written_sgpr_in_front_of_vmem():
+    asm = """
+_Z4demov: ; @demo
+	v_readfirstlane_b32 s45, v3
+	v_readfirstlane_b32 s44, v2
+	global_load_dwordx4 v[10:13], v4, s[44:45] offset:0
+	s_waitcnt vmcnt(0)
+.Lfunc_end0:
+"""
+    assert isa_hazards.check_sgpr_vmem(asm)["_Z4demov"] == ["global_load_dwordx4 v[10:13], v4, s[44:45] offset:0"]
+    ok = asm.replace("v_readfirstlane_b32 s44, v2\n", "v_readfirstlane_b32 s44, v2\n\ts_nop 4\n")
+    assert isa_hazards.check_sgpr_vmem(ok)["_Z4demov"] == []
+    other = asm.replace("s[44:45]", "s[46:47]")
+    assert isa_hazards.check_sgpr_vmem(other)["_Z4demov"] == []
+
+
 def test_checker_flags_a_copy_before_the_wait():
     asm = """
 _Z4demov: ; @demo

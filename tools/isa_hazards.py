@@ -73,6 +73,48 @@ def check_asm(text):
     return res
 
 
+_SREG = re.compile(r"\bs\[(\d+):(\d+)\]|\bs(\d+)\b")
+
+
+def _sregs(tok):
+    out = set()
+    for a, b, c in _SREG.findall(tok):
+        if c:
+            out.add(int(c))
+        else:
+            out.update(range(int(a), int(b) + 1))
+    return out
+
+
+def check_sgpr_vmem(text):
+    """VALU-written SGPR (v_readfirstlane / v_readlane) read by a vector-memory instruction fewer than five wait states later:
+    hipcc pads this itself EXCEPT when the memory instruction sits inside an asm statement (a stale base address; round 3: a
+    memory fault in gemm_kr on some shapes).  -> {kernel: [offending instruction lines]}"""
+    res = {}
+    for name, body in re.findall(r"^(_Z\w+):[^\n]*\n(.*?)\.Lfunc_end", text, re.S | re.M):
+        recent = []  # (sgpr set, wait states since)
+        bad = []
+        for line in body.split("\n"):
+            l = line.strip()
+            if not l or l[0] in ";." or l.endswith(":"):
+                continue
+            op = l.split()[0]
+            states = 1
+            if op == "s_nop":
+                states = int(l.split()[1]) + 1
+            if op.startswith(("global_", "buffer_", "flat_", "scratch_")):
+                used = _sregs(l)
+                for regs, age in recent:
+                    if regs & used and age < 5:
+                        bad.append(l)
+                        break
+            recent = [(r, a + states) for r, a in recent if a + states < 8]
+            if op.startswith(("v_readfirstlane", "v_readlane")):
+                recent.append((_sregs(l.split(",")[0]), 0))
+        res[name] = bad
+    return res
+
+
 def check_decode_hygiene(path, extra_flags=()):
     """The decode GEMVs keep their weight prefetch only while hipcc can COUNT the loads in flight: a FLAT memory
     instruction anywhere in the kernel (a pointer that lost its address space) or a stack frame (closures that were not
@@ -99,7 +141,11 @@ def check_file(path, extra_flags=()):
     linear): a fixed trip count turns the loop into straight-line code."""
     with tempfile.NamedTemporaryFile(suffix=".s") as f:
         subprocess.run([HIPCC, *FLAGS, *extra_flags, path, "-o", f.name], check=True, stderr=subprocess.DEVNULL)
-        return check_asm(open(f.name).read())
+        text = open(f.name).read()
+    res = check_asm(text)
+    for k, bad in check_sgpr_vmem(text).items():
+        res[k] = res.get(k, []) + ["[VALU-written SGPR -> VMEM] " + b for b in bad]
+    return res
 
 
 if __name__ == "__main__":
