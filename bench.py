@@ -610,9 +610,9 @@ def run():
         tf = fl / (gus * 1e-6) / 1e12
         roofline_gemm = {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(tf / MFMA_F16_PEAK_TFLOPS, 4),
-                         "kernel": "prep_f32 + gemm_lw_kernel<Q4_K, 128x64 tile, scaled operands> (128 tiles of 128x128 cannot fill 256 CUs)",
+                         "kernel": "prep_scaled_kernel + gemm_ks_kernel<Q4_K> (128x64 tile, K-split waves, scaled operands; 128 tiles of 128x128 cannot fill 256 CUs)",
                          "shape": [o.m, o.k, a.prefill], "avg_launch_us": round(gus, 2)}
-        # the same measurement on the largest Q4_K shape of the model (128x128 loader-wave body, gemm_lw.hip)
+        # the same measurement on the largest Q4_K shape of the model (256x128 row-split body, gemm_kr.hip)
         big = [q for q in runner.layers[0] if q.W.type == T.Q4_K and q.m >= 8192]
         if big:
             q = big[0]
@@ -621,7 +621,7 @@ def run():
             tf = 2.0 * q.m * q.k * a.prefill / (gus * 1e-6) / 1e12
             roofline_gemm["large_shape"] = {"shape": [q.m, q.k, a.prefill], "avg_launch_us": round(gus, 2),
                                             "achieved": round(tf, 1), "frac": round(tf / MFMA_F16_PEAK_TFLOPS, 4),
-                                            "kernel": "prep_f32 + gemm_lw_kernel<Q4_K, 128x128 tile, scaled operands>"}
+                                            "kernel": "prep_scaled_kernel + gemm_kr_kernel<Q4_K> (256x128 tile, row-split waves, scaled operands)"}
 
     if roofline_gemm and tj:
         # HBM traffic of the GEMM tiles: averages over the launches of the profiled bench (each tile serves several
