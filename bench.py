@@ -45,6 +45,10 @@ def parse():
     p.add_argument("--decode", type=int, default=128)
     p.add_argument("--no-graph", action="store_true")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--ffn-block", action="store_true",
+                   help="decode: ffn_gate + ffn_up + silu*up + ffn_down as ONE lfamd_ffn_block launch (measured SLOWER than the "
+                        "separate launches on MI355X — 53 vs 23 us per block: its grid barrier costs ~26 us under the weight "
+                        "stream against ~2.6 us for the launch boundary it replaces; DESIGN.md section 4 — so off by default)")
     p.add_argument("--force-dist", action="store_true",
                    help="rehearsal: initialise the process group and issue the collectives even at world size 1")
     p.add_argument("--model", default="llama3-8b-q4_k_m", choices=["llama3-8b-q4_k_m", "llama3-8b-q8_0", "llama3-70b-q4_k_m"])
@@ -66,6 +70,7 @@ class Runner:
         self.collectives = collectives
         self.comm = comm  # llamafile_amd.tp.Comm (the C ABI's collectives); None: torch.distributed (LFAMD_COLLECTIVES=torch)
         self.flags = sgemm.host_variant_flags()
+        self.fuse_ffn = False  # batch 1: ffn_gate + ffn_up + swiglu + ffn_down as one launch (lfamd_ffn_block; --ffn-block)
         self.layers = []
         seed = 0x5EED0000
         for layer in layers:
@@ -129,13 +134,33 @@ class Runner:
         return groups
 
     def prepare(self, n):
-        """Pre-build the ctypes argument arrays of every launch of a pass at batch n."""
+        """Pre-build the ctypes argument arrays of every launch of a pass at batch n.  At batch 1 a layer's ffn_gate + ffn_up
+        group followed by its ffn_down becomes ONE lfamd_ffn_block launch (gate / up GEMV, silu * up, Q8_K, down GEMV) when
+        the fused form covers the types and sizes (self.fuse_ffn; --no-ffn-block keeps the separate launches)."""
         b = self.buf[n]
         calls = []
         for ops in self.layers:
-            for g in self._groups(ops):
+            groups = self._groups(ops)
+            gi = 0
+            while gi < len(groups):
+                g = groups[gi]
                 o0 = g[0]
                 x = b["x"][(o0.spec.input, o0.k)]
+                nxt = groups[gi + 1] if gi + 1 < len(groups) else None
+                if (n == 1 and self.fuse_ffn and len(g) == 2 and nxt is not None and len(nxt) == 1 and
+                        g[0].spec.name.endswith("ffn_gate") and g[1].spec.name.endswith("ffn_up") and
+                        nxt[0].spec.name.endswith("ffn_down") and g[0].spec.type == g[1].spec.type == T.Q4_K and g[0].m == g[1].m and
+                        g[0].k <= 4096 and nxt[0].k == g[0].m and nxt[0].k <= 15360 and nxt[0].spec.type in (T.Q4_K, T.Q6_K)):
+                    od = nxt[0]
+                    key = (od.m, 0)
+                    if key not in b["out"]:
+                        b["out"][key] = torch.empty((n, od.m), dtype=torch.float32, device=self.dev)
+                    out = b["out"][key]
+                    if "ffn_ws" not in b:
+                        b["ffn_ws"] = torch.empty(int(self.L.lfamd_ffn_block_workspace(g[0].m)), dtype=torch.uint8, device=self.dev)
+                    calls.append(("ffn", g + [od], x, [out], None, None, None, None))
+                    gi += 2
+                    continue
                 cnt = len(g)
                 outs = []
                 for j, o in enumerate(g):
@@ -147,24 +172,41 @@ class Runner:
                 C_arr = (C.c_void_p * cnt)(*[t.data_ptr() for t in outs])
                 m_arr = (C.c_long * cnt)(*[o.m for o in g])
                 t_arr = (C.c_int * cnt)(*[o.spec.type for o in g])
-                calls.append((g, x, outs, A_arr, C_arr, m_arr, t_arr))
+                calls.append(("mm", g, x, outs, A_arr, C_arr, m_arr, t_arr))
+                gi += 1
         b["calls"] = calls
 
     def run_pass(self, n, only_type=None):
         """Launch every GGML_OP_MUL_MAT of the model at batch n on the current stream: f32 activations in
-        (quantisation is fused into the kernels), sibling ops sharing an input fused per layer.
-        `only_type`: restrict to the launches of one weight type, no collectives (roofline measurement).
-        Returns (launches, ops)."""
+        (quantisation is fused into the kernels), sibling ops sharing an input fused per layer, the feed-forward block one
+        launch at batch 1.  `only_type`: restrict to the launches all of whose matrices are of one weight type, no collectives
+        (roofline measurement).  Returns (launches, ops)."""
         L, b = self.L, self.buf[n]
         if "calls" not in b:
             self.prepare(n)
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         ws, wsn = C.c_void_p(b["ws"].data_ptr()), b["ws"].numel()
         launches = nops = 0
-        for g, x, outs, A_arr, C_arr, m_arr, t_arr in b["calls"]:
+        for kind, g, x, outs, A_arr, C_arr, m_arr, t_arr in b["calls"]:
             o0 = g[0]
             types = {o.spec.type for o in g}
             if only_type is not None and types != {only_type}:
+                continue
+            if kind == "ffn":
+                og, ou, od = g
+                fw = b["ffn_ws"]
+                rc = L.lfamd_ffn_block(og.spec.type, C.c_void_p(og.W.data.data_ptr()), C.c_void_p(ou.W.data.data_ptr()), og.m, og.k,
+                                       od.spec.type, C.c_void_p(od.W.data.data_ptr()), od.m, C.c_void_p(x.data_ptr()), None,
+                                       C.c_void_p(outs[0].data_ptr()), C.c_void_p(fw.data_ptr()), fw.numel(), stream)
+                if rc:
+                    _hip.check(rc, "ffn_block " + og.spec.name)
+                launches += 1
+                nops += 3
+                if only_type is None and self.collectives and od.spec.shard == "cols":
+                    if self.comm is not None:
+                        self.comm.allreduce_add(outs[0])
+                    else:
+                        torch.distributed.all_reduce(outs[0])
                 continue
             rc = L.lfamd_mul_mat_multi_types(len(g), t_arr, A_arr, m_arr, o0.k, T.F32, C.c_void_p(x.data_ptr()),
                                              x.stride(0) * 4, n, C_arr, m_arr, ws, wsn, self.flags, stream)
@@ -451,6 +493,7 @@ def run():
     layers = {"llama3-8b-q4_k_m": LS.llama3_8b_q4_k_m, "llama3-8b-q8_0": LS.llama3_8b_q8_0,
               "llama3-70b-q4_k_m": LS.llama3_70b_q4_k_m}[a.model]()
     runner = Runner(layers, rank, world, (a.prefill, 1), dev, collectives=dist_on, comm=comm)
+    runner.fuse_ffn = a.ffn_block
 
     def barrier():
         torch.cuda.synchronize()
@@ -573,8 +616,16 @@ def run():
     avg_us = us / n_launch
     # algorithmic bytes per launch: weights once + f32 activations (once per launch: sibling
     # ops fused into a launch share them) + f32 outputs
-    groups = [g for ops in runner.layers for g in runner._groups(ops) if {o.spec.type for o in g} == {dom_type}]
-    alg_bytes = sum(sum(o.m * T.row_size(dom_type, o.k) + o.m * 4 for o in g) + g[0].k * 4 for g in groups)
+    # (a fused feed-forward launch: its three matrices, the f32 row in, the f32 row out — gate / up / h never leave the chip's
+    # caches as far as the algorithm is concerned)
+    dom_calls = [c for c in runner.buf[1]["calls"] if {o.spec.type for o in c[1]} == {dom_type}]
+    alg_bytes = 0
+    for kind, g, *_ in dom_calls:
+        if kind == "ffn":
+            alg_bytes += sum(o.m * T.row_size(dom_type, o.k) for o in g) + g[0].k * 4 + g[2].m * 4
+        else:
+            alg_bytes += sum(o.m * T.row_size(dom_type, o.k) + o.m * 4 for o in g) + g[0].k * 4
+    n_fused = sum(1 for c in dom_calls if c[0] == "ffn")
     avg_bytes = alg_bytes / launches_per_pass
     achieved = avg_bytes / (avg_us * 1e-6) / 1e9
     # HBM traffic per launch: from the rocprofv3 PMC passes of this same workload (tools/profile_round.sh:
@@ -594,7 +645,8 @@ def run():
                 tj = None
         except (KeyError, ValueError, OSError):
             tj = None
-    kname = "gemv_kq_kernel<q4k_traits, 1, F32, {16 | 8 waves}, {1,2}> (all Q4_K decode launches of a pass)" if dom_type == T.Q4_K else "gemv_q80_kernel<1, F32, mode>"
+    kname = ("gemv_kq_kernel<q4k_traits, 1, F32, {16 | 8 waves}, {1,2}>" + (f" + ffn_block_kernel<q4k, q4k> ({n_fused} fused feed-forward launches)" if n_fused else "") +
+             " (all decode launches of a pass whose matrices are all Q4_K)") if dom_type == T.Q4_K else "gemv_q80_kernel<1, F32, mode>"
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": kname, "launches_per_pass": launches_per_pass, "mat_muls_per_pass": len(dom_ops),
@@ -649,7 +701,7 @@ def run():
         "dtype": "int8",
         "data": "synthetic",
         "config": {
-            "workload": f"{a.model} mat-muls ({sum(len(l) for l in layers)} GGML_OP_MUL_MAT per pass, f32 activations in, quantisation fused, sibling ops fused at decode), "
+            "workload": f"{a.model} mat-muls ({sum(len(l) for l in layers)} GGML_OP_MUL_MAT per pass, f32 activations in, quantisation fused, sibling ops fused at decode" + (", feed-forward block (gate, up, silu*up, Q8_K, down) one launch at decode" if a.ffn_block else "") + "), "
                         f"{a.prefill}-token prefill + {a.decode} decode, matmul-only",
             "numerics": "decode: exact int8 x int4/int6 block dot products with f32 scales (v_dot4_i32_i8); prefill: f16 MFMA, "
                         "f32 accumulate, Q4_K and Q6_K on scaled operands f16(d*sc*q) x f16(d8*code) (<= 1e-3 relative, measured "
@@ -660,6 +712,8 @@ def run():
             "prefill_tokens_per_s": round(a.prefill / (pf_us * 1e-6), 1),
             "decode_tokens_per_s": round(1.0 / (dc_us * 1e-6), 1),
             "prefill_pass_ms": round(pf_us / 1e3, 3), "decode_pass_ms": round(dc_us / 1e3, 4),
+            "decode_launches_per_pass": sum(1 for _ in runner.buf[1]["calls"]),
+            "decode_GBps_whole_pass": round(runner.weight_bytes() / (dc_us * 1e-6) / 1e9, 1),
         },
         "roofline": roofline,
     }

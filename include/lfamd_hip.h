@@ -183,6 +183,24 @@ int lfamd_gemm_strided_batched_f16(long m, long n, long k, float alpha, const vo
 int lfamd_gemm_batched_f16(long m, long n, long k, float alpha, const void *const *d_Aarray, long lda, const void *const *d_Barray,
                            long ldb, float beta, void *const *d_Carray, int Ctype, long ldc, int batch, void *stream);
 
+/* ---- the decode feed-forward block as ONE launch -------------------------------------------
+ * d_out[m_out] = W_down x quantize_q8_K( silu(W_gate x q(x)) * (W_up x q(x)) )  (+ d_residual), one activation row x[k] (f32).
+ * Replaces five graph nodes of a llama feed-forward at batch 1 — GGML_OP_MUL_MAT (ffn_gate), GGML_OP_MUL_MAT (ffn_up),
+ * GGML_OP_SILU * GGML_OP_MUL, the activation quantiser, GGML_OP_MUL_MAT (ffn_down) [+ GGML_OP_ADD]; reference kernels
+ * mul_mat_vec_q + quantize_q8_1 (ggml-cuda.cu.patch:14428-14575, 15259-15293), silu_f32 (:16172-16179) — with the arithmetic
+ * of the separate calls (lfamd_mul_mat_multi, lfamd_swiglu_quantize, lfamd_mul_mat): exact integer block dots, f32 silu,
+ * quantize_row_q8_K bit for bit.  One persistent launch with a grid-wide barrier between the two mat-mul phases; ffn_down's
+ * weights are already streaming into registers while the barrier completes (llamafile_amd/csrc/ffn_block.hip).
+ * Covers Q4_K gate / up with k <= 4096 and Q4_K / Q6_K down with n_ff <= 15360 (LFAMD_ERR_UNSUPPORTED otherwise: use the
+ * separate calls).  Launches on ONE device must not overlap each other (one barrier state per device); the barrier is
+ * bounded by wall time (LFAMD_FFN_TIMEOUT_S, default 2 s): lfamd_ffn_block_check() != 0 reports a launch whose grid was not
+ * co-resident (results void).  Packed weights as from lfamd_pack_weights; workspace = lfamd_ffn_block_workspace(n_ff) bytes. */
+size_t lfamd_ffn_block_workspace(long n_ff);
+int lfamd_ffn_block(int type_gate_up, const void *d_Wgate_packed, const void *d_Wup_packed, long n_ff, long k, int type_down,
+                    const void *d_Wdown_packed, long m_out, const float *d_x, const float *d_residual, float *d_out,
+                    void *d_workspace, size_t workspace_bytes, void *stream);
+int lfamd_ffn_block_check(void);
+
 /* ---- collectives (tensor parallel, one process per GPU) ---------------------------------------
  * The exchange step of the sharded path: attn_output / ffn_down are split by input columns and
  * the f32 partial sums of the residual stream are all-reduced; output.weight is split by vocabulary rows and the logits

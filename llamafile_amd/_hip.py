@@ -57,6 +57,9 @@ _SIGS = {
     "lfamd_gemm_strided_batched_f16": (_i, [_l, _l, _l, C.c_float, _vp, _l, C.c_longlong, _vp, _l, C.c_longlong, C.c_float, _vp, _i, _l,
                                             C.c_longlong, _i, _vp]),
     "lfamd_gemm_batched_f16": (_i, [_l, _l, _l, C.c_float, _vp, _l, _vp, _l, C.c_float, _vp, _i, _l, _i, _vp]),
+    "lfamd_ffn_block_workspace": (_sz, [_l]),
+    "lfamd_ffn_block": (_i, [_i, _vp, _vp, _l, _l, _i, _vp, _l, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "lfamd_ffn_block_check": (_i, []),
     "lfamd_comm_unique_id": (_i, [_vp]),
     "lfamd_comm_init": (_i, [C.POINTER(_vp), _i, _i, _vp]),
     "lfamd_comm_destroy": (_i, [_vp]),
