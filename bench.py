@@ -361,29 +361,47 @@ def make_comm(rank, world, same_device=False):
     use_rccl = not same_device and world > 1
     comm = tp.Comm(rank, world, use_rccl=use_rccl, oneshot_bytes=oneshot)
     comm.mode = ("RCCL" if use_rccl else "no RCCL") + (f" + one-shot peer kernel <= {oneshot} B" if oneshot and world > 1 else "")
+    comm.selftest = "not run"
     if oneshot and world > 1:
-        x = torch.full((4096,), float(rank + 1), device="cuda") + torch.arange(4096, device="cuda", dtype=torch.float32) * 1e-3
-        y = torch.empty_like(x)
-        for _ in range(3):
+        # 32 calls with data that changes per call and per rank, the ranks deliberately out of step (rank r sleeps r ms before
+        # every fourth call: a consumer that arrives early must WAIT for its peers, one that arrives late must still find
+        # their slots intact), every element checked against the closed form
+        idx = torch.arange(4096, device="cuda", dtype=torch.float32) * 1e-3
+        y = torch.empty(4096, device="cuda")
+        bad = 0
+        for it in range(32):
+            if it % 4 == 3:
+                time.sleep(1e-3 * rank)
+            x = torch.full((4096,), float((rank + 1) * (it + 1)), device="cuda") + idx
             comm.allreduce_add(x, None, y)
-        torch.cuda.synchronize()
-        want = world * (world + 1) / 2 + world * torch.arange(4096, device="cuda", dtype=torch.float32) * 1e-3
-        good = comm.check() == 0 and bool(torch.allclose(y, want, rtol=1e-6, atol=1e-6))
+            torch.cuda.synchronize()
+            want = (it + 1) * world * (world + 1) / 2 + world * idx
+            if not bool(torch.allclose(y, want, rtol=1e-6, atol=1e-6)):
+                bad += 1
+        good = comm.check() == 0 and bad == 0
         flag = torch.tensor([1 if good else 0])
         torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+        comm.selftest = f"passed 32/32 on every rank" if int(flag.item()) else f"FAILED ({bad}/32 wrong on rank {rank}, check {comm.check()})"
         if not int(flag.item()):
             if rank == 0:
                 print("bench.py: one-shot peer all-reduce failed its self-test on this node: RCCL for every size", file=sys.stderr)
             comm.close()
             comm = tp.Comm(rank, world, use_rccl=True, oneshot_bytes=0)
             comm.mode = "RCCL (one-shot self-test failed)"
+            comm.selftest = "one-shot FAILED -> RCCL only"
     if use_rccl or "self-test failed" in comm.mode:  # the RCCL path too, on a message beyond the one-shot slot
         big = torch.full((1 << 18,), float(rank + 1), device="cuda")
         comm.allreduce_add(big)
         torch.cuda.synchronize()
         if abs(float(big[0].item()) - world * (world + 1) / 2) > 1e-3 or abs(float(big[-1].item()) - world * (world + 1) / 2) > 1e-3:
             raise RuntimeError("RCCL all-reduce through the C ABI returned a wrong sum")
-    comm.describe = lambda: comm.mode + ", through the C ABI"
+    comm.oneshot_eff = oneshot if (oneshot and world > 1 and "self-test failed" not in comm.mode) else 0
+    rccl_on = use_rccl or "self-test failed" in comm.mode
+    comm.describe = lambda: (
+        (f"all-reduce <= {comm.oneshot_eff} B: one-shot peer kernel in fine-grained memory (self-test {comm.selftest}); " if comm.oneshot_eff else "")
+        + ("larger all-reduces and the logits all-gather: ncclAllReduce / ncclAllGather (RCCL, known-answer check passed)" if rccl_on
+           else "no RCCL (ranks share a device): every size on the one-shot kernel")
+        + ", through the C ABI")
     comm.has_rccl = use_rccl or "self-test failed" in comm.mode
     comm.oneshot = oneshot if "self-test failed" not in comm.mode else 0
     return comm
@@ -441,6 +459,8 @@ def main():
         os.dup2(real_stdout, 1)
     if line is not None:
         os.write(real_stdout, (line + "\n").encode())
+        if '"invalid":' in line:  # collectives failed their check after the timed region: the number is void
+            sys.exit(3)
 
 
 def run():
@@ -577,6 +597,35 @@ def run():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed * 1000.0 / a.steps
+
+    # ---- the collectives of the timed region are verified AFTER it: no peer was lost (lfamd_comm_check) and one more
+    # known-answer all-reduce is right on every rank; a line measured over void sums is marked invalid and the run fails
+    comm_invalid = None
+    allreduce_us = None
+    if dist_on and comm is not None and world > 1:
+        ck = comm.check()
+        xv = torch.full((4096,), float(rank + 1), device=dev)
+        yv = torch.empty_like(xv)
+        comm.allreduce_add(xv, None, yv)
+        torch.cuda.synchronize()
+        okv = ck == 0 and comm.check() == 0 and bool(torch.allclose(yv, torch.full_like(yv, world * (world + 1) / 2), rtol=1e-6))
+        flag = torch.tensor([1 if okv else 0])
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+        if not int(flag.item()):
+            comm_invalid = f"collective verification after the timed region failed (rank {rank}: check {ck}, sum ok {okv})"
+            print("bench.py: " + comm_invalid, file=sys.stderr)
+        # what the residual-stream exchange of one decode pass costs: its 2 x n_layers all-reduces back to back
+        n_ar = sum(1 for ops in runner.layers for o in ops if o.spec.shard == "cols")
+        if n_ar:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            buf = torch.zeros(next(o.m for ops in runner.layers for o in ops if o.spec.shard == "cols"), device=dev)
+            barrier()
+            e0.record()
+            for _ in range(n_ar):
+                comm.allreduce_add(buf)
+            e1.record()
+            torch.cuda.synchronize()
+            allreduce_us = round(e0.elapsed_time(e1) * 1e3, 1)
 
     # ---- phase split (informational): prefill pass and decode pass timed apart with events
     def time_region(fn, reps):
@@ -717,6 +766,10 @@ def run():
         },
         "roofline": roofline,
     }
+    if allreduce_us is not None:
+        out["roofline"]["allreduce_us"] = allreduce_us  # the 2 x n_layers residual-stream all-reduces of one decode pass, back to back
+    if comm_invalid:
+        out["invalid"] = comm_invalid
     if roofline_gemm:
         out["roofline_prefill_gemm"] = roofline_gemm
     # ---- BASELINE configs 3 and 4 beside the headline config, so the driver's record carries them (1 GPU, default model)
