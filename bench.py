@@ -52,6 +52,9 @@ def parse():
     p.add_argument("--force-dist", action="store_true",
                    help="rehearsal: initialise the process group and issue the collectives even at world size 1")
     p.add_argument("--model", default="llama3-8b-q4_k_m", choices=["llama3-8b-q4_k_m", "llama3-8b-q8_0", "llama3-70b-q4_k_m"])
+    p.add_argument("--gguf", default=None, metavar="PATH",
+                   help="build the op list from a GGUF model file (tensor types and shapes as stored) and run on ITS weights, "
+                        "uploaded straight from the read-only mapping, instead of --model's synthetic inventory")
     p.add_argument("--no-extra-configs", action="store_true",
                    help="skip the BASELINE config 3 (Llama-3-8B Q8_0) and config 4 (Mixtral-8x7B expert path) legs of the line")
     return p.parse_args()
@@ -64,7 +67,7 @@ class Op:
 class Runner:
     """Holds the sharded weights and pre-allocated buffers; runs one pass of all mat-muls at batch n."""
 
-    def __init__(self, layers, rank, world, batches, dev, collectives=False, comm=None):
+    def __init__(self, layers, rank, world, batches, dev, collectives=False, comm=None, tensors=None):
         self.L = _hip.lib()
         self.rank, self.world, self.dev = rank, world, dev
         self.collectives = collectives
@@ -87,7 +90,13 @@ class Runner:
                         assert spec.k % (world * T.BLCK[spec.type]) == 0, (spec.name, spec.k, world)
                         o.k = spec.k // world
                 seed += 1
-                raw = synth.random_weights_torch(spec.type, o.m, o.k, seed * 131 + rank, dev)
+                if tensors is not None:  # a model file: this rank's shard of the mapped bytes ([rows, row_bytes] uint8)
+                    from llamafile_amd import tp
+                    import numpy as np
+                    shard, _, _ = tp.shard_weight(tensors[spec.name].array(), spec.type, spec.m, spec.k, spec.shard, rank, world)
+                    raw = torch.from_numpy(np.array(shard, copy=True) if world > 1 else np.asarray(shard).copy()).to(dev)
+                else:
+                    raw = synth.random_weights_torch(spec.type, o.m, o.k, seed * 131 + rank, dev)
                 o.W = sgemm.upload_weights(spec.type, raw, o.m, o.k, dev)
                 del raw
                 ops.append(o)
@@ -510,9 +519,16 @@ def run():
         else:
             torch.distributed.init_process_group(backend, rank=rank, world_size=world)
 
-    layers = {"llama3-8b-q4_k_m": LS.llama3_8b_q4_k_m, "llama3-8b-q8_0": LS.llama3_8b_q8_0,
-              "llama3-70b-q4_k_m": LS.llama3_70b_q4_k_m}[a.model]()
-    runner = Runner(layers, rank, world, (a.prefill, 1), dev, collectives=dist_on, comm=comm)
+    gguf_file, gguf_tensors = None, None
+    if a.gguf:
+        from llamafile_amd import gguf as gguf_mod
+        gguf_file = gguf_mod.GGUFFile(a.gguf)
+        layers, gguf_tensors = LS.from_gguf(gguf_file)
+        a.model = "gguf:" + os.path.basename(a.gguf)
+    else:
+        layers = {"llama3-8b-q4_k_m": LS.llama3_8b_q4_k_m, "llama3-8b-q8_0": LS.llama3_8b_q8_0,
+                  "llama3-70b-q4_k_m": LS.llama3_70b_q4_k_m}[a.model]()
+    runner = Runner(layers, rank, world, (a.prefill, 1), dev, collectives=dist_on, comm=comm, tensors=gguf_tensors)
     runner.fuse_ffn = a.ffn_block
 
     def barrier():
@@ -648,6 +664,13 @@ def run():
     # ---- roofline of the dominant kernel: the decode GEMV of the dominant weight type, all its
     # launches of one decode pass, back to back on the stream, timed with HIP events
     dom_type = T.Q8_0 if a.model == "llama3-8b-q8_0" else T.Q4_K
+    if a.gguf:  # the type that holds most of the file's mat-mul bytes among launches of one type
+        by_type = {}
+        for c in (runner.buf[1].get("calls") or (runner.prepare(1), runner.buf[1]["calls"])[1]):
+            ts = {o.spec.type for o in c[1]}
+            if len(ts) == 1:
+                by_type[next(iter(ts))] = by_type.get(next(iter(ts)), 0) + sum(o.W.nbytes for o in c[1])
+        dom_type = max(by_type, key=by_type.get) if by_type else T.Q4_K
     dom_ops = [o for ops in runner.layers for g in runner._groups(ops) if {q.spec.type for q in g} == {dom_type} for o in g]
     launches_per_pass, _ = runner.run_pass(1, only_type=dom_type)
     dom_graph = None
@@ -694,8 +717,14 @@ def run():
                 tj = None
         except (KeyError, ValueError, OSError):
             tj = None
-    kname = ("gemv_kq_kernel<q4k_traits, 1, F32, {16 | 8 waves}, {1,2}>" + (f" + ffn_block_kernel<q4k, q4k> ({n_fused} fused feed-forward launches)" if n_fused else "") +
-             " (all decode launches of a pass whose matrices are all Q4_K)") if dom_type == T.Q4_K else "gemv_q80_kernel<1, F32, mode>"
+    if dom_type == T.Q4_K:
+        kname = ("gemv_kq_kernel<q4k_traits, 1, F32, {16 | 8 waves}, {1,2}>" +
+                 (f" + ffn_block_kernel<q4k, q4k> ({n_fused} fused feed-forward launches)" if n_fused else "") +
+                 " (all decode launches of a pass whose matrices are all Q4_K)")
+    elif dom_type == T.Q8_0:
+        kname = "gemv_q80_kernel<1, F32, mode>"
+    else:
+        kname = f"decode GEMV launches whose matrices are all {T.NAMES[dom_type]}"
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": kname, "launches_per_pass": launches_per_pass, "mat_muls_per_pass": len(dom_ops),
@@ -748,7 +777,7 @@ def run():
         "scaling": "strong",
         "vs_baseline": None,
         "dtype": "int8",
-        "data": "synthetic",
+        "data": "synthetic" if not a.gguf else f"weights of {os.path.basename(a.gguf)} (GGUF v{gguf_file.version}, {len(gguf_tensors)} mat-mul tensors), synthetic activations",
         "config": {
             "workload": f"{a.model} mat-muls ({sum(len(l) for l in layers)} GGML_OP_MUL_MAT per pass, f32 activations in, quantisation fused, sibling ops fused at decode" + (", feed-forward block (gate, up, silu*up, Q8_K, down) one launch at decode" if a.ffn_block else "") + "), "
                         f"{a.prefill}-token prefill + {a.decode} decode, matmul-only",

@@ -77,3 +77,39 @@ def gemv_algorithmic_bytes(op: MatMul, n: int = 1) -> int:
 
 def gemm_flops(op: MatMul, n: int) -> int:
     return 2 * op.m * op.k * n
+
+
+# ---- the same inventory read from a model file (f-4: llama-bench / localscore run from a GGUF, localscore/benchmark.cpp:93-145)
+_GGUF_OPS = (("attn_q", "attn_in", "rows"), ("attn_k", "attn_in", "rows"), ("attn_v", "attn_in", "rows"),
+             ("attn_output", "attn_out_in", "cols"), ("ffn_gate", "ffn_in", "rows"), ("ffn_up", "ffn_in", "rows"),
+             ("ffn_down", "ffn_down_in", "cols"))
+
+
+def from_gguf(g) -> tuple[list[list[MatMul]], dict]:
+    """-> (per-layer op lists + a final [output] list, {op name: GGUFTensor}) from the tensor directory of an open
+    llamafile_amd.gguf.GGUFFile: every blk.N.{attn_q, attn_k, attn_v, attn_output, ffn_gate, ffn_up, ffn_down}.weight it holds
+    (types and shapes as stored) and output.weight (token_embd.weight when the file ties the two).  Tensors whose type has no
+    block format in this module (nbytes == 0) are an error: the bench would silently skip work."""
+    by_name = {t.name: t for t in g.tensors}
+    layers, tensors = [], {}
+    il = 0
+    while any(f"blk.{il}.{op}.weight" in by_name for op, _, _ in _GGUF_OPS):
+        ops = []
+        for op, inp, shard in _GGUF_OPS:
+            t = by_name.get(f"blk.{il}.{op}.weight")
+            if t is None:
+                continue
+            if not t.nbytes:
+                raise ValueError(f"{t.name}: ggml type {t.type} has no block format here")
+            name = f"blk.{il}.{op}"
+            ops.append(MatMul(name, t.type, int(t.ne[1]), int(t.ne[0]), inp, shard))
+            tensors[name] = t
+        layers.append(ops)
+        il += 1
+    out = by_name.get("output.weight") or by_name.get("token_embd.weight")
+    if out is not None and out.nbytes:
+        layers.append([MatMul("output", out.type, int(out.ne[1]), int(out.ne[0]), "out_in", "vocab")])
+        tensors["output"] = out
+    if not layers:
+        raise ValueError("no llama mat-mul tensors (blk.N.attn_q.weight ...) in this file")
+    return layers, tensors

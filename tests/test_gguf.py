@@ -103,3 +103,55 @@ def test_sgemm_straight_from_the_mapped_file(gpu, oracle, tmp_path):
     assert host.llamafile_sgemm_amd_cached_bytes() > before  # the read-only mapping was recognised: packed once, kept
     host.llamafile_sgemm_amd_reset()
     g.close()
+
+
+def _tiny_llama(tmp_path, n_layers=2, n_embd=512, n_ff=1024, n_kv=256, n_vocab=768):
+    ts = []
+    seed = 100
+    for il in range(n_layers):
+        hi = T.Q6_K if il == 0 else T.Q4_K
+        for name, t, m, k in (("attn_q", T.Q4_K, n_embd, n_embd), ("attn_k", T.Q4_K, n_kv, n_embd), ("attn_v", hi, n_kv, n_embd),
+                              ("attn_output", T.Q4_K, n_embd, n_embd), ("ffn_gate", T.Q4_K, n_ff, n_embd),
+                              ("ffn_up", T.Q4_K, n_ff, n_embd), ("ffn_down", hi, n_embd, n_ff)):
+            seed += 1
+            ts.append((f"blk.{il}.{name}.weight", t, (k, m), synth.random_weights(t, m, k, seed)))
+        ts.append((f"blk.{il}.attn_norm.weight", T.F32, (n_embd,), synth.random_weights(T.F32, 1, n_embd, seed + 50)))
+    ts.append(("output.weight", T.Q6_K, (n_embd, n_vocab), synth.random_weights(T.Q6_K, n_vocab, n_embd, 999)))
+    p = tmp_path / "tiny.gguf"
+    gguf.write_gguf(p, {"general.architecture": "llama", "llama.block_count": n_layers}, ts)
+    return p, ts
+
+
+def test_op_list_from_a_model_file(tmp_path):
+    """bench.py --gguf: the mat-mul inventory comes from the file's tensor directory (llama-bench / localscore run from a
+    model file, localscore/benchmark.cpp:93-145) — names, stored types and shapes, grouping inputs, shard modes."""
+    from llamafile_amd import llama_shapes as LS
+    p, ts = _tiny_llama(tmp_path)
+    g = gguf.GGUFFile(p)
+    layers, tensors = LS.from_gguf(g)
+    assert len(layers) == 3 and [len(l) for l in layers] == [7, 7, 1]
+    assert layers[0][2] == LS.MatMul("blk.0.attn_v", T.Q6_K, 256, 512, "attn_in", "rows")
+    assert layers[1][6] == LS.MatMul("blk.1.ffn_down", T.Q4_K, 512, 1024, "ffn_down_in", "cols")
+    assert layers[2][0] == LS.MatMul("output", T.Q6_K, 768, 512, "out_in", "vocab")
+    for ops in layers:
+        for o in ops:
+            raw = next(r for n, _, _, r in ts if n == o.name + ".weight")
+            assert np.array_equal(tensors[o.name].array().reshape(-1), np.ascontiguousarray(raw).view(np.uint8).reshape(-1))
+    g.close()
+
+
+@pytest.mark.gpu
+def test_bench_runs_from_a_model_file(gpu, tmp_path):
+    """The whole harness on a file: `bench.py --gguf tiny.gguf` prints the contract's JSON line with the file named in it."""
+    import json
+    import os
+    import subprocess
+    import sys
+    p, _ = _tiny_llama(tmp_path)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gguf", str(p), "--steps", "1", "--warmup", "1", "--prefill", "128",
+                        "--decode", "4", "--no-cpu-baseline", "--no-extra-configs"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["value"] > 0 and d["config"]["model"] == "gguf:tiny.gguf" and "tiny.gguf" in d["data"]
+    assert d["roofline"]["frac"] > 0 and d["config"]["decode_launches_per_pass"] == 2 * 4 + 1

@@ -173,3 +173,63 @@ def test_qkv_two_types_one_gemm_launch(gpu, ta):
             assert float((f - sep).abs().max()) / float(sep.abs().max()) <= 4e-6, (T.NAMES[W.type], W.rows)
         else:
             assert torch.equal(_bits(f), _bits(sep)), (T.NAMES[W.type], W.rows)
+
+
+@pytest.mark.parametrize("case", [("gate", T.Q4_K, 14336, 4096), ("down", T.Q6_K, 4096, 14336)], ids=lambda c: c[0])
+def test_mul_mat_id_full_size_mixtral(gpu, oracle, case):
+    """BASELINE config 4 at its real sizes: GGML_OP_MUL_MAT_ID with 8 experts of 14336 x 4096 (Q4_K, ffn_gate_exps) and of
+    4096 x 14336 (Q6_K, ffn_down_exps in a Q4_K_M file), 2 experts per token (shapes: tinyblas_cpu_mixmul.inc:65-72; call
+    site ggml.c.patch:2004-2018).
+      * decode (1 token): both chosen experts against the oracle;
+      * 512 tokens: 24 sampled (token, thinker) rows against the oracle, and EVERY row against the decode GEMV of its expert on
+        its activation row (the column-equals-GEMV property: the batch only regroups rows by expert);
+      * an out-of-range expert id leaves its row untouched."""
+    from llamafile_amd import synth, _hip
+    _, t, rows, cols = case
+    experts, thinkers, tasks, tokens = 8, 2, 1, PREFILL
+    raws = [synth.random_weights_torch(t, rows, cols, 7000 + e) for e in range(experts)]
+    Ws = [gpu.upload_weights(t, r, rows, cols) for r in raws]
+    packed = torch.cat([W.data for W in Ws])
+    x = synth.random_activations(tokens * tasks, cols, 71)
+    xq = synth.quantize_activations(T.Q8_K, x)
+    xd = torch.from_numpy(x).cuda()
+    thought = xd.view(torch.uint8).view(tokens * tasks, cols * 4)
+    rng = np.random.default_rng(72)
+    plan = np.stack([rng.permutation(experts)[:thinkers] for _ in range(tokens)]).astype(np.int32)  # two DIFFERENT experts per token
+    plan[17, 1] = experts + 1  # invalid id
+    pd = torch.from_numpy(plan).cuda()
+
+    def oracle_row(ex, tok):
+        ok, G = oracle.sgemm(t, raws[ex].cpu().numpy(), T.Q8_K, xq[tok:tok + 1], rows, 1, cols, nth=8)
+        assert ok == 1
+        return G[0]
+
+    # ---- decode: token 0 alone
+    res1 = gpu.mul_mat_id(packed, t, rows, cols, experts, thought[:1].contiguous(), T.F32, tasks, 1, pd[:1].contiguous(), thinkers, prefill=-7.0)
+    torch.cuda.synchronize()
+    r1 = res1.cpu().numpy()
+    for th in range(thinkers):
+        assert rel_err(r1[0, th], oracle_row(int(plan[0, th]), 0)) <= 2e-6, th
+
+    # ---- the 512-token batch (scaled operands: the default of every K-quant batch)
+    res = gpu.mul_mat_id(packed, t, rows, cols, experts, thought, T.F32, tasks, tokens, pd, thinkers, prefill=-7.0)
+    torch.cuda.synchronize()
+    assert (res[17, 1] == -7.0).all()
+    rn = res.cpu().numpy()
+    scale = float(np.abs(rn[rn != -7.0]).max())
+    picks = [(int(a), int(b)) for a, b in zip(rng.integers(0, tokens, 24), rng.integers(0, thinkers, 24)) if not (a == 17 and b == 1)]
+    for tok, th in picks:
+        g = oracle_row(int(plan[tok, th]), tok)
+        assert float(np.abs(rn[tok, th] - g).max()) / scale <= 1e-3, (tok, th)
+        assert rel_err(rn[tok, th], g) <= 1e-3, (tok, th)
+    # every row == the decode GEMV of its expert on its activation row (exact integer dots), to the MFMA operand rounding
+    worst = 0.0
+    for ex in range(experts):
+        sel = [(tok, th) for tok in range(tokens) for th in range(thinkers) if plan[tok, th] == ex]
+        toks = torch.tensor([tok for tok, _ in sel], device="cuda")
+        got = torch.stack([res[tok, th] for tok, th in sel])
+        for c0 in range(0, len(sel), 8):  # the GEMV takes up to 8 columns per call
+            idx = toks[c0:c0 + 8]
+            g = gpu.mul_mat(Ws[ex], thought[idx].contiguous(), T.F32, n=len(idx))
+            worst = max(worst, float((got[c0:c0 + 8] - g).abs().max()) / scale)
+    assert worst <= 1e-3, worst
