@@ -14,6 +14,7 @@
 #include "../../include/lfamd_hip.h"
 
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -137,6 +138,8 @@ GGML_CALL void buf_clear(ggml_backend_buffer_t buffer, uint8_t value) {
     buffer_ctx *c = (buffer_ctx *)buffer->context;
     (void)hipMemset(c->base, value, c->size);
     (void)hipDeviceSynchronize();
+    std::lock_guard<std::mutex> lk(g_mu); // every packed copy made from this buffer's bytes is stale now
+    drop_range((const uint8_t *)c->base, (const uint8_t *)c->base + c->size);
 }
 const ggml_backend_buffer_i k_buffer_iface = {buf_get_name, buf_free, buf_get_base, buf_init_tensor, buf_set_tensor,
                                               buf_get_tensor, buf_cpy_tensor, buf_clear, nullptr};
@@ -441,7 +444,16 @@ GGML_CALL int ggml_backend_cuda_get_device_count(void) {
 }
 
 GGML_CALL ggml_backend_buffer_type_t ggml_backend_cuda_buffer_type(int device) {
-    return device == 0 && g_linked ? &g_buft : nullptr;
+    if (device != 0 || !g_linked)
+        return nullptr;
+    // LFAMD_BACKEND_MATRICES_ONLY=1: the per-layer ("offload") buffer type is host memory, so that norm weights, the KV cache
+    // and compute buffers stay with the CPU backend; matrices reach the device through the split buffer type below
+    // (llama.cpp --split-mode row: buft_matrix).  INTEGRATION.md section 2.
+    static const bool matrices_only = [] {
+        const char *e = getenv("LFAMD_BACKEND_MATRICES_ONLY");
+        return e && *e && *e != '0';
+    }();
+    return matrices_only ? g_api->ggml_backend_cpu_buffer_type() : &g_buft;
 }
 
 GGML_CALL ggml_backend_buffer_type_t ggml_backend_cuda_host_buffer_type(void) {

@@ -42,7 +42,8 @@ static GGML_CALL ggml_backend_buffer_t h_buffer_init(ggml_backend_buffer_type_t 
     return b;
 }
 static GGML_CALL ggml_backend_buffer_t h_cpu_from_ptr(void *p, size_t n) { (void)p, (void)n; return NULL; }
-static GGML_CALL ggml_backend_buffer_type_t h_cpu_buft(void) { return NULL; }
+static struct ggml_backend_buffer_type cpu_buft_obj;
+static GGML_CALL ggml_backend_buffer_type_t h_cpu_buft(void) { return &cpu_buft_obj; }
 static GGML_CALL size_t h_nbytes(const struct ggml_tensor *t) {
     size_t blck = lfamd_blck_size(t->type);
     size_t n = t->ne[0] * t->nb[0] / blck;
@@ -156,6 +157,12 @@ int main(int argc, char **argv) {
         printf("%s count=%d\n", linked ? "linked" : "nolink", get_count());
         return 0;
     }
+    if (!strcmp(argv[2], "bufts")) { /* which buffer type a layer's small tensors / its matrices get (llama.cpp buft vs buft_matrix) */
+        ggml_backend_buffer_type_t GGML_CALL (*split_type)(const float *) = sym[4];
+        if (!linked) return 5;
+        printf("layer=%s matrix=%s\n", buffer_type(0) == h_cpu_buft() ? "host" : "device", split_type(NULL) == h_cpu_buft() ? "host" : "device");
+        return 0;
+    }
     if (!linked) { fprintf(stderr, "link failed\n"); return 5; }
     if (reg_devices() != 1 || registered != 1) { fprintf(stderr, "reg_devices\n"); return 6; }
     struct ggml_cuda_device_properties pr;
@@ -218,6 +225,17 @@ int main(int argc, char **argv) {
     be->iface.synchronize(be);
     size_t no = h_nbytes(&OUT);
     void *ho = malloc(no);
+    /* clear() rewrites the weights behind the kept packed copy: zero bytes are zero weights in every block format, so the
+       product must come out as exact zeros; set_tensor() afterwards must bring the real product back */
+    wbuf->iface.clear(wbuf, 0);
+    if (be->iface.graph_compute(be, &g) != GGML_STATUS_SUCCESS) return 12;
+    be->iface.synchronize(be);
+    cbuf->iface.get_tensor(cbuf, &OUT, ho, 0, no);
+    for (size_t i = 0; i < no / 4; i++)
+        if (((const uint32_t *)ho)[i] & 0x7fffffffu) { fprintf(stderr, "stale packed weights after clear()\n"); return 13; }
+    wbuf->iface.set_tensor(wbuf, &W, hw, 0, nw);
+    if (be->iface.graph_compute(be, &g) != GGML_STATUS_SUCCESS) return 12;
+    be->iface.synchronize(be);
     cbuf->iface.get_tensor(cbuf, &OUT, ho, 0, no);
     FILE *f = fopen(outpath, "wb");
     fwrite(ho, 1, no, f);

@@ -30,6 +30,15 @@ def test_module_exports_the_twelve_symbols_and_links_or_declines(host_exe):
 
 
 @pytest.mark.gpu
+def test_matrices_only_switch_keeps_layer_buffers_on_the_host(gpu, host_exe):
+    """with LFAMD_BACKEND_MATRICES_ONLY=1 only the split (matrix) buffer type is device memory, so norm
+    weights, the KV cache and compute buffers stay with ggml's CPU backend."""
+    for env, want in (({}, "layer=device matrix=device"), ({"LFAMD_BACKEND_MATRICES_ONLY": "1"}, "layer=host matrix=device")):
+        r = subprocess.run([host_exe, _hip.HIP_SO, "bufts"], capture_output=True, text=True, timeout=120, env={**os.environ, **env})
+        assert r.returncode == 0 and r.stdout.strip() == want, (r.stdout, r.stderr)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("t,m,k,n,nb2", [(T.Q4_K, 96, 1024, 1, 1), (T.Q4_K, 160, 768, 40, 1), (T.Q6_K, 64, 512, 3, 2), (T.Q8_0, 72, 256, 1, 1),
                                          (T.F16, 48, 256, 5, 3), (T.Q5_K, 32, 512, 12, 1), (T.Q4_0, 64, 256, 2, 1)],
                          ids=lambda v: str(v))
