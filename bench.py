@@ -660,6 +660,16 @@ def run():
     dc_us, _ = time_region(lambda: one_pass(1), 20)
     pf_us /= 3
     dc_us /= 20
+    # the same prefill pass with LFAMD_FLAG_PRECISE: the exact integer-code MFMA bodies for Q4_K / Q5_K / Q6_K batches (2e-6 of
+    # the oracle) instead of the scaled-operand ones (<= 1e-3) — what a bit-faithful prefill costs (eager launches, not in `value`)
+    saved_flags = runner.flags
+    runner.flags |= _hip.FLAG_PRECISE
+    try:
+        runner.run_pass(a.prefill)
+        pfx_us, _ = time_region(lambda: runner.run_pass(a.prefill), 2)
+        pfx_us /= 2
+    finally:
+        runner.flags = saved_flags
 
     # ---- roofline of the dominant kernel: the decode GEMV of the dominant weight type, all its
     # launches of one decode pass, back to back on the stream, timed with HIP events
@@ -790,6 +800,8 @@ def run():
             "prefill_tokens_per_s": round(a.prefill / (pf_us * 1e-6), 1),
             "decode_tokens_per_s": round(1.0 / (dc_us * 1e-6), 1),
             "prefill_pass_ms": round(pf_us / 1e3, 3), "decode_pass_ms": round(dc_us / 1e3, 4),
+            "prefill_exact": {"flags": "LFAMD_FLAG_PRECISE", "pass_ms": round(pfx_us / 1e3, 3),
+                              "tokens_per_s": round(a.prefill / (pfx_us * 1e-6), 1), "numerics": "2e-6 of the oracle"},
             "decode_launches_per_pass": sum(1 for _ in runner.buf[1]["calls"]),
             "decode_GBps_whole_pass": round(runner.weight_bytes() / (dc_us * 1e-6) / 1e9, 1),
         },

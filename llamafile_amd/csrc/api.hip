@@ -169,6 +169,11 @@ static bool type_known(int t) {
     }
 }
 
+// Q8_0: bytes of the P80 image (256-aligned: the PC8 image starts behind it)
+static size_t q80_p80_bytes(long rows, long cols) {
+    return align_up((size_t)((rows + 7) / 8) * (size_t)((cols / 32 + 3) / 4) * P80_TILE, 256);
+}
+
 size_t lfamd_packed_size(int type, long rows, long cols) {
     if (!type_known(type) || rows < 0 || cols < 0 || cols % lfamd_blck_size(type))
         return 0;
@@ -183,8 +188,9 @@ size_t lfamd_packed_size(int type, long rows, long cols) {
         return (size_t)((rows + 31) / 32) * (size_t)(cols / 256) * P5K_TILE;
     case LFAMD_TYPE_Q6_K:
         return (size_t)((rows + 31) / 32) * (size_t)(cols / 256) * P6K_TILE;
-    case LFAMD_TYPE_Q8_0:
-        return (size_t)((rows + 7) / 8) * (size_t)((cols / 32 + 3) / 4) * P80_TILE;
+    case LFAMD_TYPE_Q8_0: // P80 (the bit-exact vecdot / exact batch kernels), then — rows of whole 256-weight groups — the PC8-form
+                          // byte image the MFMA batch body reads (2.1 bytes per weight resident instead of a rebuild per call)
+        return q80_p80_bytes(rows, cols) + (cols % 256 == 0 ? lfamd_wprep8_bytes(rows, cols) : 0);
     case LFAMD_TYPE_Q2_K:
     case LFAMD_TYPE_Q3_K: // PCK: the image the MFMA GEMM and the decode GEMV both read
         return lfamd_wprep16_bytes(rows, cols);
@@ -230,6 +236,8 @@ int lfamd_pack_weights(int type, long rows, long cols, const void *d_raw, size_t
         break;
     case LFAMD_TYPE_Q8_0:
         HIPCHK(lfamd_launch_pack_q80(d_raw, raw_row_bytes, rows, cols, d_packed, s), "pack_q80");
+        if (cols % 256 == 0)
+            HIPCHK(lfamd_launch_wprep8(type, d_packed, 0, rows, cols, (uint8_t *)d_packed + q80_p80_bytes(rows, cols), s), "pack_pc8 (Q8_0)");
         break;
     case LFAMD_TYPE_Q2_K:
     case LFAMD_TYPE_Q3_K:
@@ -335,9 +343,10 @@ static bool use_gemm_q80_mfma(int Atype, long n, unsigned flags, long k) {
 static bool use_gemm_q80(int Atype, long n, unsigned flags, long k) {
     return !(flags & LFAMD_FLAG_FORCE_GENERIC) && n > 8 && Atype == LFAMD_TYPE_Q8_0 && !use_gemm_q80_mfma(Atype, n, flags, k);
 }
-static size_t gemm_q80_mfma_ws(long m, long k, long n) { // Xh, d8T [nb*8][n_pad], image
+static size_t gemm_q80_mfma_ws(long m, long k, long n) { // Xh, d8T [nb*8][n_pad]  (the weight image is resident: lfamd_packed_size)
+    (void)m;
     size_t n_pad = align_up((size_t)n, 128), nb = (size_t)(k / 256);
-    return align_up(n_pad * (size_t)k * 2, 256) + align_up(nb * 8 * n_pad * 4, 256) + align_up(lfamd_wprep8_bytes(m, k), 256);
+    return align_up(n_pad * (size_t)k * 2, 256) + align_up(nb * 8 * n_pad * 4, 256);
 }
 
 static bool use_gemv(int Atype, long n, unsigned flags, long k) {
@@ -494,12 +503,11 @@ int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const v
     if (use_gemm_q80_mfma(Atype, n, flags, k)) {
         if (ws_bytes < gemm_q80_mfma_ws(m, k, n) || !d_ws)
             return fail(LFAMD_ERR_WORKSPACE, "mul_mat: workspace too small%s", "");
-        size_t n_pad = align_up((size_t)n, 128), nb = (size_t)(k / 256);
+        size_t n_pad = align_up((size_t)n, 128);
         uint8_t *ws = (uint8_t *)d_ws;
         void *Xh = ws;
         void *d8T = ws + align_up(n_pad * (size_t)k * 2, 256);
-        void *img = (uint8_t *)d8T + align_up(nb * 8 * n_pad * 4, 256);
-        HIPCHK(lfamd_launch_wprep8(Atype, d_A, 0, m, k, img, s), "wprep8 (Q8_0)");
+        const void *img = (const uint8_t *)d_A + q80_p80_bytes(m, k); // built once by lfamd_pack_weights
         HIPCHK(lfamd_launch_prep80(Btype, d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, nullptr, s), "prep80");
         HIPCHK(lfamd_launch_gemm_wide(Atype, img, m, k, Xh, d8T, nullptr, n, (long)n_pad, d_C, ldc, plain, nullptr, 0, s), "gemm_wide (Q8_0)");
         return LFAMD_OK;

@@ -62,6 +62,12 @@ class PackedWeights:
 
     @property
     def nbytes(self) -> int:
+        """ALGORITHMIC bytes: the tensor's size in the GGUF file (what one pass over the weights has to read at least).  The
+        resident image may be larger (Q8_0 keeps a second, MFMA-ordered byte image for batches): `resident_bytes`."""
+        return self.rows * T.row_size(self.type, self.cols)
+
+    @property
+    def resident_bytes(self) -> int:
         return self.data.numel()
 
 
