@@ -75,8 +75,10 @@ int lfamd_stream_sync(void *stream);
  * them with coalesced 16-byte-per-lane loads (DESIGN.md "Data layout in HBM").  `raw` is the
  * tensor exactly as GGUF/ggml stores it: `rows` rows, `raw_row_bytes` apart, each a sequence of
  * blocks (include/lfamd_blocks.h).  Packing is a device kernel: raw and packed are device
- * pointers.  lfamd_packed_size is the ONLY source of the packed byte count: Q4_K / Q5_K / Q6_K / Q8_0 / Q4_0 images are
- * the GGUF size (+ tile round-up); Q2_K / Q3_K / IQ4_XS / Q4_1 / Q5_0 / Q5_1 are kept as the canonical image their MFMA
+ * pointers.  lfamd_packed_size is the ONLY source of the packed byte count: Q4_K / Q5_K / Q6_K / Q4_0 images are
+ * the GGUF size (+ tile round-up); Q8_0 keeps TWO images — the GGUF-sized one the bit-exact vecdot and exact batch kernels
+ * read, and (rows of whole 256-weight groups) the MFMA batch body's byte image behind it, 2.1 bytes per weight resident in
+ * all, so that a batch never rebuilds it; Q2_K / Q3_K / IQ4_XS / Q4_1 / Q5_0 / Q5_1 are kept as the canonical image their MFMA
  * and decode kernels read (164 / 164 / 272 / 192 / 192 / 192 bytes per 256 weights: up to 2x the file size, DESIGN.md
  * section 3); legacy 32-block rows that are not whole 256-weight groups and float tensors stay as GGUF rows. */
 size_t lfamd_packed_size(int type, long rows, long cols);

@@ -83,17 +83,66 @@ _Z4demov: ; @demo
 
 GEMV_TUS = ["gemv_q4k.hip", "gemv_q5k.hip", "gemv_q6k.hip", "gemv_q40.hip", "gemv_q41.hip", "gemv_q50.hip", "gemv_q51.hip", "gemv_q2k.hip", "gemv_q3k.hip", "gemv_iq4xs.hip",
             "gemv_dual.hip"]
+# (the inline-asm VALU sites — the `v_permlane*_swap` pair — live in gemv_impl.h, shared by every gemv_*.hip)
+VALU_TUS = GEMV_TUS + ["gemv_q80.hip", "gemm_q80.hip", "moe.hip", "ffn_block.hip", "norm_quant.hip", "quantize.hip"]
+SHIPPED_FLAGS = ("-mllvm", "-amdgpu-kernarg-preload-count=13")  # csrc/Makefile
+
+
+@pytest.fixture(scope="module")
+def shipped_asm():
+    """Assembly of the shipped build of every unit the two tests below look at, compiled once (8 at a time)."""
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        texts = list(ex.map(lambda f: isa_hazards.shipped_asm(os.path.join(ROOT, "llamafile_amd", "csrc", f), SHIPPED_FLAGS), VALU_TUS))
+    return dict(zip(VALU_TUS, texts))
 
 
 @pytest.mark.skipif(not os.path.exists(isa_hazards.HIPCC), reason="needs hipcc")
-def test_decode_kernels_have_no_flat_access_and_no_stack():
+def test_decode_kernels_have_no_flat_access_and_no_stack(shipped_asm):
     """hipcc counts vmcnt exactly only without FLAT instructions and without a stack frame in the kernel; either one turned
     every counted wait of the decode GEMV into vmcnt(0) (no weight prefetch) while all parity tests stayed green."""
-    flags = ("-mllvm", "-amdgpu-kernarg-preload-count=9")
-    with ThreadPoolExecutor(max_workers=3) as ex:
-        results = list(ex.map(lambda f: isa_hazards.check_decode_hygiene(os.path.join(ROOT, "llamafile_amd", "csrc", f), flags), GEMV_TUS))
-    for f, res in zip(GEMV_TUS, results):
+    for f in GEMV_TUS:
+        res = isa_hazards.decode_hygiene(shipped_asm[f])
         decode = {k: v for k, v in res.items() if "gemv_kq" in k and ("Li1ELi" in k or "dual" in k)}  # NC = 1 bodies
         assert decode, f
         for kernel, probs in decode.items():
             assert not probs, (f, kernel[:80], probs)
+
+
+@pytest.mark.skipif(not os.path.exists(isa_hazards.HIPCC), reason="needs hipcc")
+def test_valu_wait_states_in_the_decode_and_exact_units(shipped_asm):
+    """Every software-wait-state rule of tools/isa_hazards.py: check_valu_hazards over the shipped build of the decode GEMVs (the
+    `v_permlane*_swap` pair of gemv_impl.h is inline asm), the exact Q8_0 batch kernel, the expert path, the quantisers."""
+    for f in VALU_TUS:
+        res = isa_hazards.check_valu_hazards(shipped_asm[f])
+        assert res, f
+        for kernel, bad in res.items():
+            assert not bad, (f, kernel, bad[:3])
+
+
+def test_checker_flags_valu_wait_state_violations():
+    def run(body):
+        return isa_hazards.check_valu_hazards("_Z4demov: ; @demo\n" + body + ".Lfunc_end0:\n")["_Z4demov"]
+    # the permlane swap pair of gemv_impl.h without / with its s_nop 1
+    assert len(run("\tv_add_f32_e32 v3, v1, v2\n\tv_permlane16_swap_b32_e32 v3, v4\n")) == 1
+    assert len(run("\tv_add_f32_e32 v3, v1, v2\n\ts_nop 0\n\tv_permlane16_swap_b32_e32 v3, v4\n")) == 1
+    assert run("\tv_add_f32_e32 v3, v1, v2\n\ts_nop 1\n\tv_permlane16_swap_b32_e32 v3, v4\n") == []
+    assert run("\tv_add_f32_e32 v3, v1, v2\n\tv_mov_b32_e32 v9, v8\n\tv_mov_b32_e32 v10, v8\n\tv_permlane32_swap_b32_e32 v4, v3\n") == []
+    assert run("\tv_add_f32_e32 v5, v1, v2\n\tv_permlane16_swap_b32_e32 v3, v4\n") == []  # another register
+    # DPP source written by the previous VALU instruction; EXEC written in front of a DPP instruction
+    assert len(run("\tv_max_f32_e32 v1, v1, v2\n\tv_mov_b32_dpp v3, v1 row_shr:1 row_mask:0xf bank_mask:0xf\n")) == 1
+    assert run("\tv_max_f32_e32 v1, v1, v2\n\ts_nop 1\n\tv_mov_b32_dpp v3, v1 row_shr:1 row_mask:0xf bank_mask:0xf\n") == []
+    assert len(run("\tv_cmpx_lt_f32_e32 v1, v2\n\ts_nop 3\n\tv_mov_b32_dpp v3, v7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n")) == 1
+    # readlane: source written by the previous VALU (1), lane select written by a VALU (4), SGPR result used as a VALU constant (2)
+    assert len(run("\tv_add_u32_e32 v1, v1, v2\n\tv_readfirstlane_b32 s4, v1\n")) == 1
+    assert run("\tv_add_u32_e32 v1, v1, v2\n\ts_nop 0\n\tv_readfirstlane_b32 s4, v1\n") == []
+    assert len(run("\tv_readfirstlane_b32 s4, v1\n\ts_nop 2\n\tv_readlane_b32 s5, v2, s4\n")) == 1
+    assert run("\tv_readfirstlane_b32 s4, v1\n\ts_nop 3\n\tv_readlane_b32 s5, v2, s4\n") == []
+    assert len(run("\tv_readfirstlane_b32 s4, v1\n\tv_add_u32_e32 v2, s4, v3\n")) == 1
+    assert run("\tv_readfirstlane_b32 s4, v1\n\ts_nop 1\n\tv_add_u32_e32 v2, s4, v3\n") == []
+    assert run("\tv_mad_u64_u32 v[16:17], s[42:43], v17, v26, v[16:17]\n\tv_mad_u64_u32 v[18:19], s[42:43], v1, v2, v[16:17]\n") == []  # carry-out is a destination
+    # transcendental result consumed by the next VALU; VCC in front of v_div_fmas; M0 in front of an LDS-DMA load
+    assert len(run("\tv_rcp_f32_e32 v1, v2\n\tv_mul_f32_e32 v3, v1, v4\n")) == 1
+    assert run("\tv_rcp_f32_e32 v1, v2\n\tv_mov_b32_e32 v9, v8\n\tv_mul_f32_e32 v3, v1, v4\n") == []
+    assert len(run("\tv_cmp_lt_f32_e32 vcc, v1, v2\n\ts_nop 2\n\tv_div_fmas_f32 v3, v4, v5, v6\n")) == 1
+    assert len(run("\ts_add_u32 m0, s3, 0x100\n\tglobal_load_lds_dwordx4 v1, s[4:5]\n")) == 1
+    assert run("\ts_add_u32 m0, s3, 0x100\n\ts_nop 0\n\tglobal_load_lds_dwordx4 v1, s[4:5]\n") == []
