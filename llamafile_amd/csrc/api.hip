@@ -24,6 +24,10 @@ hipError_t lfamd_launch_pack_q80(const void *, size_t, long, long, void *, hipSt
 hipError_t lfamd_launch_pack_raw(const void *, size_t, long, size_t, void *, hipStream_t);
 hipError_t lfamd_launch_prep_q8k(const void *, size_t, long, long, long, void *, void *, void *, int, const int32_t *, hipStream_t);
 hipError_t lfamd_launch_prep_f32(const void *, size_t, long, long, long, void *, void *, void *, int, const int32_t *, hipStream_t);
+size_t lfamd_gemm_sb_workspace(long k);
+bool lfamd_gemm_sb_ok(int Atype, long k, long n);
+hipError_t lfamd_launch_gemm_sb(int Atype, const void *A, long m, long k, int Btype, const void *B, size_t b_row_bytes, long n, float *C,
+                                long ldc, void *ws, hipStream_t s);
 hipError_t lfamd_launch_wprep16(int, const void *, size_t, long, long, void *, hipStream_t);
 size_t lfamd_wprep16_bytes(long, long);
 hipError_t lfamd_launch_generic(int, const void *, long, long, int, const void *, size_t, long, float *, long, hipStream_t);
@@ -349,6 +353,26 @@ static size_t gemm_q80_mfma_ws(long m, long k, long n) { // Xh, d8T [nb*8][n_pad
     return align_up(n_pad * (size_t)k * 2, 256) + align_up(nb * 8 * n_pad * 4, 256);
 }
 
+// Small batches of Q4_K / Q5_K / Q6_K (up to 32 tokens) on gemm_sb.hip, where it is the fastest route (MI355X, profiles/
+// r03_small_batch.txt; times in us for old -> new):
+//   deep rows (k > 8192, ffn_down)          : n >= 3   (n = 8: 45 -> 16.6 Q4_K, 66 -> 20.3 Q6_K; n = 32: 28 -> 25.8)
+//   at most one row tile per CU (m <= 8192) : n >= 5   (4096 x 4096: n = 8 14.4 -> 9.4, n = 32 16.9 -> 12.2)
+//   up to four row tiles per CU             : 8 <= n <= 24, not Q6_K   (14336 x 4096: n = 8 24.3 -> 20.7)
+// Below that the multi-column GEMV is faster (one launch, no staging pass); taller matrices (output.weight) keep the GEMV /
+// the 128-token GEMM tiles.  The testing flags that force a GEMM body or the generic kernels keep their meaning.
+static bool use_gemm_sb(int Atype, long n, unsigned flags, long k, long m) {
+    if (flags & (LFAMD_FLAG_FORCE_GENERIC | LFAMD_FLAG_GEMM_NARROW | LFAMD_FLAG_GEMM_WIDE | LFAMD_FLAG_GEMM_PLAIN))
+        return false;
+    if (!lfamd_gemm_sb_ok(Atype, k, n))
+        return false;
+    if (k > 8192)
+        return n >= 3;
+    const long tiles_per_cu = ((m + 31) / 32 + 255) / 256;
+    if (tiles_per_cu <= 1)
+        return n >= 5;
+    return tiles_per_cu <= 4 && Atype != LFAMD_TYPE_Q6_K && n >= 8 && n <= 24;
+}
+
 static bool use_gemv(int Atype, long n, unsigned flags, long k) {
     if (flags & LFAMD_FLAG_FORCE_GENERIC)
         return false;
@@ -363,7 +387,7 @@ static bool gemv_quantise_separately(int Atype, long m) {
     return false; // persistent GEMV work-groups stage the activations once each: fused is always cheaper
 }
 
-size_t lfamd_mul_mat_workspace(int Atype, long m, long k, long n) {
+static size_t mul_mat_workspace_base(int Atype, long m, long k, long n) {
     if (use_gemv(Atype, n, 0, k) && gemv_quantise_separately(Atype, m))
         return align_up((size_t)n * lfamd_row_size(lfamd_vec_dot_type(Atype), k), 256);
     if (use_gemm(Atype, n, 0, k)) {
@@ -390,6 +414,12 @@ size_t lfamd_mul_mat_workspace(int Atype, long m, long k, long n) {
     return align_up((size_t)n * lfamd_row_size(lfamd_vec_dot_type(Atype), k), 256);
 }
 
+size_t lfamd_mul_mat_workspace(int Atype, long m, long k, long n) {
+    const size_t base = mul_mat_workspace_base(Atype, m, k, n); // (the body a testing flag may force)
+    const size_t sb = use_gemm_sb(Atype, n, 0, k, m) ? align_up(lfamd_gemm_sb_workspace(k), 256) : 0;
+    return base > sb ? base : sb;
+}
+
 int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const void *d_B, size_t b_row_bytes, long n,
                   float *d_C, long ldc, void *d_ws, size_t ws_bytes, unsigned flags, void *stream) {
     (void)hipGetLastError(); // a stale error of an earlier call (e.g. an invalidated stream capture) must not fail this one
@@ -414,6 +444,12 @@ int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const v
     hipStream_t s = (hipStream_t)stream;
     const int vregs32 = (flags & LFAMD_FLAG_Q0_VREGS32) ? 1 : 0, precise = (flags & LFAMD_FLAG_PRECISE) ? 1 : 0;
 
+    if (use_gemm_sb(Atype, n, flags, k, m)) { // a handful of tokens: weights streamed once, MFMA tile of 32 token slots (gemm_sb.hip)
+        if (ws_bytes < align_up(lfamd_gemm_sb_workspace(k), 256) || !d_ws)
+            return fail(LFAMD_ERR_WORKSPACE, "mul_mat: workspace too small%s", "");
+        HIPCHK(lfamd_launch_gemm_sb(Atype, d_A, m, k, Btype, d_B, b_row_bytes, n, d_C, ldc, d_ws, s), "gemm_sb");
+        return LFAMD_OK;
+    }
     if (use_gemm(Atype, n, flags, k)) {
         size_t need = lfamd_mul_mat_workspace(Atype, m, k, n);
         if (ws_bytes < need || !d_ws)
@@ -677,6 +713,8 @@ int lfamd_mul_mat_multi(int Atype, int count, const void *const *d_A, const long
     const int plain = (flags & LFAMD_FLAG_GEMM_PLAIN) ? 1 : 0;
     if (count <= 0)
         return LFAMD_OK;
+    if (count == 1 && use_gemm_sb(Atype, n, flags, k, m[0])) // a handful of tokens on one matrix (attn_output, ffn_down): gemm_sb.hip
+        return lfamd_mul_mat(Atype, d_A[0], m[0], k, Btype, d_B, b_row_bytes, n, d_C[0], ldc[0], d_ws, ws_bytes, flags, stream);
     // one fused launch when the GEMV path applies to every matrix; otherwise one mul_mat per matrix
     bool fuse = count <= 4 && use_gemv(Atype, n, flags, k) && (Btype == LFAMD_TYPE_F32 || Btype == lfamd_vec_dot_type(Atype)) &&
                 k > 0 && k % lfamd_blck_size(Atype) == 0 && (Atype == LFAMD_TYPE_Q8_0 || k % 256 == 0) &&

@@ -34,3 +34,62 @@ def test_decode_variant_vs_oracle(gpu, oracle, t, m, k, n):
     ok, G = oracle.sgemm(t, np.ascontiguousarray(raw[rows]), bt, Bq, len(rows), n, k, nth=4)
     assert ok == 1
     assert rel_err(c_q[:, rows], G) <= 1e-5, (T.NAMES[t], m, k, n, rel_err(c_q[:, rows], G))
+
+
+# ---- small batches on the matrix cores (csrc/gemm_sb.hip): SB_MIN .. 32 tokens of Q4_K / Q5_K / Q6_K
+# (which body runs: api.hip use_gemm_sb — deep rows from 3 tokens; one row tile per CU from 5; up to four tiles per CU 8..24 tokens,
+#  where a work-group walks several tiles on two alternating weight register sets: m = 9000 -> 2 tiles, m = 20000 -> 3)
+SB_SHAPES = [(48, 768), (33, 256), (100, 4352), (4096, 4096), (24, 14336), (1000, 2048), (9000, 512), (20000, 256)]
+
+
+@pytest.mark.parametrize("n", [3, 5, 8, 17, 32])
+@pytest.mark.parametrize("m,k", SB_SHAPES, ids=lambda v: str(v))
+@pytest.mark.parametrize("t", [T.Q4_K, T.Q5_K, T.Q6_K], ids=lambda t: T.NAMES[t])
+def test_small_batch_mfma_vs_oracle(gpu, oracle, t, m, k, n):
+    """A handful of tokens: exact integer codes as f16 fragments, one MFMA tile of 32 token slots, two work-groups (K halves) adding
+    into the zeroed result.  <= 2e-6 of the oracle; f32 and pre-quantised activations give the same bits; a rerun gives the same
+    bits (two addends commute); rows and tokens beside the result are left alone."""
+    raw = synth.random_weights_torch(t, m, k, 500 + t + k % 89).cpu().numpy()
+    x = synth.random_activations(n, k, 23 + k % 11)
+    x[n - 1, :256] = 0.0  # an all-zero block
+    bt = T.VEC_DOT[t]
+    Bq = synth.quantize_activations(bt, x)
+    W = gpu.upload_weights(t, raw, m, k)
+    xd = torch.from_numpy(x).cuda().view(torch.uint8).view(n, k * 4)
+    c_f32 = gpu.mul_mat(W, xd, T.F32, n=n).cpu().numpy()
+    c_again = gpu.mul_mat(W, xd, T.F32, n=n).cpu().numpy()
+    c_q = gpu.mul_mat(W, torch.from_numpy(Bq).cuda(), bt, n=n).cpu().numpy()
+    assert np.array_equal(c_f32.view(np.uint32), c_again.view(np.uint32))
+    assert np.array_equal(c_f32.view(np.uint32), c_q.view(np.uint32))
+    rows = np.arange(m) if m <= 256 else np.unique(np.concatenate([np.arange(0, m, 61), np.arange(40), np.arange(m - 40, m)]))
+    ok, G = oracle.sgemm(t, np.ascontiguousarray(raw[rows]), bt, Bq, len(rows), n, k, nth=4)
+    assert ok == 1
+    tiles_per_cu = ((m + 31) // 32 + 255) // 256
+    small = (n >= 3) if k > 8192 else (n >= 5) if tiles_per_cu <= 1 else (tiles_per_cu <= 4 and t != T.Q6_K and 8 <= n <= 24)
+    # (a batch of more than 8 tokens that the dispatcher keeps on the 128-token GEMM tiles runs the scaled-operand body: 1e-3)
+    tol = 2e-6 if small or n <= 8 else 1e-3
+    assert rel_err(c_q[:, rows], G) <= tol, (T.NAMES[t], m, k, n, rel_err(c_q[:, rows], G))
+    # every column equals the single-token GEMV of that token as well (an independent kernel)
+    one = gpu.mul_mat(W, xd[n // 2:n // 2 + 1].contiguous(), T.F32, n=1).cpu().numpy()
+    assert rel_err(c_f32[n // 2:n // 2 + 1], one) <= tol
+
+
+def test_small_batch_respects_the_result_stride(gpu, oracle):
+    """ldc > m: the staging pass zeroes and the kernel adds into rows of the result only (the gap keeps its bytes)."""
+    import ctypes as C
+    from llamafile_amd import _hip, sgemm
+    t, m, k, n, ldc = T.Q4_K, 70, 1024, 6, 96
+    raw = synth.random_weights_torch(t, m, k, 77).cpu().numpy()
+    x = synth.random_activations(n, k, 78)
+    W = gpu.upload_weights(t, raw, m, k)
+    xd = torch.from_numpy(x).cuda()
+    out = torch.full((n, ldc), 7.0, device="cuda")
+    ws = torch.empty(max(16, sgemm.workspace_bytes(t, m, k, n)), dtype=torch.uint8, device="cuda")
+    L = _hip.lib()
+    rc = L.lfamd_mul_mat(t, C.c_void_p(W.data.data_ptr()), m, k, T.F32, C.c_void_p(xd.data_ptr()), k * 4, n, C.c_void_p(out.data_ptr()), ldc,
+                         C.c_void_p(ws.data_ptr()), ws.numel(), 0, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0, L.lfamd_last_error()
+    got = out.cpu().numpy()
+    assert (got[:, m:] == 7.0).all()
+    ok, G = oracle.sgemm(t, raw, T.Q8_K, synth.quantize_activations(T.Q8_K, x), m, n, k, nth=4)
+    assert ok == 1 and rel_err(got[:, :m], G) <= 2e-6
