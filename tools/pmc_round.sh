@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/pmc_round; rm -rf $OUT; mkdir -p $OUT
 CASES="Q4_K,4096,4096,512;Q4_K,14336,4096,512;Q4_K,4096,4096,1;Q4_K,4096,14336,1"
 n=0
-for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_MFMA" "SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU" "GRBM_GUI_ACTIVE FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; do
+for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_MFMA" "SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU" "GRBM_GUI_ACTIVE FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "SQ_VALU_MFMA_COEXEC_CYCLES SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_SCA"; do
   n=$((n+1))
   timeout -k 10 200 rocprofv3 --pmc $set --output-format csv -d $OUT/s$n -- python3 tools/kbench.py --cases "$CASES" --iters 2 --copies 8 > $OUT/s$n.log 2>&1 || echo "set failed: $set"
 done
@@ -19,6 +19,10 @@ for f in glob.glob(f"{out}/s*/**/*counter_collection.csv", recursive=True):
         k = r["Kernel_Name"]
         if "gemm_lw_kernel" in k:
             key = "gemm_lw " + ("128x64" if "Li2E" in k.split("gemm_mats")[0] else "128x128")
+        elif "gemm_ks_kernel" in k:
+            key = "gemm_ks 128x64 (4096x4096x512)"
+        elif "gemm_kr_kernel" in k:
+            key = "gemm_kr 256x128 (14336x4096x512)"
         elif "gemv_kq_kernel" in k and "q4k" in k:
             key = "gemv_q4k " + ("k<=4096" if ", 16, 1," in k or "Li16ELi1E" in k else "deep-k")
         elif "prep_scaled" in k:

@@ -39,6 +39,10 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             agg["gemm_q4k_wide"].append(float(r["Counter_Value"]))
         elif "gemm_lw_kernel" in k and "Li12E" in k:
             agg["gemm_q4k_lw_" + ("128x64" if "Li2E" in k else "128x128")].append(float(r["Counter_Value"]))
+        elif "gemm_ks_kernel" in k:
+            agg["gemm_q4k_ks_128x64"].append(float(r["Counter_Value"]))
+        elif "gemm_kr_kernel" in k:
+            agg["gemm_q4k_kr_256x128"].append(float(r["Counter_Value"]))
     for k, v in agg.items():
         res[k][ctr + "_KB_avg_per_launch"] = sum(v) / len(v)
         res[k]["launches"] = len(v)
