@@ -158,6 +158,14 @@ int lfamd_mul_mat_id(int type, const void *d_W_packed, long rows, long cols, int
                      const int32_t *d_plan, int thinkers, float *d_result, void *d_workspace,
                      size_t workspace_bytes, unsigned flags, void *stream);
 
+/* Several GGML_OP_MUL_MAT_ID nodes of one weight type and shape over the SAME activations and routing table (ffn_gate_exps and
+ * ffn_up_exps of a layer, ggml-cuda.cu.patch:18945 graph_compute sees them back to back): at decode (tokens <= 4, tasks == 1, Q4_K / Q5_K
+ * / Q6_K experts) all (tensor, thinker) GEMVs of a token share launches of up to four — one launch for Mixtral's two tensors x two
+ * thinkers; otherwise one lfamd_mul_mat_id per tensor.  d_result[j]: f32 [tokens][thinkers][rows] of tensor j. */
+int lfamd_mul_mat_id_multi(int type, int count, const void *const *d_W_packed, long rows, long cols, int experts, int Btype,
+                           const void *d_thought, size_t b_row_bytes, int tasks, long tokens, const int32_t *d_plan, int thinkers,
+                           float *const *d_result, void *d_ws, size_t ws_bytes, unsigned flags, void *stream);
+
 /* ---- the step in front of the path, fused: RMS-norm x weight -> Q8_K -----------------------------
  * y[i] = (x[i] * 1/sqrtf(mean(x^2) + eps)) * weight[i] per row (ggml_compute_forward_rms_norm_f32 + the MUL node; GPU
  * reference rms_norm_f32, ggml-cuda.cu.patch:14926-14960), written as the reference's Q8_K activation blocks

@@ -24,6 +24,10 @@ hipError_t lfamd_launch_pack_q80(const void *, size_t, long, long, void *, hipSt
 hipError_t lfamd_launch_pack_raw(const void *, size_t, long, size_t, void *, hipStream_t);
 hipError_t lfamd_launch_prep_q8k(const void *, size_t, long, long, long, void *, void *, void *, int, const int32_t *, hipStream_t);
 hipError_t lfamd_launch_prep_f32(const void *, size_t, long, long, long, void *, void *, void *, int, const int32_t *, hipStream_t);
+bool lfamd_moe_decode_multi_ok(int type, long cols, int Btype, int tasks, long tokens, unsigned flags);
+hipError_t lfamd_launch_moe_decode_multi(int type, int count, const void *const *W, long rows, long cols, int experts, size_t expert_bytes,
+                                         int Btype, const void *thought, size_t b_row_bytes, long tokens, const int32_t *plan, int thinkers,
+                                         float *const *result, hipStream_t s);
 size_t lfamd_gemm_sb_workspace(long k);
 bool lfamd_gemm_sb_ok(int Atype, long k, long n);
 hipError_t lfamd_launch_gemm_sb(int Atype, const void *A, long m, long k, int Btype, const void *B, size_t b_row_bytes, long n, float *C,
@@ -801,6 +805,30 @@ int lfamd_mul_mat_id(int type, const void *d_W, long rows, long cols, int expert
                             b_row_bytes, tasks, tokens, d_plan, thinkers, d_result, d_ws, ws_bytes, flags,
                             (hipStream_t)stream),
            "mul_mat_id");
+    return LFAMD_OK;
+}
+
+int lfamd_mul_mat_id_multi(int type, int count, const void *const *d_W, long rows, long cols, int experts, int Btype, const void *d_thought,
+                           size_t b_row_bytes, int tasks, long tokens, const int32_t *d_plan, int thinkers, float *const *d_result,
+                           void *d_ws, size_t ws_bytes, unsigned flags, void *stream) {
+    (void)hipGetLastError();
+    if (count <= 0)
+        return LFAMD_OK;
+    if (!d_W || !d_result)
+        return fail(LFAMD_ERR_INVALID, "mul_mat_id_multi: null argument%s", "");
+    if (count <= 4 && type_known(type) && rows > 0 && cols > 0 && experts > 0 && thinkers > 0 && thinkers <= experts && tokens > 0 &&
+        b_row_bytes >= lfamd_row_size(Btype, cols) && lfamd_moe_decode_multi_ok(type, cols, Btype, tasks, tokens, flags)) {
+        HIPCHK(lfamd_launch_moe_decode_multi(type, count, d_W, rows, cols, experts, lfamd_packed_size(type, rows, cols), Btype, d_thought,
+                                             b_row_bytes, tokens, d_plan, thinkers, d_result, (hipStream_t)stream),
+               "mul_mat_id_multi");
+        return LFAMD_OK;
+    }
+    for (int j = 0; j < count; j++) { // batches, other types, per-thinker activations: one operator at a time
+        const int r = lfamd_mul_mat_id(type, d_W[j], rows, cols, experts, Btype, d_thought, b_row_bytes, tasks, tokens, d_plan, thinkers,
+                                       d_result[j], d_ws, ws_bytes, flags, stream);
+        if (r)
+            return r;
+    }
     return LFAMD_OK;
 }
 

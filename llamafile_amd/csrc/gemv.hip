@@ -167,7 +167,8 @@ extern "C" hipError_t lfamd_launch_gemv_dual(int type_a, int count_a, const void
 
 // GGML_OP_MUL_MAT_ID for ONE activation row: `count` (<= GEMV_MAX_MATS) outputs C[j] = W[ids[id_idx[j]]] x B, the expert
 // index read on the device.  Q4_K / Q6_K stacks; Btype F32 or Q8_K.
-extern "C" hipError_t lfamd_launch_gemv_ids(int Atype, int count, const void *W, long expert_bytes, int experts,
+// W[j]: the expert tensor matrix j picks from (ffn_gate_exps and ffn_up_exps may share one launch: same activations)
+extern "C" hipError_t lfamd_launch_gemv_ids(int Atype, int count, const void *const *W, long expert_bytes, int experts,
                                             const int32_t *ids, const int *id_idx, long m, long k, int Btype, const void *B,
                                             size_t b_row_bytes, float *const *C, hipStream_t s) {
     if (count <= 0 || count > GEMV_MAX_MATS || m <= 0 ||
@@ -181,7 +182,7 @@ extern "C" hipError_t lfamd_launch_gemv_ids(int Atype, int count, const void *W,
     mats.ids = ids, mats.expert_bytes = expert_bytes, mats.experts = experts;
     for (int i = 0; i < GEMV_MAX_MATS; i++) {
         const int j = i < count ? i : 0;
-        mats.A[i] = (const uint8_t *)W, mats.C[i] = C[j], mats.m[i] = i < count ? m : 0, mats.ldc[i] = m;
+        mats.A[i] = (const uint8_t *)W[j], mats.C[i] = C[j], mats.m[i] = i < count ? m : 0, mats.ldc[i] = m;
         mats.id_idx[i] = id_idx[j];
         if (i < count)
             n_ht += (int)(((m + 31) / 32) * 2);

@@ -18,7 +18,7 @@
 extern "C" int lfamd_mul_mat(int, const void *, long, long, int, const void *, size_t, long, float *, long, void *, size_t,
                              unsigned, void *);
 extern "C" size_t lfamd_mul_mat_workspace(int, long, long, long);
-extern "C" hipError_t lfamd_launch_gemv_ids(int, int, const void *, long, int, const int32_t *, const int *, long, long, int,
+extern "C" hipError_t lfamd_launch_gemv_ids(int, int, const void *const *, long, int, const int32_t *, const int *, long, long, int,
                                             const void *, size_t, float *const *, hipStream_t);
 
 __global__ void moe_gather_kernel(const uint8_t *__restrict__ src, size_t src_stride, size_t row_bytes,
@@ -154,6 +154,38 @@ extern "C" size_t lfamd_moe_workspace(int type, long rows, long cols, int expert
     return host_path;
 }
 
+// Decode, several expert tensors of one type and shape that consume the SAME activation row (ffn_gate_exps + ffn_up_exps,
+// tasks == 1): all (tensor, thinker) pairs of a token in launches of up to four GEMVs — one launch for two tensors x two thinkers
+// (Mixtral) instead of one per tensor.  false: the caller runs lfamd_launch_moe per tensor.
+extern "C" bool lfamd_moe_decode_multi_ok(int type, long cols, int Btype, int tasks, long tokens, unsigned flags) {
+    return tokens <= 4 && tasks == 1 && (type == LFAMD_TYPE_Q4_K || type == LFAMD_TYPE_Q5_K || type == LFAMD_TYPE_Q6_K) &&
+           !(flags & LFAMD_FLAG_FORCE_GENERIC) && (Btype == LFAMD_TYPE_F32 || Btype == LFAMD_TYPE_Q8_K) && cols % 256 == 0 &&
+           (size_t)(cols / 256) * 384 <= 150 * 1024;
+}
+extern "C" hipError_t lfamd_launch_moe_decode_multi(int type, int count, const void *const *W, long rows, long cols, int experts,
+                                                    size_t expert_bytes, int Btype, const void *thought, size_t b_row_bytes, long tokens,
+                                                    const int32_t *plan, int thinkers, float *const *result, hipStream_t s) {
+    for (long t = 0; t < tokens; t++) {
+        const uint8_t *Brow = (const uint8_t *)thought + (size_t)t * b_row_bytes;
+        const void *Ws[4];
+        int idx[4];
+        float *Cs[4];
+        int cnt = 0;
+        for (int j = 0; j < count; j++)
+            for (int th = 0; th < thinkers; th++) {
+                Ws[cnt] = W[j], idx[cnt] = (int)(t * thinkers + th), Cs[cnt] = result[j] + (size_t)(t * thinkers + th) * rows;
+                if (++cnt == 4 || (j == count - 1 && th == thinkers - 1)) {
+                    hipError_t e = lfamd_launch_gemv_ids(type, cnt, Ws, (long)expert_bytes, experts, plan, idx, rows, cols, Btype, Brow,
+                                                         b_row_bytes, Cs, s);
+                    if (e != hipSuccess)
+                        return e;
+                    cnt = 0;
+                }
+            }
+    }
+    return hipSuccess;
+}
+
 extern "C" hipError_t lfamd_launch_moe(int type, const void *W, long rows, long cols, int experts, size_t expert_bytes,
                                        int Btype, const void *thought, size_t b_row_bytes, int tasks, long tokens,
                                        const int32_t *plan, int thinkers, float *result, void *ws, size_t ws_bytes,
@@ -179,7 +211,8 @@ extern "C" hipError_t lfamd_launch_moe(int type, const void *W, long rows, long 
                     Cs[q] = result + (size_t)(t * thinkers + th + q) * rows;
                 }
                 const uint8_t *Brow = (const uint8_t *)thought + (size_t)(t * tasks + th % tasks) * b_row_bytes;
-                hipError_t e2 = lfamd_launch_gemv_ids(type, cnt, W, (long)expert_bytes, experts, plan, idx, rows, cols, Btype, Brow,
+                const void *Ws[4] = {W, W, W, W};
+                hipError_t e2 = lfamd_launch_gemv_ids(type, cnt, Ws, (long)expert_bytes, experts, plan, idx, rows, cols, Btype, Brow,
                                                       b_row_bytes, Cs, s);
                 if (e2 != hipSuccess)
                     return e2;

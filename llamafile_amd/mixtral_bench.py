@@ -54,7 +54,9 @@ def run(n_layers: int = 32, iters: int = 20, prefill: int = 512, dev=None) -> di
     x = torch.rand((1, D), device=dev) * 2 - 1
     xf = torch.rand((TOPK, FF), device=dev) * 2 - 1  # one activation row per chosen expert for ffn_down
     ws = torch.empty(1 << 26, dtype=torch.uint8, device=dev)
-    res_gu = torch.empty((1, TOPK, FF), device=dev)
+    res_g = torch.empty((1, TOPK, FF), device=dev)
+    res_u = torch.empty((1, TOPK, FF), device=dev)
+    res_ptrs = (C.c_void_p * 2)(res_g.data_ptr(), res_u.data_ptr())
     res_d = torch.empty((1, TOPK, D), device=dev)
 
     def ptr(t):
@@ -68,12 +70,17 @@ def run(n_layers: int = 32, iters: int = 20, prefill: int = 512, dev=None) -> di
                                 ptr(res), ptr(ws), ws.numel(), flags, C.c_void_p(torch.cuda.current_stream().cuda_stream))
         _hip.check(rc, "mul_mat_id")
 
+    def moe_gate_up(lay):  # ffn_gate_exps + ffn_up_exps: same activations, same routing -> one launch (2 tensors x 2 thinkers)
+        wp = (C.c_void_p * 2)(lay["gate"].data_ptr(), lay["up"].data_ptr())
+        rc = L.lfamd_mul_mat_id_multi(T.Q4_K, 2, wp, FF, D, E, T.F32, ptr(x), x.stride(0) * 4, 1, 1, ptr(lay["plan"]), TOPK, res_ptrs,
+                                      ptr(ws), ws.numel(), flags, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        _hip.check(rc, "mul_mat_id_multi")
+
     def decode_pass():
         for lay in layers:
             mm([lay["q"], lay["k"], lay["v"]], x)  # (one launch: the K-quant pair {Q4_K, Q6_K} is fused)
             mm([lay["o"]], x)
-            moe(lay["gate"], T.Q4_K, FF, D, x, 1, lay["plan"], res_gu)
-            moe(lay["up"], T.Q4_K, FF, D, x, 1, lay["plan"], res_gu)
+            moe_gate_up(lay)
             moe(lay["down"], lay["hi"], D, FF, xf, TOPK, lay["plan"], res_d)
         mm([out_w], x)
 

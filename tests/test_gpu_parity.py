@@ -622,3 +622,38 @@ def test_mul_mat_id_other_expert_types(gpu, oracle, t, tokens):
             else:  # (an expert with more than 8 rows runs the MFMA body: IQ4_XS rounds |sc * v| above 2048 to f16 there)
                 tol = 1e-3 if t == T.IQ4_XS and tokens > 1 else TOL.get(t, DEFAULT_TOL)
                 assert rel_err(res[tok, th], G[0]) <= tol, (T.NAMES[t], tok, th)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tokens,thinkers,count", [(1, 2, 2), (3, 2, 2), (1, 3, 2), (2, 2, 3), (9, 2, 2)], ids=str)
+@pytest.mark.parametrize("t", [T.Q4_K, T.Q6_K], ids=lambda t: T.NAMES[t])
+def test_mul_mat_id_multi_equals_separate_calls(gpu, t, tokens, thinkers, count):
+    """lfamd_mul_mat_id_multi: ffn_gate_exps + ffn_up_exps (same activations, same routing) share decode launches of up to four
+    (tensor, thinker) GEMVs; the results are the bits of one lfamd_mul_mat_id per tensor (itself oracle-tested above), also where
+    it falls back to those calls (9 tokens), also with an out-of-range expert id."""
+    import ctypes as C
+    from llamafile_amd import synth, _hip
+    rows, cols, experts = 80, 768, 5
+    stacks = [torch.cat([gpu.upload_weights(t, synth.random_weights(t, rows, cols, 1200 + 10 * j + e), rows, cols).data for e in range(experts)])
+              for j in range(count)]
+    x = synth.random_activations(tokens, cols, 79)
+    thought = torch.from_numpy(x).cuda().view(torch.uint8).view(tokens, cols * 4)
+    rng = np.random.default_rng(8)
+    plan = rng.integers(0, experts, size=(tokens, thinkers)).astype(np.int32)
+    if tokens > 1:
+        plan[-1, 0] = experts + 1
+    pd = torch.from_numpy(plan).cuda()
+    want = [gpu.mul_mat_id(s, t, rows, cols, experts, thought, T.F32, 1, tokens, pd, thinkers, prefill=-3.0) for s in stacks]
+    got = [torch.full((tokens, thinkers, rows), -3.0, device="cuda") for _ in range(count)]
+    L = _hip.lib()
+    need = L.lfamd_mul_mat_id_workspace(t, rows, cols, experts, tokens, thinkers)
+    ws = torch.empty(max(need, 16), dtype=torch.uint8, device="cuda")
+    wp = (C.c_void_p * count)(*[s.data_ptr() for s in stacks])
+    rp = (C.c_void_p * count)(*[g.data_ptr() for g in got])
+    rc = L.lfamd_mul_mat_id_multi(t, count, wp, rows, cols, experts, T.F32, C.c_void_p(thought.data_ptr()), thought.stride(0), 1, tokens,
+                                  C.c_void_p(pd.data_ptr()), thinkers, rp, C.c_void_p(ws.data_ptr()), ws.numel(), gpu.host_variant_flags(),
+                                  C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0, L.lfamd_last_error()
+    torch.cuda.synchronize()
+    for g, w in zip(got, want):
+        assert torch.equal(g.view(torch.int32), w.view(torch.int32))
