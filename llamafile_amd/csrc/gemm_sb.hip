@@ -49,28 +49,18 @@ __global__ __launch_bounds__(64) void sb_prep_kernel(const uint8_t *__restrict__
         // clamped at 127; d = 1 / iscale  (pack.hip: prep_f32_kernel, the same arithmetic)
         const float4 f = *(const float4 *)((const float *)(B + (size_t)tok * b_row_bytes) + (size_t)b * 256 + 4 * t);
         const float v[4] = {f.x, f.y, f.z, f.w};
-        float amax = 0.0f, val = 0.0f;
-        int idx = 4 * t;
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            const float ax = fabsf(v[e]);
-            if (ax > amax) {
-                amax = ax;
-                val = v[e];
-                idx = 4 * t + e;
-            }
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const float oa = __shfl_xor(amax, off, 64);
-            const int oi = __shfl_xor(idx, off, 64);
-            const float ov = __shfl_xor(val, off, 64);
-            if (oa > amax || (oa == amax && oi < idx)) {
-                amax = oa;
-                idx = oi;
-                val = ov;
-            }
-        }
+        // block maximum by DPP (no LDS round trips), then the FIRST lane / element that reaches it (gemv_impl.h: stage_f32_q8k_wave)
+        const float a0 = fabsf(v[0]), a1 = fabsf(v[1]), a2 = fabsf(v[2]), a3 = fabsf(v[3]);
+        float am = fmaxf(fmaxf(a0, a1), fmaxf(a2, a3));
+        am = fmaxf(am, dpp_f32<DPP_XOR1>(am));
+        am = fmaxf(am, dpp_f32<DPP_XOR2>(am));
+        am = fmaxf(am, dpp_f32<DPP_HALF_MIRROR>(am));
+        am = fmaxf(am, dpp_f32<DPP_MIRROR>(am));
+        const float amax = fmaxf(fmaxf(readlane_f32(am, 0), readlane_f32(am, 16)), fmaxf(readlane_f32(am, 32), readlane_f32(am, 48)));
+        const bool m0 = a0 == amax, m1 = a1 == amax, m2 = a2 == amax, m3 = a3 == amax;
+        const unsigned long long ball = __builtin_amdgcn_ballot_w64(m0 || m1 || m2 || m3);
+        const float cand = m0 ? v[0] : (m1 ? v[1] : (m2 ? v[2] : v[3]));
+        const float val = readlane_f32(cand, ball ? __builtin_ctzll(ball) : 0);
         q[0] = q[1] = q[2] = q[3] = 0;
         d = 0.0f;
         if (amax != 0.0f) {
@@ -96,9 +86,9 @@ __global__ __launch_bounds__(64) void sb_prep_kernel(const uint8_t *__restrict__
         d8T[(size_t)b * SB_COLS + tok] = d;
     if constexpr (MINS) { // pair sum j = codes 32j .. 32j+31 = lanes 8j .. 8j+7; |S| <= 4096: S = 64 hi + lo, lo in [0, 63]
         int S = q[0] + q[1] + q[2] + q[3];
-        S += __shfl_xor(S, 1, 64);
-        S += __shfl_xor(S, 2, 64);
-        S += __shfl_xor(S, 4, 64);
+        S += (int)dpp_u32<DPP_XOR1>((uint32_t)S);
+        S += (int)dpp_u32<DPP_XOR2>((uint32_t)S);
+        S += (int)dpp_u32<DPP_HALF_MIRROR>((uint32_t)S); // lanes 8j .. 8j+7
         if ((t & 7) == 0) {
             const int lo = S & 63, hi = (S - lo) / 64;
             mo[t >> 3] = (_Float16)(float)lo;
