@@ -50,8 +50,8 @@ enum lfamd_status {
 #define LFAMD_FLAG_GEMM_WIDE 16u    /* testing: force the 128x128 MFMA body */
 #define LFAMD_FLAG_GEMM_PLAIN 32u   /* testing: the 128x128 body without loader waves (Q4_K / Q5_K default to them) */
 #define LFAMD_FLAG_Q80_EXACT 64u    /* Q8_0 batches (n > 8): the BIT-EXACT restatement of tinyBLAS_Q0's 8-lane chains (VALU, ~12x
-                                       slower) instead of the default MFMA body (exact integer block dots, f32 scales: within 2e-6
-                                       of the reference).  n <= 8 — the Q8_0 vecdot of the north star — is always bit-exact;
+                                       slower) instead of the default: the vendor f16 GEMM on the resident f16(d * q) image (<= 1e-3),
+                                       or, where lfamd_vendor_gemm_available() is 0, the MFMA body on exact integer codes (2e-6).  n <= 8 — the Q8_0 vecdot of the north star — is always bit-exact;
                                        LFAMD_FLAG_PRECISE implies this flag. */
 
 int lfamd_abi_version(void);
@@ -82,6 +82,11 @@ int lfamd_stream_sync(void *stream);
  * and decode kernels read (164 / 164 / 272 / 192 / 192 / 192 bytes per 256 weights: up to 2x the file size, DESIGN.md
  * section 3); legacy 32-block rows that are not whole 256-weight groups and float tensors stay as GGUF rows. */
 size_t lfamd_packed_size(int type, long rows, long cols);
+/* 1 when batches on PLAIN 16-bit float matrices — F16 / BF16 weight tensors and the resident f16(d * q) image of Q8_0 weights — go
+ * through the vendor's GEMM (hipBLASLt, dlopen()ed on first use; LFAMD_NO_BLASLT=1 in the environment keeps it out), 0 when they
+ * run on this module's own MFMA bodies.  Decides the second Q8_0 image (f16 rows, 3.1 bytes per weight resident, <= 1e-3 — or
+ * the byte image of the exact-code body, 2.1 bytes per weight, 2e-6); constant for the life of the process. */
+int lfamd_vendor_gemm_available(void);
 int lfamd_pack_weights(int type, long rows, long cols, const void *d_raw, size_t raw_row_bytes,
                        void *d_packed, void *stream);
 

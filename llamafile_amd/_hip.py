@@ -52,6 +52,7 @@ _SIGS = {
     "lfamd_mul_mat_multi_types": (_i, [_i, _vp, _vp, _vp, _l, _i, _vp, _sz, _l, _vp, _vp, _vp, _sz, _u, _vp]),
     "lfamd_mul_mat_id_workspace": (_sz, [_i, _l, _l, _i, _l, _i]),
     "lfamd_mul_mat_id": (_i, [_i, _vp, _l, _l, _i, _i, _vp, _sz, _i, _l, _vp, _i, _vp, _vp, _sz, _u, _vp]),
+    "lfamd_vendor_gemm_available": (_i, []),
     "lfamd_mul_mat_id_multi": (_i, [_i, _i, _vp, _l, _l, _i, _i, _vp, _sz, _i, _l, _vp, _i, _vp, _vp, _sz, _u, _vp]),
     "lfamd_rms_norm_quantize": (_i, [_vp, _sz, _vp, C.c_float, _l, _l, _i, _vp, _sz, _vp, _sz, _vp]),
     "lfamd_swiglu_quantize": (_i, [_vp, _sz, _vp, _sz, _l, _l, _i, _vp, _sz, _vp, _sz, _vp]),

@@ -28,6 +28,13 @@ bool lfamd_moe_decode_multi_ok(int type, long cols, int Btype, int tasks, long t
 hipError_t lfamd_launch_moe_decode_multi(int type, int count, const void *const *W, long rows, long cols, int experts, size_t expert_bytes,
                                          int Btype, const void *thought, size_t b_row_bytes, long tokens, const int32_t *plan, int thinkers,
                                          float *const *result, hipStream_t s);
+bool lfamd_blaslt_ok();
+size_t lfamd_blaslt_workspace();
+hipError_t lfamd_blaslt_gemm(int dtype, const void *W, long ldw, const void *X, long ldx, long m, long n, long k, float *C, long ldc, void *ws,
+                             size_t ws_bytes, hipStream_t s);
+hipError_t lfamd_launch_rows_to_16(int dtype, const void *X, size_t x_row_bytes, long n, long k, void *out, hipStream_t s);
+hipError_t lfamd_launch_q80_rows_to_f16(int Btype, const void *X, size_t x_row_bytes, long n, long k, void *out, hipStream_t s);
+hipError_t lfamd_launch_q80_image(const void *raw, size_t raw_row_bytes, long rows, long cols, void *out, hipStream_t s);
 size_t lfamd_gemm_sb_workspace(long k);
 bool lfamd_gemm_sb_ok(int Atype, long k, long n);
 hipError_t lfamd_launch_gemm_sb(int Atype, const void *A, long m, long k, int Btype, const void *B, size_t b_row_bytes, long n, float *C,
@@ -196,8 +203,11 @@ size_t lfamd_packed_size(int type, long rows, long cols) {
         return (size_t)((rows + 31) / 32) * (size_t)(cols / 256) * P5K_TILE;
     case LFAMD_TYPE_Q6_K:
         return (size_t)((rows + 31) / 32) * (size_t)(cols / 256) * P6K_TILE;
-    case LFAMD_TYPE_Q8_0: // P80 (the bit-exact vecdot / exact batch kernels), then — rows of whole 256-weight groups — the PC8-form
-                          // byte image the MFMA batch body reads (2.1 bytes per weight resident instead of a rebuild per call)
+    case LFAMD_TYPE_Q8_0: // P80 (the bit-exact vecdot / exact batch kernels), then the image batches read: f16(d * q) rows for the
+                          // vendor GEMM (3.1 bytes per weight resident), or — hipBLASLt not loadable, rows of whole 256-weight
+                          // groups — the PC8-form byte image of the MFMA body (2.1 bytes per weight)
+        if (lfamd_blaslt_ok()) // plain f16 image f16(d * q), row-major: batches are a library GEMM (blaslt.hip)
+            return q80_p80_bytes(rows, cols) + (size_t)rows * (size_t)cols * 2;
         return q80_p80_bytes(rows, cols) + (cols % 256 == 0 ? lfamd_wprep8_bytes(rows, cols) : 0);
     case LFAMD_TYPE_Q2_K:
     case LFAMD_TYPE_Q3_K: // PCK: the image the MFMA GEMM and the decode GEMV both read
@@ -244,7 +254,9 @@ int lfamd_pack_weights(int type, long rows, long cols, const void *d_raw, size_t
         break;
     case LFAMD_TYPE_Q8_0:
         HIPCHK(lfamd_launch_pack_q80(d_raw, raw_row_bytes, rows, cols, d_packed, s), "pack_q80");
-        if (cols % 256 == 0)
+        if (lfamd_blaslt_ok())
+            HIPCHK(lfamd_launch_q80_image(d_raw, raw_row_bytes, rows, cols, (uint8_t *)d_packed + q80_p80_bytes(rows, cols), s), "pack_f16 (Q8_0)");
+        else if (cols % 256 == 0)
             HIPCHK(lfamd_launch_wprep8(type, d_packed, 0, rows, cols, (uint8_t *)d_packed + q80_p80_bytes(rows, cols), s), "pack_pc8 (Q8_0)");
         break;
     case LFAMD_TYPE_Q2_K:
@@ -341,15 +353,26 @@ static bool use_gemm_float(int Atype, long n, unsigned flags, long k) {
     return !(flags & LFAMD_FLAG_FORCE_GENERIC) && n > 8 && k % 256 == 0 && (Atype == LFAMD_TYPE_F16 || Atype == LFAMD_TYPE_BF16);
 }
 
-// Q8_0 batches.  Default (rows of whole 256-weight groups): the MFMA body on a per-call byte image — exact integer block
-// dots, f32 block scales, <= 2e-6 of the reference; the north star asks for bit-exactness of the Q8_0 VECDOT (n <= 8: the
-// GEMV), not for replaying tinyBLAS's 8-lane chains at n = 512.  LFAMD_FLAG_PRECISE (or other row lengths): the
-// register-tiled BIT-EXACT kernel (gemm_q80.hip), 12x slower.
+// Q8_0 batches.  Default: the vendor's f16 GEMM on the resident f16(d * q) image (blaslt.hip; <= 1e-3, the north star's tolerance
+// for f16 MFMA paths); where hipBLASLt does not load (rows of whole 256-weight groups): this module's MFMA body on the resident
+// byte image — exact integer block dots, f32 block scales, <= 2e-6.  The north star asks for bit-exactness of the Q8_0 VECDOT
+// (n <= 8: the GEMV), not for replaying tinyBLAS's 8-lane chains at n = 512; LFAMD_FLAG_PRECISE / LFAMD_FLAG_Q80_EXACT (or other
+// row lengths without the library): the register-tiled BIT-EXACT kernel (gemm_q80.hip), an order of magnitude slower.
+// (with hipBLASLt loadable the default is the library GEMM on the resident f16 image: use_gemm_q80_lt)
+static bool use_gemm_q80_lt(int Atype, long n, unsigned flags, long k) {
+    return !(flags & (LFAMD_FLAG_FORCE_GENERIC | LFAMD_FLAG_PRECISE | LFAMD_FLAG_Q80_EXACT)) && n > 8 && Atype == LFAMD_TYPE_Q8_0 && k % 32 == 0 &&
+           lfamd_blaslt_ok();
+}
 static bool use_gemm_q80_mfma(int Atype, long n, unsigned flags, long k) {
-    return !(flags & (LFAMD_FLAG_FORCE_GENERIC | LFAMD_FLAG_PRECISE | LFAMD_FLAG_Q80_EXACT)) && n > 8 && Atype == LFAMD_TYPE_Q8_0 && k % 256 == 0;
+    return !(flags & (LFAMD_FLAG_FORCE_GENERIC | LFAMD_FLAG_PRECISE | LFAMD_FLAG_Q80_EXACT)) && n > 8 && Atype == LFAMD_TYPE_Q8_0 && k % 256 == 0 &&
+           !lfamd_blaslt_ok();
+}
+static size_t gemm_lt_ws(long k, long n) { // the 16-bit activation rows, then the library's workspace
+    return align_up((size_t)n * (size_t)k * 2, 256) + lfamd_blaslt_workspace();
 }
 static bool use_gemm_q80(int Atype, long n, unsigned flags, long k) {
-    return !(flags & LFAMD_FLAG_FORCE_GENERIC) && n > 8 && Atype == LFAMD_TYPE_Q8_0 && !use_gemm_q80_mfma(Atype, n, flags, k);
+    return !(flags & LFAMD_FLAG_FORCE_GENERIC) && n > 8 && Atype == LFAMD_TYPE_Q8_0 && !use_gemm_q80_mfma(Atype, n, flags, k) &&
+           !use_gemm_q80_lt(Atype, n, flags, k);
 }
 static size_t gemm_q80_mfma_ws(long m, long k, long n) { // Xh, d8T [nb*8][n_pad]  (the weight image is resident: lfamd_packed_size)
     (void)m;
@@ -399,13 +422,16 @@ static size_t mul_mat_workspace_base(int Atype, long m, long k, long n) {
         return align_up(n_pad * (size_t)k * 2, 256) + align_up(nb * n_pad * 4, 256) + align_up(n_pad * nb * 32, 256) +
                (Atype == LFAMD_TYPE_Q4_0 ? 0 : lfamd_gemm_lw_ksplit_bytes(m, n)); // partial tiles of a K-split launch
     }
-    if (Atype == LFAMD_TYPE_Q8_0 && n > 8) { // (either body may be asked for through the flags: the larger of the two)
+    if (Atype == LFAMD_TYPE_Q8_0 && n > 8) { // (either body may be asked for through the flags: the largest)
         const size_t exact = align_up(lfamd_gemm_q80_workspace(k, n), 256);
-        const size_t mfma = k % 256 == 0 ? gemm_q80_mfma_ws(m, k, n) : 0;
+        const size_t mfma = use_gemm_q80_lt(Atype, n, 0, k) ? gemm_lt_ws(k, n) : k % 256 == 0 ? gemm_q80_mfma_ws(m, k, n) : 0;
         return exact > mfma ? exact : mfma;
     }
-    if (use_gemm_float(Atype, n, 0, k))
-        return align_up(align_up((size_t)n, 128) * (size_t)k * 2, 256);
+    if (use_gemm_float(Atype, n, 0, k)) {
+        const size_t own = align_up(align_up((size_t)n, 128) * (size_t)k * 2, 256);
+        const size_t lt = lfamd_blaslt_ok() ? gemm_lt_ws(k, n) : 0;
+        return own > lt ? own : lt;
+    }
     if (use_gemm_canon(Atype, n, 0))
         return gemm_act_ws(k, n);
     if (use_gemm_canon32(Atype, n, 0, k)) { // Xh, d8T [nb*8][n_pad], sT [nb*8][n_pad], image
@@ -499,6 +525,23 @@ int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const v
         size_t need = lfamd_mul_mat_workspace(Atype, m, k, n);
         if (ws_bytes < need || !d_ws)
             return fail(LFAMD_ERR_WORKSPACE, "mul_mat: workspace too small%s", "");
+        // plain 16-bit float weights: the vendor's GEMM (blaslt.hip) unless a testing flag asks for this module's body
+        if (lfamd_blaslt_ok() && !(flags & (LFAMD_FLAG_GEMM_WIDE | LFAMD_FLAG_GEMM_NARROW | LFAMD_FLAG_GEMM_PLAIN)) && ((uintptr_t)d_A & 15) == 0) {
+            uint8_t *ws8 = (uint8_t *)d_ws;
+            const void *X16 = d_B;
+            long ldx = (long)(b_row_bytes / 2);
+            if (Btype == LFAMD_TYPE_F32 || ((uintptr_t)d_B & 15) || (b_row_bytes & 15)) {
+                if (Btype != LFAMD_TYPE_F32)
+                    goto own_float_body; // (unaligned 16-bit rows: rare; the module's kernel takes them)
+                HIPCHK(lfamd_launch_rows_to_16(Atype, d_B, b_row_bytes, n, k, ws8, s), "rows_to_16");
+                X16 = ws8, ldx = k;
+            }
+            uint8_t *ltws = ws8 + align_up((size_t)n * (size_t)k * 2, 256);
+            if (lfamd_blaslt_gemm(Atype, d_A, k, X16, ldx, m, n, k, d_C, ldc, ltws, lfamd_blaslt_workspace(), s) == hipSuccess)
+                return LFAMD_OK;
+            (void)hipGetLastError(); // the library declined this shape: this module's body
+        }
+    own_float_body:
         size_t n_pad = align_up((size_t)n, 128);
         HIPCHK(lfamd_launch_prep_float(Atype, Btype, d_B, b_row_bytes, n, (long)n_pad, k, d_ws, s), "prep_float");
         HIPCHK(lfamd_launch_gemm_wide(Atype, d_A, m, k, d_ws, d_ws, d_ws, n, (long)n_pad, d_C, ldc, plain, nullptr, 0, s), "gemm_wide");
@@ -538,6 +581,17 @@ int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const v
         else
             HIPCHK(lfamd_launch_prep_q8k(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, mins16, nullptr, s), "prep_q8k");
         HIPCHK(lfamd_launch_gemm_wide(Atype, d_A, m, k, Xh, d8T, Xm, n, (long)n_pad, d_C, ldc, plain, nullptr, 0, s), "gemm_wide");
+        return LFAMD_OK;
+    }
+    if (use_gemm_q80_lt(Atype, n, flags, k)) {
+        if (ws_bytes < gemm_lt_ws(k, n) || !d_ws)
+            return fail(LFAMD_ERR_WORKSPACE, "mul_mat: workspace too small%s", "");
+        uint8_t *ws8 = (uint8_t *)d_ws;
+        const void *img = (const uint8_t *)d_A + q80_p80_bytes(m, k); // f16(d * q) rows, built once by lfamd_pack_weights
+        HIPCHK(lfamd_launch_q80_rows_to_f16(Btype, d_B, b_row_bytes, n, k, ws8, s), "q80_rows_to_f16");
+        HIPCHK(lfamd_blaslt_gemm(LFAMD_TYPE_F16, img, k, ws8, k, m, n, k, d_C, ldc, ws8 + align_up((size_t)n * (size_t)k * 2, 256),
+                                 lfamd_blaslt_workspace(), s),
+               "blaslt_gemm (Q8_0)");
         return LFAMD_OK;
     }
     if (use_gemm_q80_mfma(Atype, n, flags, k)) {
@@ -806,6 +860,10 @@ int lfamd_mul_mat_id(int type, const void *d_W, long rows, long cols, int expert
                             (hipStream_t)stream),
            "mul_mat_id");
     return LFAMD_OK;
+}
+
+int lfamd_vendor_gemm_available(void) {
+    return lfamd_blaslt_ok() ? 1 : 0;
 }
 
 int lfamd_mul_mat_id_multi(int type, int count, const void *const *d_W, long rows, long cols, int experts, int Btype, const void *d_thought,

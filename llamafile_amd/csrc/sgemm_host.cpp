@@ -182,7 +182,7 @@ void load_module() {
     if (__builtin_cpu_supports("avx512f"))
         g.flags |= LFAMD_FLAG_Q0_VREGS32;
 #endif
-    if (const char *e = getenv("LFAMD_Q80_EXACT")) // Q8_0 batches bit for bit like tinyBLAS_Q0 (default: MFMA body, within 2e-6)
+    if (const char *e = getenv("LFAMD_Q80_EXACT")) // Q8_0 batches bit for bit like tinyBLAS_Q0 (default: library f16 GEMM, <= 1e-3; MFMA body, 2e-6, where hipBLASLt does not load)
         if (atoi(e))
             g.flags |= LFAMD_FLAG_Q80_EXACT;
     g.ok = true;

@@ -29,3 +29,11 @@ def elem_err(C, G, rtol=1e-3):
     rms = float(np.sqrt(np.mean(G * G))) or 1e-30
     d = np.abs(C - G)
     return float(np.mean(d > rtol * np.abs(G) + rtol * rms)), float((d / (np.abs(G) + rms)).max())
+
+
+def q80_batch_tol():
+    """Q8_0 batches (n > 8), default flags: with hipBLASLt loadable they are a library GEMM on f16(d * q) x f16(d8 * code) — one f16
+    rounding per operand, the scaled-operand tolerance of the north star (1e-3, measured 2-4e-4); without it the exact-code MFMA
+    body (2e-6).  The bit-exact kernel is LFAMD_FLAG_Q80_EXACT either way."""
+    from llamafile_amd import _hip
+    return 1e-3 if _hip.lib().lfamd_vendor_gemm_available() else 2e-6

@@ -45,8 +45,10 @@ def test_packed_size_is_exactly_gguf_size_for_aligned_shapes():
     for t in (T.Q4_K, T.Q6_K):
         assert lib.lfamd_packed_size(t, 4096, 4096) == 4096 * T.row_size(t, 4096)
     # Q8_0: the GGUF-sized P80 image, then (rows of whole 256-weight groups) the MFMA batch body's byte image: 8704 B per 32 x 256
-    assert lib.lfamd_packed_size(T.Q8_0, 4096, 4096) == 4096 * T.row_size(T.Q8_0, 4096) + 128 * 16 * 8704
-    assert lib.lfamd_packed_size(T.Q8_0, 64, 96) == 64 // 8 * 1088  # 3 blocks -> one P80 tile of four per 8 rows, no second image
+    # (or, where hipBLASLt loads and a GPU gives it a handle, plain f16 rows for the vendor GEMM: 2 bytes per weight)
+    second = 4096 * 4096 * 2 if lib.lfamd_vendor_gemm_available() else 128 * 16 * 8704
+    assert lib.lfamd_packed_size(T.Q8_0, 4096, 4096) == 4096 * T.row_size(T.Q8_0, 4096) + second
+    assert lib.lfamd_packed_size(T.Q8_0, 64, 96) == 64 // 8 * 1088 + (64 * 96 * 2 if lib.lfamd_vendor_gemm_available() else 0)  # 3 blocks -> one P80 tile of four
     assert lib.lfamd_packed_size(T.Q4_K, 33, 256) == 2 * 4608  # rows round up to 32
     # resident canonical images (the layout GEMM and GEMV both read): PCK for Q2_K / Q3_K, PC8 for IQ4_XS
     assert lib.lfamd_packed_size(T.Q2_K, 4096, 4096) == lib.lfamd_packed_size(T.Q3_K, 4096, 4096) == 128 * 16 * 5248

@@ -20,7 +20,14 @@ def test_pack_matches_layout_spec(gpu, t, ref, shape):
     if t == T.Q8_0:  # two images: P80 (vecdot, exact batches), then 256-aligned the PC8-form byte image of the MFMA batch body
         first = (want.size + 255) // 256 * 256
         assert np.array_equal(got[: want.size], want)
-        second = pack_ref.pack_q80_pc8(raw, rows, cols)
+        from llamafile_amd import _hip
+        if _hip.lib().lfamd_vendor_gemm_available():  # the vendor-GEMM image: f16(d * q), row-major
+            blk = raw.reshape(rows, cols // 32, 34)
+            d = blk[:, :, :2].copy().view(np.float16).astype(np.float32)  # [rows, nblk, 1]
+            q = blk[:, :, 2:].view(np.int8).astype(np.float32)
+            second = (d * q).astype(np.float16).reshape(-1).view(np.uint8)
+        else:
+            second = pack_ref.pack_q80_pc8(raw, rows, cols)
         assert got.size == first + second.size
         assert np.array_equal(got[first:], second)
         return
