@@ -360,8 +360,13 @@ bool get_weights(int type, const void *A, long rows, long cols, size_t row_bytes
     CachedWeights w{type, rows, cols, row_bytes, nullptr, packed};
     w.origin = origin;
     while (g.api.malloc_(&w.d_packed, w.bytes) != LFAMD_OK) { // device full: evict and retry
-        if (g.lru.empty())
-            return false;
+        if (g.lru.empty()) { // nothing left to evict: serve this call from the per-call scratch image instead of failing it
+            bool eo = false;
+            if (!reserve(g.a_scratch, packed) || !upload_packed(type, A, rows, cols, row_bytes, g.a_scratch.p, &eo))
+                return false;
+            *out = {g.a_scratch.p, eo};
+            return true;
+        }
         drop(g.cache.find(g.lru.back()));
     }
     if (!upload_packed(type, A, rows, cols, row_bytes, w.d_packed, &w.exact_only)) {
