@@ -384,7 +384,7 @@ static size_t gemm_q80_mfma_ws(long m, long k, long n) { // Xh, d8T [nb*8][n_pad
 // r03_small_batch.txt; times in us for old -> new):
 //   deep rows (k > 8192, ffn_down)          : n >= 3   (n = 8: 45 -> 16.6 Q4_K, 66 -> 20.3 Q6_K; n = 32: 28 -> 25.8)
 //   at most one row tile per CU (m <= 8192) : n >= 5   (4096 x 4096: n = 8 14.4 -> 9.4, n = 32 16.9 -> 12.2)
-//   up to four row tiles per CU             : 8 <= n <= 24, not Q6_K   (14336 x 4096: n = 8 24.3 -> 20.7)
+//   up to four row tiles per CU             : 6 <= n <= 24, not Q6_K   (14336 x 4096: n = 8 24.3 -> 16.4 on the 16-wave body)
 // Below that the multi-column GEMV is faster (one launch, no staging pass); taller matrices (output.weight) keep the GEMV /
 // the 128-token GEMM tiles.  The testing flags that force a GEMM body or the generic kernels keep their meaning.
 static bool use_gemm_sb(int Atype, long n, unsigned flags, long k, long m) {
@@ -397,7 +397,7 @@ static bool use_gemm_sb(int Atype, long n, unsigned flags, long k, long m) {
     const long tiles_per_cu = ((m + 31) / 32 + 255) / 256;
     if (tiles_per_cu <= 1)
         return n >= 5;
-    return tiles_per_cu <= 4 && Atype != LFAMD_TYPE_Q6_K && n >= 8 && n <= 24;
+    return tiles_per_cu <= 4 && Atype != LFAMD_TYPE_Q6_K && n >= 6 && n <= 24;
 }
 
 static bool use_gemv(int Atype, long n, unsigned flags, long k) {

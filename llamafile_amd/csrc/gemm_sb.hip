@@ -32,7 +32,7 @@ __global__ __launch_bounds__(64) void sb_prep_kernel(const uint8_t *__restrict__
                                                       _Float16 *__restrict__ Xh, float *__restrict__ d8T, _Float16 *__restrict__ Xm,
                                                       float *__restrict__ C, long m, long ldc) {
     const int blk = blockIdx.x, tok = blk / nb, b = blk - tok * nb, t = threadIdx.x;
-    { // the result: n rows of m floats, spread over the grid
+    if (C) { // the result: n rows of m floats, spread over the grid (null: the consumer stores whole rows itself)
         const long total = (long)n * m, stride = (long)gridDim.x * 64;
         for (long e = (long)blk * 64 + t; e < total; e += stride) {
             const long r = e / m;
@@ -504,6 +504,162 @@ __global__ __launch_bounds__(NW * 64) void gemm_sb_shallow_kernel(const uint8_t 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// UP TO 16 TOKENS, Q4_K / Q5_K: sixteen waves per work-group with the token fragments in LDS instead of registers.  The two bodies
+// above keep a unit's sixteen 16-byte token fragments in 64 VGPRs, which leaves two waves per SIMD and one unit of weights in
+// flight per wave (≈ 37 KB per CU: a third of what the HBM stream needs on matrices with several tiles per CU).  Here the
+// work-group copies its share of the staged codes (n rows x its super-blocks, 512 B each, 16-byte chunks XOR-swizzled by the
+// row) into LDS once, a wave reads a fragment right in front of the MFMA that consumes it, and 16 waves x one unit of weights
+// (rolling refill) are in flight.  KSPLIT = 1: a work-group owns whole rows of the result and stores them; KSPLIT = 2 (deep rows,
+// or more than 8 tokens: half the codes per work-group): two work-groups add into the zeroed result as above.
+template <int TYPE, int KSPLIT, int RL>
+__global__ __launch_bounds__(1024) void gemm_sb16_kernel(const uint8_t *__restrict__ A, long m, int nb, const _Float16 *__restrict__ Xh,
+                                                         const float *__restrict__ d8T, const _Float16 *__restrict__ Xm, int n,
+                                                         float *__restrict__ C, long ldc, int n_rt) {
+    constexpr bool Q5 = TYPE == LFAMD_TYPE_Q5_K;
+    constexpr int TILE = Q5 ? P5K_TILE : P4K_TILE, NW = 16;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[]; // codes [nbl][n][512 B], then red [NW][RL][64] f32
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int i = lane & 31, h = lane >> 5;
+    const int kh = KSPLIT == 2 ? (int)(blockIdx.x & 1) : 0, wg = KSPLIT == 2 ? (int)(blockIdx.x >> 1) : (int)blockIdx.x;
+    const int n_wg = KSPLIT == 2 ? (int)(gridDim.x >> 1) : (int)gridDim.x;
+    const int half = KSPLIT == 2 ? (nb + 1) >> 1 : nb;
+    const int b0 = kh ? half : 0, b1 = kh ? nb : half, nbl = b1 - b0;
+    float *red = (float *)(lds + (size_t)nbl * n * 512);
+    // ---- this work-group's codes: chunk c (16 B = K-step t, half h: c = 2 t + h) of row (bl, slot) at c ^ (slot & 15)
+    for (int e = threadIdx.x; e < nbl * n * 32; e += 1024) {
+        const int c = e & 31, row = e >> 5, bl = row / n, slot = row - bl * n;
+        const uint4 v = *(const uint4 *)(Xh + ((size_t)(b0 + bl) * SB_COLS + slot) * 256 + c * 8);
+        *(uint4 *)(lds + (size_t)row * 512 + ((c ^ (slot & 15)) << 4)) = v;
+    }
+    __syncthreads();
+    const int first = b0 + wave;
+    const int nmine = first < b1 ? (b1 - first + NW - 1) / NW : 0;
+    const int slot = i < n ? i : 0; // (token slots past n are never stored: they re-read slot 0)
+    const uint32_t frag0 = (uint32_t)(slot * 512), sw = (uint32_t)(slot & 15);
+    const uint32_t xmoff = (uint32_t)(slot * 16 + 8 * h);
+    const float16_t_ zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const uint32_t magic = opaque_magic();
+
+    u32x4_t qs[4], hd, qh0 = {0, 0, 0, 0};
+    half8_t xm;
+    float4_t_ d8[(RL + 3) / 4];
+    (void)qh0;
+    int rt_n = wg, b_n = first;
+    const uint8_t *tile_n = A;
+    const _Float16 *xm_n = Xm;
+    const float *d8_n = d8T;
+    auto point = [&]() {
+        tile_n = A + ((size_t)rt_n * nb + b_n) * TILE;
+        xm_n = Xm + (size_t)b_n * SB_COLS * 16 + xmoff;
+        d8_n = d8T + (size_t)b_n * SB_COLS + 4 * h;
+    };
+    auto advance = [&]() {
+        int b2 = b_n + NW, rt2 = rt_n;
+        if (b2 >= b1)
+            b2 = first, rt2 = rt_n + n_wg;
+        if (rt2 < n_rt)
+            b_n = b2, rt_n = rt2;
+        point();
+    };
+    auto ld_qs = [&](int g) { qs[g] = __builtin_nontemporal_load((const u32x4_t *)(tile_n + g * 1024 + lane * 16)); };
+    auto ld_hd = [&]() { hd = __builtin_nontemporal_load((const u32x4_t *)(tile_n + P4K_HDR + i * 16)); };
+    auto ld_d8 = [&]() {
+#pragma unroll
+        for (int r4 = 0; r4 < (RL + 3) / 4; r4++)
+            d8[r4] = *(const float4_t_ *)(d8_n + 8 * r4); // reg r of the tile is token slot 8 (r >> 2) + 4 h + (r & 3)
+    };
+    if (nmine > 0) {
+        point();
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+            ld_qs(g);
+        ld_hd();
+        if constexpr (Q5)
+            qh0 = __builtin_nontemporal_load((const u32x4_t *)(tile_n + P5K_QH + lane * 16));
+        xm = *(const half8_t *)xm_n;
+        ld_d8();
+    }
+    for (int rt = wg; rt < n_rt; rt += n_wg) {
+        float acc[RL];
+#pragma unroll
+        for (int r = 0; r < RL; r++)
+            acc[r] = 0.0f;
+        int b = first;
+        for (int j = 0; j < nmine; j++, b += NW) {
+            const uint8_t *fr = lds + (size_t)(b - b0) * n * 512 + frag0; // this lane's code row of super-block b
+            advance();
+            float16_t_ tmp = zero16;
+            const float d = h2f((uint16_t)(hd.x & 0xffff)), dmin = h2f((uint16_t)(hd.x >> 16));
+            uint32_t sc03, sc47, mn03, mn47;
+            q4k_scales_bytes(hd.y, hd.z, hd.w, sc03, sc47, mn03, mn47);
+            ld_hd();
+            uint32_t hq5[4] = {qh0.x, qh0.y, qh0.z, qh0.w};
+            (void)hq5;
+            if constexpr (Q5)
+                qh0 = __builtin_nontemporal_load((const u32x4_t *)(tile_n + P5K_QH + lane * 16));
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const uint32_t qw[4] = {qs[g].x, qs[g].y, qs[g].z, qs[g].w};
+                ld_qs(g);
+#pragma unroll
+                for (int dd = 0; dd < 4; dd++) {
+                    const int t = 4 * g + dd, jb = t >> 1;
+                    const q4_consts2 cp = q4_consts_pair(jb < 4 ? sc03 : sc47, (jb & 2) ? 2 : 0);
+                    const int hsel = jb & 1;
+                    const half2_t S = {cp.S[hsel], cp.S[hsel]}, O = {cp.O[hsel], cp.O[hsel]};
+                    const half2_t S16 = {cp.S16[hsel], cp.S16[hsel]}, O16 = {cp.O16[hsel], cp.O16[hsel]};
+                    half8_t wf;
+                    if constexpr (Q5)
+                        wf = dequant_q5(qw[dd], hq5[g] >> dd, S, O, S16, O16, magic);
+                    else
+                        wf = dequant_q4(qw[dd], S, O, S16, O16, magic);
+                    const half8_t f = *(const half8_t *)(fr + ((((uint32_t)(2 * t) + (uint32_t)h) ^ sw) << 4));
+                    tmp = __builtin_amdgcn_mfma_f32_32x32x16_f16(f, wf, tmp, 0, 0, 0);
+                }
+            }
+            frag_u wm;
+            const float mscale = h ? 64.0f : 1.0f;
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                const uint32_t mw = p < 2 ? mn03 : mn47;
+                const float m0 = (float)((mw >> (16 * (p & 1))) & 0xff), m1 = (float)((mw >> (16 * (p & 1) + 8)) & 0xff);
+                const half2_t v = {(_Float16)(m0 * mscale), (_Float16)(m1 * mscale)};
+                wm.p[p] = v;
+            }
+            const float16_t_ tm = __builtin_amdgcn_mfma_f32_32x32x16_f16(xm, wm.v, zero16, 0, 0, 0);
+            xm = *(const half8_t *)xm_n;
+#pragma unroll
+            for (int r = 0; r < RL; r++) {
+                const float u = fmaf(-dmin, tm[r], d * tmp[r]);
+                acc[r] = fmaf(u, d8[r >> 2][r & 3], acc[r]);
+            }
+            ld_d8();
+        }
+        // ---- the waves' partial tiles (the RL registers that hold token slots below 16), summed in wave order
+#pragma unroll
+        for (int r = 0; r < RL; r++)
+            red[(wave * RL + r) * 64 + lane] = acc[r];
+        __syncthreads();
+        for (int v = threadIdx.x; v < RL * 64; v += 1024) {
+            const int r = v >> 6, l = v & 63;
+            const int tok = 8 * (r >> 2) + 4 * (l >> 5) + (r & 3);
+            const long row = (long)rt * 32 + (l & 31);
+            if (tok < n && row < m) {
+                float s = 0.0f;
+#pragma unroll
+                for (int w = 0; w < NW; w++)
+                    s += red[(w * RL + r) * 64 + l];
+                if constexpr (KSPLIT == 2)
+                    unsafeAtomicAdd(C + (long)tok * ldc + row, s);
+                else
+                    C[(long)tok * ldc + row] = s;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 static int lfamd_num_cus() {
     static int cus = 0;
     if (!cus) {
@@ -539,21 +695,56 @@ hipError_t lfamd_launch_gemm_sb(int Atype, const void *A, long m, long k, int Bt
     _Float16 *Xm = (_Float16 *)(w8 + (size_t)nb * SB_COLS * 512 + (size_t)nb * SB_COLS * 4);
     const unsigned pg = (unsigned)(n * nb); // (token slots past n are never read: gemm_sb_kernel re-reads slot 0 for them)
     const bool mins = Atype != LFAMD_TYPE_Q6_K;
+    // up to 16 tokens of Q4_K / Q5_K: the 16-wave body with the codes in LDS; K halves when one work-group's codes would not fit
+    // beside the reduction buffer, and on deep rows (twice the work-groups for the 128 row tiles of a 4096-row matrix)
+    static const bool no16 = getenv("LFAMD_SB_NO16") != nullptr;
+    const int rl = n <= 8 ? 4 : 8;
+    const size_t red_bytes = 16 * (size_t)rl * 64 * 4;
+    int ksplit = 0;
+    // (measured, profiles/r03_small_batch16.txt: a gain only where a work-group walks several tiles — 14336 x 4096 n = 8: 20.5 -> 16.4 us;
+    //  with one tile per work-group the two-launch latency chain dominates and the 8-wave bodies are as fast)
+    if (mins && n <= 16 && !no16 && (m + 31) / 32 > lfamd_num_cus()) {
+        if ((size_t)nb * n * 512 + red_bytes <= 150 * 1024 && nb <= 16)
+            ksplit = 1;
+        else if ((size_t)((nb + 1) / 2) * n * 512 + red_bytes <= 150 * 1024)
+            ksplit = 2;
+    }
+    float *Czero = ksplit == 1 ? nullptr : C;
     if (Btype == LFAMD_TYPE_F32) {
         if (mins)
-            sb_prep_kernel<true, true><<<pg, 64, 0, s>>>((const uint8_t *)B, b_row_bytes, (int)n, nb, Xh, d8T, Xm, C, m, ldc);
+            sb_prep_kernel<true, true><<<pg, 64, 0, s>>>((const uint8_t *)B, b_row_bytes, (int)n, nb, Xh, d8T, Xm, Czero, m, ldc);
         else
-            sb_prep_kernel<true, false><<<pg, 64, 0, s>>>((const uint8_t *)B, b_row_bytes, (int)n, nb, Xh, d8T, Xm, C, m, ldc);
+            sb_prep_kernel<true, false><<<pg, 64, 0, s>>>((const uint8_t *)B, b_row_bytes, (int)n, nb, Xh, d8T, Xm, Czero, m, ldc);
     } else {
         if (mins)
-            sb_prep_kernel<false, true><<<pg, 64, 0, s>>>((const uint8_t *)B, b_row_bytes, (int)n, nb, Xh, d8T, Xm, C, m, ldc);
+            sb_prep_kernel<false, true><<<pg, 64, 0, s>>>((const uint8_t *)B, b_row_bytes, (int)n, nb, Xh, d8T, Xm, Czero, m, ldc);
         else
-            sb_prep_kernel<false, false><<<pg, 64, 0, s>>>((const uint8_t *)B, b_row_bytes, (int)n, nb, Xh, d8T, Xm, C, m, ldc);
+            sb_prep_kernel<false, false><<<pg, 64, 0, s>>>((const uint8_t *)B, b_row_bytes, (int)n, nb, Xh, d8T, Xm, Czero, m, ldc);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
         return e;
     const int n_rt = (int)((m + 31) / 32);
+    if (ksplit) {
+        const int cus = lfamd_num_cus();
+        const size_t smem = (size_t)(ksplit == 1 ? nb : (nb + 1) / 2) * n * 512 + red_bytes;
+        const unsigned g16 = (unsigned)ksplit * (unsigned)(n_rt < cus ? n_rt : cus);
+        auto go = [&](auto kernel) {
+            if (smem > 64 * 1024) {
+                hipError_t e2 = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+                if (e2 != hipSuccess)
+                    return e2;
+            }
+            kernel<<<g16, 1024, smem, s>>>((const uint8_t *)A, m, nb, Xh, d8T, Xm, (int)n, C, ldc, n_rt);
+            return hipGetLastError();
+        };
+        const bool q5 = Atype == LFAMD_TYPE_Q5_K;
+        if (ksplit == 1)
+            return rl == 4 ? (q5 ? go(gemm_sb16_kernel<LFAMD_TYPE_Q5_K, 1, 4>) : go(gemm_sb16_kernel<LFAMD_TYPE_Q4_K, 1, 4>))
+                           : (q5 ? go(gemm_sb16_kernel<LFAMD_TYPE_Q5_K, 1, 8>) : go(gemm_sb16_kernel<LFAMD_TYPE_Q4_K, 1, 8>));
+        return rl == 4 ? (q5 ? go(gemm_sb16_kernel<LFAMD_TYPE_Q5_K, 2, 4>) : go(gemm_sb16_kernel<LFAMD_TYPE_Q4_K, 2, 4>))
+                       : (q5 ? go(gemm_sb16_kernel<LFAMD_TYPE_Q5_K, 2, 8>) : go(gemm_sb16_kernel<LFAMD_TYPE_Q4_K, 2, 8>));
+    }
     const unsigned grid = 2u * (unsigned)(n_rt < lfamd_num_cus() ? n_rt : lfamd_num_cus()); // one 8-wave work-group per CU, K halves adjacent
     constexpr int NW = 8;
     static const bool no_shallow = getenv("LFAMD_SB_ROLLING") != nullptr; // development: A/B of the two bodies

@@ -39,10 +39,11 @@ def test_decode_variant_vs_oracle(gpu, oracle, t, m, k, n):
 # ---- small batches on the matrix cores (csrc/gemm_sb.hip): SB_MIN .. 32 tokens of Q4_K / Q5_K / Q6_K
 # (which body runs: api.hip use_gemm_sb — deep rows from 3 tokens; one row tile per CU from 5; up to four tiles per CU 8..24 tokens,
 #  where a work-group walks several tiles on two alternating weight register sets: m = 9000 -> 2 tiles, m = 20000 -> 3)
-SB_SHAPES = [(48, 768), (33, 256), (100, 4352), (4096, 4096), (24, 14336), (1000, 2048), (9000, 512), (20000, 256)]
+#  — on the 16-wave body with the codes in LDS up to 16 tokens; (8500, 8192): its K-halves form)
+SB_SHAPES = [(48, 768), (33, 256), (100, 4352), (4096, 4096), (24, 14336), (1000, 2048), (9000, 512), (20000, 256), (8500, 8192)]
 
 
-@pytest.mark.parametrize("n", [3, 5, 8, 17, 32])
+@pytest.mark.parametrize("n", [3, 5, 8, 12, 17, 32])
 @pytest.mark.parametrize("m,k", SB_SHAPES, ids=lambda v: str(v))
 @pytest.mark.parametrize("t", [T.Q4_K, T.Q5_K, T.Q6_K], ids=lambda t: T.NAMES[t])
 def test_small_batch_mfma_vs_oracle(gpu, oracle, t, m, k, n):
@@ -65,7 +66,7 @@ def test_small_batch_mfma_vs_oracle(gpu, oracle, t, m, k, n):
     ok, G = oracle.sgemm(t, np.ascontiguousarray(raw[rows]), bt, Bq, len(rows), n, k, nth=4)
     assert ok == 1
     tiles_per_cu = ((m + 31) // 32 + 255) // 256
-    small = (n >= 3) if k > 8192 else (n >= 5) if tiles_per_cu <= 1 else (tiles_per_cu <= 4 and t != T.Q6_K and 8 <= n <= 24)
+    small = (n >= 3) if k > 8192 else (n >= 5) if tiles_per_cu <= 1 else (tiles_per_cu <= 4 and t != T.Q6_K and 6 <= n <= 24)
     # (a batch of more than 8 tokens that the dispatcher keeps on the 128-token GEMM tiles runs the scaled-operand body: 1e-3)
     tol = 2e-6 if small or n <= 8 else 1e-3
     assert rel_err(c_q[:, rows], G) <= tol, (T.NAMES[t], m, k, n, rel_err(c_q[:, rows], G))
