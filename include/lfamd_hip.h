@@ -115,9 +115,13 @@ int lfamd_quantize_rows(int vec_dot_type, const float *d_x, long nrows, long col
  *      llamafile_sgemm boundary) or F32 (the GGML_OP_MUL_MAT boundary: quantised on the device,
  *      bit-identically to quantize_row_q8_K / q8_0 / q8_1, fused into the kernels); row stride
  *      b_row_bytes
- *   C: f32, ldc >= m
- * Policy (cf. ggml_cuda_mul_mat): n <= 8 -> wave-reduction GEMV kernels, else dequant-to-MFMA
- * GEMM.  `workspace` must hold lfamd_mul_mat_workspace() bytes (may be NULL if that is 0). */
+ *   C: f32, ldc >= m; ORDINARY device memory (hipMalloc / lfamd_malloc): the small-batch kernels add their two K halves
+ *      with hardware float atomics, which fine-grained or host-mapped memory does not honour
+ * Policy (cf. ggml_cuda_mul_mat): one token -> wave-reduction GEMV kernels; 2 .. 8 tokens -> multi-column GEMVs or, where
+ * faster, the small-batch MFMA kernel (also 9 .. 32 tokens on deep rows and matrices of at most 8192 rows: csrc/gemm_sb.hip);
+ * larger batches -> dequant-to-MFMA GEMM on 128-token tiles; plain F16 / BF16 weights and the f16 image of Q8_0 weights ->
+ * the vendor GEMM when lfamd_vendor_gemm_available().  `workspace` must hold lfamd_mul_mat_workspace() bytes (may be NULL
+ * if that is 0). */
 size_t lfamd_mul_mat_workspace(int Atype, long m, long k, long n);
 int lfamd_mul_mat(int Atype, const void *d_A_packed, long m, long k, int Btype, const void *d_B,
                   size_t b_row_bytes, long n, float *d_C, long ldc, void *d_workspace,
