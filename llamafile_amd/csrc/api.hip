@@ -35,6 +35,9 @@ hipError_t lfamd_blaslt_gemm(int dtype, const void *W, long ldw, const void *X, 
 hipError_t lfamd_launch_rows_to_16(int dtype, const void *X, size_t x_row_bytes, long n, long k, void *out, hipStream_t s);
 hipError_t lfamd_launch_q80_rows_to_f16(int Btype, const void *X, size_t x_row_bytes, long n, long k, void *out, hipStream_t s);
 hipError_t lfamd_launch_q80_image(const void *raw, size_t raw_row_bytes, long rows, long cols, void *out, hipStream_t s);
+size_t lfamd_pk_bytes(int type, long rows, long cols);
+hipError_t lfamd_launch_pk_pack(int type, const void *raw, size_t raw_row_bytes, long rows, long cols, void *out, hipStream_t s);
+hipError_t lfamd_launch_pk_expand(int type, const void *packed, long rows, long cols, void *out, hipStream_t s);
 size_t lfamd_gemm_sb_workspace(long k);
 bool lfamd_gemm_sb_ok(int Atype, long k, long n);
 hipError_t lfamd_launch_gemm_sb(int Atype, const void *A, long m, long k, int Btype, const void *B, size_t b_row_bytes, long n, float *C,
@@ -210,8 +213,8 @@ size_t lfamd_packed_size(int type, long rows, long cols) {
             return q80_p80_bytes(rows, cols) + (size_t)rows * (size_t)cols * 2;
         return q80_p80_bytes(rows, cols) + (cols % 256 == 0 ? lfamd_wprep8_bytes(rows, cols) : 0);
     case LFAMD_TYPE_Q2_K:
-    case LFAMD_TYPE_Q3_K: // PCK: the image the MFMA GEMM and the decode GEMV both read
-        return lfamd_wprep16_bytes(rows, cols);
+    case LFAMD_TYPE_Q3_K: // PK2 / PK3: compact images (84 / 116 bytes per 256 weights) the decode GEMV reads; batches expand them
+        return lfamd_pk_bytes(type, rows, cols); // into the canonical PCK image in the workspace, per call
     case LFAMD_TYPE_IQ4_XS: // PC8
         return lfamd_wprep8_bytes(rows, cols);
     case LFAMD_TYPE_Q4_1:
@@ -261,7 +264,7 @@ int lfamd_pack_weights(int type, long rows, long cols, const void *d_raw, size_t
         break;
     case LFAMD_TYPE_Q2_K:
     case LFAMD_TYPE_Q3_K:
-        HIPCHK(lfamd_launch_wprep16(type, d_raw, raw_row_bytes, rows, cols, d_packed, s), "pack_pck");
+        HIPCHK(lfamd_launch_pk_pack(type, d_raw, raw_row_bytes, rows, cols, d_packed, s), "pack_pk");
         break;
     case LFAMD_TYPE_IQ4_XS:
         HIPCHK(lfamd_launch_wprep8(type, d_raw, raw_row_bytes, rows, cols, d_packed, s), "pack_pc8");
@@ -432,8 +435,8 @@ static size_t mul_mat_workspace_base(int Atype, long m, long k, long n) {
         const size_t lt = lfamd_blaslt_ok() ? gemm_lt_ws(k, n) : 0;
         return own > lt ? own : lt;
     }
-    if (use_gemm_canon(Atype, n, 0))
-        return gemm_act_ws(k, n);
+    if (use_gemm_canon(Atype, n, 0)) // (+ the canonical image of a Q2_K / Q3_K matrix, rebuilt from the compact one per call)
+        return gemm_act_ws(k, n) + (Atype == LFAMD_TYPE_IQ4_XS ? 0 : align_up(lfamd_wprep16_bytes(m, k), 256));
     if (use_gemm_canon32(Atype, n, 0, k)) { // Xh, d8T [nb*8][n_pad], sT [nb*8][n_pad], image
         size_t n_pad = align_up((size_t)n, 128), nb = (size_t)(k / 256);
         return align_up(n_pad * (size_t)k * 2, 256) + 2 * align_up(nb * 8 * n_pad * 4, 256);
@@ -580,7 +583,13 @@ int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const v
             HIPCHK(lfamd_launch_prep_f32(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, mins16, nullptr, s), "prep_f32");
         else
             HIPCHK(lfamd_launch_prep_q8k(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, mins16, nullptr, s), "prep_q8k");
-        HIPCHK(lfamd_launch_gemm_wide(Atype, d_A, m, k, Xh, d8T, Xm, n, (long)n_pad, d_C, ldc, plain, nullptr, 0, s), "gemm_wide");
+        const void *img = d_A;
+        if (Atype != LFAMD_TYPE_IQ4_XS) { // Q2_K / Q3_K: the resident image is the compact one; the MFMA body reads the canonical form
+            void *pck = ws + gemm_act_ws(k, n);
+            HIPCHK(lfamd_launch_pk_expand(Atype, d_A, m, k, pck, s), "pk_expand");
+            img = pck;
+        }
+        HIPCHK(lfamd_launch_gemm_wide(Atype, img, m, k, Xh, d8T, Xm, n, (long)n_pad, d_C, ldc, plain, nullptr, 0, s), "gemm_wide");
         return LFAMD_OK;
     }
     if (use_gemm_q80_lt(Atype, n, flags, k)) {

@@ -581,6 +581,66 @@ struct pck_traits {
     }
 };
 
+// Q2_K / Q3_K on the RESIDENT compact images (lfamd_device.h: PK2 / PK3): half the bytes of the canonical image per row; two
+// K-steps come out of one code dword with an AND and a shift-AND, Q3_K's third bit with a shift, an AND and a shift-OR.
+// Then the arithmetic of pck_traits above.
+template <int TYPE>
+struct pk_traits {
+    static constexpr int ACT = LFAMD_TYPE_Q8_K;
+    static constexpr bool Q3 = TYPE == LFAMD_TYPE_Q3_K;
+    static constexpr int TILE = Q3 ? PK3_TILE : PK2_TILE;
+    static constexpr bool MINS = !Q3;
+    static constexpr int OFF = Q3 ? 4 : 0;
+    struct chunk {
+        uint4 q[GEMV_CH_MAX];
+        uint2 hb[GEMV_CH_MAX], sc[GEMV_CH_MAX];
+        uint32_t dd[GEMV_CH_MAX];
+    };
+    __device__ static inline void load(chunk &ch, int s, lfamd_rsrc r, uint32_t off, int gsel, int slot, int hrow) {
+        ch.q[s] = buf_ld16_nt(r, off + gsel * 1024 + slot * 16);
+        if constexpr (Q3)
+            ch.hb[s] = buf_ld8(r, off + PK3_HB + gsel * 512 + slot * 8);
+        ch.sc[s] = buf_ld8(r, off + (Q3 ? PK3_SC : PK2_SC) + hrow * 16 + gsel * 8); // scale bytes of K-steps 8*gsel..+7
+        ch.dd[s] = __builtin_amdgcn_raw_buffer_load_b32(r, off + (Q3 ? PK3_D : PK2_D) + hrow * 4, 0, 0); // {d, dmin}
+    }
+    __device__ static inline float dot(const chunk &ch, int s, const uint8_t *xb, int gsel, int h) {
+        const uint4 qc = ch.q[s];
+        const uint2 scb = ch.sc[s];
+        const uint32_t dw = ch.dd[s];
+        const float d = h2f((uint16_t)(dw & 0xffff));
+        const uint32_t cw[4] = {qc.x, qc.y, qc.z, qc.w};
+        const uint4 *yq = (const uint4 *)(xb + 128 * gsel + 64 * h);
+        const uint4 ya = yq[0], yb = yq[1], yc = yq[2], yd = yq[3];
+        const uint32_t yw[16] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w,
+                                 yc.x, yc.y, yc.z, yc.w, yd.x, yd.y, yd.z, yd.w};
+        const uint4 hbw = *(const uint4 *)(xb + XBLK_HB + 32 * gsel + 16 * h);
+        const uint32_t hbv[4] = {hbw.x, hbw.y, hbw.z, hbw.w};
+        int sumi = 0, summ = 0;
+#pragma unroll
+        for (int t8 = 0; t8 < 8; t8++) { // t8 = 4 gi + dd
+            uint32_t x = ((t8 & 1) ? (cw[t8 >> 1] >> 2) : cw[t8 >> 1]) & 0x33333333u;
+            if constexpr (Q3) {
+                const uint32_t H = (t8 < 4 ? ch.hb[s].x : ch.hb[s].y) >> (t8 & 3);
+                x |= (H & 0x11111111u) << 2;
+            }
+            int isum = sdot4(x & 0x0F0F0F0F, yw[2 * t8], 0);
+            isum = sdot4((x >> 4) & 0x0F0F0F0F, yw[2 * t8 + 1], isum);
+            const int hs = (int)(int16_t)((hbv[t8 >> 1] >> (16 * (t8 & 1))) & 0xffff);
+            const uint32_t sbyte = ((t8 < 4 ? scb.x : scb.y) >> (8 * (t8 & 3))) & 0xff;
+            if constexpr (Q3) {
+                sumi += (int)(int8_t)sbyte * (isum - OFF * hs);
+            } else {
+                sumi += (int)(sbyte & 15) * isum;
+                summ += (int)(sbyte >> 4) * hs;
+            }
+        }
+        const float d8 = *(const float *)(xb + XBLK_D);
+        if constexpr (MINS)
+            return fmaf(d * d8, (float)sumi, -(h2f((uint16_t)(dw >> 16)) * d8) * (float)summ);
+        return (d * d8) * (float)sumi;
+    }
+};
+
 // IQ4_XS on the PC8 image: the codebook value + 128 as one byte per weight (DequantizerIQ4XS looks the same values up
 // with a shuffle, iqk_mul_mat.inc:601-628), eight int8 sub-block scales (ls - 32) and d per row.  The image keeps the
 // MFMA K-step order (bytes k0..k3 | k4..k7 of a lane's half K-step); the staged activation codes are ordered
@@ -1845,12 +1905,12 @@ static hipError_t launch_q6k(const gemv_mats &mats, int n_ht, long k, const void
 
 template <int NC, int BT>
 static hipError_t launch_q2k(const gemv_mats &mats, int n_ht, long k, const void *B, size_t brb, long col0, hipStream_t s) {
-    return launch_kq_pick<pck_traits<LFAMD_TYPE_Q2_K>, NC, BT>(mats, n_ht, k, B, brb, col0, s);
+    return launch_kq_pick<pk_traits<LFAMD_TYPE_Q2_K>, NC, BT>(mats, n_ht, k, B, brb, col0, s);
 }
 
 template <int NC, int BT>
 static hipError_t launch_q3k(const gemv_mats &mats, int n_ht, long k, const void *B, size_t brb, long col0, hipStream_t s) {
-    return launch_kq_pick<pck_traits<LFAMD_TYPE_Q3_K>, NC, BT>(mats, n_ht, k, B, brb, col0, s);
+    return launch_kq_pick<pk_traits<LFAMD_TYPE_Q3_K>, NC, BT>(mats, n_ht, k, B, brb, col0, s);
 }
 
 template <int NC, int BT>

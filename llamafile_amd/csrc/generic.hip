@@ -439,6 +439,135 @@ extern "C" hipError_t lfamd_launch_wprep8(int type, const void *raw, size_t raw_
     return hipGetLastError();
 }
 
+// Resident compact images of Q2_K / Q3_K (lfamd_device.h: PK2 / PK3): RAW blocks -> compact tiles.  One thread per output dword.
+template <int TYPE>
+__global__ void pk_pack_kernel(const uint8_t *__restrict__ raw, size_t raw_row_bytes, long rows, int nb, uint8_t *__restrict__ out,
+                               long n_tiles) {
+    constexpr bool Q3 = TYPE == LFAMD_TYPE_Q3_K;
+    constexpr int OFF = Q3 ? 4 : 0, TILE = Q3 ? PK3_TILE : PK2_TILE, NDW = TILE / 4;
+    constexpr int SC0 = (Q3 ? PK3_SC : PK2_SC) / 4, D0 = (Q3 ? PK3_D : PK2_D) / 4;
+    constexpr size_t bs = Q3 ? sizeof(lfamd_block_q3_K) : sizeof(lfamd_block_q2_K);
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long tile = tid / NDW;
+    const int w = (int)(tid % NDW);
+    if (tile >= n_tiles)
+        return;
+    const long rt = tile / nb;
+    const int b = (int)(tile % nb);
+    uint32_t *dst = (uint32_t *)(out + tile * TILE);
+    int q[16], sc, mn;
+    float d, dmin;
+    uint32_t v = 0;
+    if (w < 512) { // codes, low two bits: K-steps 8 gsel + 2 u (bits 0-1 of a nibble) and + 1 (bits 2-3)
+        const int gsel = w >> 8, lane = (w >> 2) & 63, u = w & 3;
+        const int i = lane & 31, h = lane >> 5;
+        const long row = rt * 32 + i;
+        if (row < rows)
+            for (int e = 0; e < 2; e++) {
+                unpack16<TYPE>(raw + row * raw_row_bytes + (size_t)b * bs, 8 * gsel + 2 * u + e, q, sc, mn, d, dmin);
+                for (int j = 0; j < 8; j++)
+                    v |= (uint32_t)((q[8 * h + j] + OFF) & 3) << (4 * NIBPOS(j) + 2 * e);
+            }
+    } else if (Q3 && w < 768) { // third bits: dword x of [gsel][lane] = K-steps 8 gsel + 4 x + s at bit 4 NIBPOS(j) + s
+        const int s8 = w - 512, gsel = s8 >> 7, lane = (s8 >> 1) & 63, x = s8 & 1;
+        const int i = lane & 31, h = lane >> 5;
+        const long row = rt * 32 + i;
+        if (row < rows)
+            for (int e = 0; e < 4; e++) {
+                unpack16<TYPE>(raw + row * raw_row_bytes + (size_t)b * bs, 8 * gsel + 4 * x + e, q, sc, mn, d, dmin);
+                for (int j = 0; j < 8; j++)
+                    v |= (uint32_t)(((q[8 * h + j] + OFF) >> 2) & 1) << (4 * NIBPOS(j) + e);
+            }
+    } else if (w >= SC0 && w < SC0 + 128) { // 16 scale bytes per row
+        const int s4 = w - SC0, i = s4 >> 2, u = s4 & 3;
+        const long row = rt * 32 + i;
+        if (row < rows)
+            for (int e = 0; e < 4; e++) {
+                unpack16<TYPE>(raw + row * raw_row_bytes + (size_t)b * bs, 4 * u + e, q, sc, mn, d, dmin);
+                v |= (uint32_t)((Q3 ? sc : (sc | (mn << 4))) & 0xff) << (8 * e);
+            }
+    } else if (w >= D0) {
+        const int i = w - D0;
+        const long row = rt * 32 + i;
+        if (row < rows) {
+            unpack16<TYPE>(raw + row * raw_row_bytes + (size_t)b * bs, 0, q, sc, mn, d, dmin);
+            v = (uint32_t)f2h_bits(d) | ((uint32_t)f2h_bits(dmin) << 16);
+        }
+    }
+    dst[w] = v;
+}
+
+// Batches: the compact image -> the canonical PCK image the MFMA body reads, into the caller's workspace (per call).
+template <int TYPE>
+__global__ void pk_expand_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, long n_tiles) {
+    constexpr bool Q3 = TYPE == LFAMD_TYPE_Q3_K;
+    constexpr int TILE = Q3 ? PK3_TILE : PK2_TILE, SC0 = Q3 ? PK3_SC : PK2_SC, D0 = Q3 ? PK3_D : PK2_D;
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long tile = tid / 1312; // (wprep16_kernel's dword order)
+    const int w = (int)(tid % 1312);
+    if (tile >= n_tiles)
+        return;
+    const uint8_t *src = in + tile * TILE;
+    uint32_t *dst = (uint32_t *)(out + tile * PCK_TILE);
+    uint32_t v;
+    if (w < 1024) {
+        const int g = w >> 8, lane = (w >> 2) & 63, dd = w & 3;
+        const int t = 4 * g + dd, gsel = t >> 3, t8 = t & 7;
+        const uint32_t c = *(const uint32_t *)(src + gsel * 1024 + lane * 16 + (t8 >> 1) * 4);
+        v = ((t8 & 1) ? (c >> 2) : c) & 0x33333333u;
+        if constexpr (Q3) {
+            const uint32_t hb = *(const uint32_t *)(src + PK3_HB + gsel * 512 + lane * 8 + (t8 >> 2) * 4);
+            v |= ((hb >> (t8 & 3)) & 0x11111111u) << 2;
+        }
+    } else if (w < 1280) {
+        const int s4 = w - 1024, mins = s4 >= 128;
+        const int i = (s4 & 127) >> 2, u = s4 & 3;
+        const uint32_t sb = *(const uint32_t *)(src + SC0 + i * 16 + u * 4);
+        v = Q3 ? (mins ? 0u : sb) : (mins ? (sb >> 4) & 0x0F0F0F0Fu : sb & 0x0F0F0F0Fu);
+    } else {
+        v = *(const uint32_t *)(src + D0 + (w - 1280) * 4);
+    }
+    dst[w] = v;
+}
+
+extern "C" size_t lfamd_pk_bytes(int type, long rows, long cols) {
+    return (size_t)((rows + 31) / 32) * (size_t)(cols / 256) * (type == LFAMD_TYPE_Q3_K ? PK3_TILE : PK2_TILE);
+}
+
+extern "C" hipError_t lfamd_launch_pk_pack(int type, const void *raw, size_t raw_row_bytes, long rows, long cols, void *out, hipStream_t s) {
+    const int nb = (int)(cols / 256);
+    const long n_tiles = ((rows + 31) / 32) * nb;
+    if (n_tiles == 0)
+        return hipSuccess;
+    if (type == LFAMD_TYPE_Q2_K) {
+        const long threads = n_tiles * (PK2_TILE / 4);
+        pk_pack_kernel<LFAMD_TYPE_Q2_K><<<(unsigned)((threads + 255) / 256), 256, 0, s>>>((const uint8_t *)raw, raw_row_bytes, rows, nb,
+                                                                                         (uint8_t *)out, n_tiles);
+    } else if (type == LFAMD_TYPE_Q3_K) {
+        const long threads = n_tiles * (PK3_TILE / 4);
+        pk_pack_kernel<LFAMD_TYPE_Q3_K><<<(unsigned)((threads + 255) / 256), 256, 0, s>>>((const uint8_t *)raw, raw_row_bytes, rows, nb,
+                                                                                         (uint8_t *)out, n_tiles);
+    } else {
+        return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+extern "C" hipError_t lfamd_launch_pk_expand(int type, const void *packed, long rows, long cols, void *out, hipStream_t s) {
+    const long n_tiles = ((rows + 31) / 32) * (cols / 256);
+    if (n_tiles == 0)
+        return hipSuccess;
+    const long threads = n_tiles * 1312;
+    const unsigned grid = (unsigned)((threads + 255) / 256);
+    if (type == LFAMD_TYPE_Q2_K)
+        pk_expand_kernel<LFAMD_TYPE_Q2_K><<<grid, 256, 0, s>>>((const uint8_t *)packed, (uint8_t *)out, n_tiles);
+    else if (type == LFAMD_TYPE_Q3_K)
+        pk_expand_kernel<LFAMD_TYPE_Q3_K><<<grid, 256, 0, s>>>((const uint8_t *)packed, (uint8_t *)out, n_tiles);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
 extern "C" size_t lfamd_wprep16_bytes(long rows, long cols) {
     return (size_t)((rows + 31) / 32) * (size_t)(cols / 256) * PCK_TILE;
 }

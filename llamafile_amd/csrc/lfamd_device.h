@@ -32,6 +32,18 @@
 #define P5K_QH 4608
 // PCK: canonical per-call image the GEMM builds in its workspace for K-quants without a resident packed layout
 // (Q2_K, Q3_K): P4K-form nibble image of (q - qmin), then per row 16 int8 sub-block scales, 16 uint8 mins, {d, dmin}
+// PK2 / PK3: the RESIDENT images of Q2_K / Q3_K (file size: 84 / 116 bytes per 256 weights; the PCK image above is built from
+// them per batch call).  qs: the PCK nibble lattice of TWO K-steps folded into one dword — codes are 2 bits wide, so K-step 2u keeps
+// bits 0-1 of every nibble and K-step 2u+1 takes bits 2-3: dword u of [gsel][lane] = A | (B << 2), 2 x 64 lanes x 16 B.  Q3_K's
+// third bit: dword x of [gsel][lane] holds K-steps 8 gsel + 4 x + s at bit 4 NIBPOS(j) + s (cf. Q5_K's fifth bits), 2 x 64 x 8 B.
+// Then per row 16 scale bytes (Q2_K: the block's sc | mn << 4 bytes as they are; Q3_K: 16 int8 = 6-bit scale - 32) and {d, dmin}.
+#define PK2_TILE 2688
+#define PK2_SC 2048
+#define PK2_D 2560
+#define PK3_TILE 3712
+#define PK3_HB 2048
+#define PK3_SC 3072
+#define PK3_D 3584
 #define PCK_TILE 5248
 #define PCK_SC 4096
 #define PCK_MN 4608

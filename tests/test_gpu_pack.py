@@ -43,3 +43,30 @@ def test_pack_honours_raw_row_stride(gpu):
     a = gpu.upload_weights(T.Q4_K, raw, rows, cols).data.cpu().numpy()
     b = gpu.upload_weights(T.Q4_K, padded, rows, cols).data.cpu().numpy()
     assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("t", [T.Q2_K, T.Q3_K], ids=lambda t: T.NAMES[t])
+@pytest.mark.parametrize("shape", [(64, 512), (37, 1024), (7, 256)], ids=str)
+def test_compact_images_expand_to_the_canonical_image(gpu, t, shape):
+    """Q2_K / Q3_K are resident as compact images (two K-steps per code dword, Q3_K's third bit on its own lattice: PK2 / PK3 in
+    lfamd_device.h); batches expand them per call into the canonical PCK image the MFMA body reads.  pack + expand must give
+    exactly the image the canonical builder makes from the GGUF rows (what was resident until round 2)."""
+    import ctypes as C
+    import torch
+    from llamafile_amd import _hip
+    rows, cols = shape
+    raw = synth.random_weights(t, rows, cols, seed=17)
+    W = gpu.upload_weights(t, raw, rows, cols)
+    L = C.CDLL(_hip.HIP_SO)
+    L.lfamd_wprep16_bytes.restype = C.c_size_t
+    nbytes = L.lfamd_wprep16_bytes(C.c_long(rows), C.c_long(cols))
+    assert W.data.numel() < 0.75 * nbytes  # (the point of the exercise)
+    rawd = torch.from_numpy(raw).cuda()
+    want = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+    got = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert L.lfamd_launch_wprep16(t, C.c_void_p(rawd.data_ptr()), C.c_size_t(raw.shape[1]), C.c_long(rows), C.c_long(cols),
+                                  C.c_void_p(want.data_ptr()), st) == 0
+    assert L.lfamd_launch_pk_expand(t, C.c_void_p(W.data.data_ptr()), C.c_long(rows), C.c_long(cols), C.c_void_p(got.data_ptr()), st) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
