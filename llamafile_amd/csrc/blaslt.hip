@@ -188,6 +188,17 @@ hipError_t lfamd_blaslt_gemm(int dtype, const void *W, long ldw, const void *X, 
         ws_bytes = 0;
     std::lock_guard<std::mutex> lk(g_mu);
     const auto key = std::make_tuple(dtype, m, n, k, ldw, ldx, ldc * 2 + (ws_bytes ? 1 : 0));
+    if (g_plans.size() >= 1024 && !g_plans.count(key)) { // (a KV cache as the A operand grows by a row per token: bound the cache)
+        for (auto &kv : g_plans) {
+            plan &q = kv.second;
+            if (q.desc)
+                a.DescDestroy(q.desc);
+            for (hipblasLtMatrixLayout_t l : {q.a, q.b, q.c})
+                if (l)
+                    a.LayoutDestroy(l);
+        }
+        g_plans.clear();
+    }
     plan &p = g_plans[key];
     if (!p.desc) { // first use of this shape: descriptors + the heuristic's first choice
         const hipDataType dt = dtype == LFAMD_TYPE_BF16 ? HIP_R_16BF : HIP_R_16F;
