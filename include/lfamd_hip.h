@@ -68,6 +68,11 @@ int lfamd_free(void *dptr);
 int lfamd_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream);
 int lfamd_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream);
 int lfamd_memset(void *dst, int value, size_t bytes, void *stream);
+/* Pinned host memory mapped into the device's address space (the same pointer is valid on both sides): a decode-sized
+ * lfamd_mul_mat may take its activation row from it and write its result to it directly (no float atomics on it: n = 1 or
+ * n = 2 only, see lfamd_mul_mat).  What llamafile_sgemm's host-pointer path uses for single-column calls. */
+int lfamd_host_alloc(void **p, size_t bytes);
+int lfamd_host_free(void *p);
 int lfamd_stream_sync(void *stream);
 
 /* ---- weights ----------------------------------------------------------------------------

@@ -154,6 +154,18 @@ int lfamd_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream) {
     HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream), "hipMemcpyAsync d2h");
     return LFAMD_OK;
 }
+// Pinned, device-mapped host memory (the address is valid on the device too): lets a decode-sized call read its activations and
+// write its result in place over PCIe instead of through two DMA transfers (sgemm_host.cpp, n = 1).
+int lfamd_host_alloc(void **p, size_t bytes) {
+    (void)hipGetLastError();
+    HIPCHK(hipHostMalloc(p, bytes, hipHostMallocMapped | hipHostMallocPortable), "hipHostMalloc");
+    return LFAMD_OK;
+}
+int lfamd_host_free(void *p) {
+    if (p)
+        HIPCHK(hipHostFree(p), "hipHostFree");
+    return LFAMD_OK;
+}
 int lfamd_memset(void *dst, int value, size_t bytes, void *stream) {
     HIPCHK(hipMemsetAsync(dst, value, bytes, (hipStream_t)stream), "hipMemsetAsync");
     return LFAMD_OK;

@@ -41,6 +41,8 @@ struct HipApi {
     decltype(&lfamd_memcpy_h2d) h2d;
     decltype(&lfamd_memcpy_d2h) d2h;
     decltype(&lfamd_stream_sync) sync;
+    decltype(&lfamd_host_alloc) host_alloc;
+    decltype(&lfamd_host_free) host_free;
     decltype(&lfamd_packed_size) packed_size;
     decltype(&lfamd_pack_weights) pack_weights;
     decltype(&lfamd_scaled_gemm_ok) scaled_ok;
@@ -150,7 +152,8 @@ void load_module() {
               import(dso, "lfamd_device_count", a.device_count, err) && import(dso, "lfamd_init", a.init, err) &&
               import(dso, "lfamd_malloc", a.malloc_, err) && import(dso, "lfamd_free", a.free_, err) &&
               import(dso, "lfamd_memcpy_h2d", a.h2d, err) && import(dso, "lfamd_memcpy_d2h", a.d2h, err) &&
-              import(dso, "lfamd_stream_sync", a.sync, err) && import(dso, "lfamd_packed_size", a.packed_size, err) &&
+              import(dso, "lfamd_stream_sync", a.sync, err) && import(dso, "lfamd_host_alloc", a.host_alloc, err) &&
+              import(dso, "lfamd_host_free", a.host_free, err) && import(dso, "lfamd_packed_size", a.packed_size, err) &&
               import(dso, "lfamd_pack_weights", a.pack_weights, err) &&
               import(dso, "lfamd_scaled_gemm_ok", a.scaled_ok, err) &&
               import(dso, "lfamd_quantize_rows", a.quantize_rows, err) &&
@@ -194,6 +197,13 @@ bool available() {
     return g.ok;
 }
 
+// pinned + device-mapped staging (single-column calls: the kernel reads / writes it in place over PCIe)
+struct HostBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+bool reserve_host(HostBuf &b, size_t bytes);
+
 bool reserve(DevBuf &b, size_t bytes) {
     if (bytes <= b.cap)
         return true;
@@ -203,6 +213,21 @@ bool reserve(DevBuf &b, size_t bytes) {
     b.cap = 0;
     size_t want = bytes + bytes / 4 + 4096;
     if (g.api.malloc_(&b.p, want) != LFAMD_OK)
+        return false;
+    b.cap = want;
+    return true;
+}
+
+HostBuf g_hb, g_hc;
+bool reserve_host(HostBuf &b, size_t bytes) {
+    if (bytes <= b.cap)
+        return true;
+    if (b.p)
+        g.api.host_free(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+    const size_t want = bytes + bytes / 4 + 4096;
+    if (g.api.host_alloc(&b.p, want) != LFAMD_OK)
         return false;
     b.cap = want;
     return true;
@@ -426,7 +451,23 @@ bool run_mul_mat(int Atype, const void *A, long m, long kelems, size_t a_row_byt
     // C spans (n-1)*ldc + m floats (the last column is not padded to ldc)
     size_t bbytes = (size_t)n * b_row_bytes, cbytes = ((size_t)(n - 1) * (size_t)ldc + (size_t)m) * 4;
     size_t wsb = g.api.mul_mat_workspace(Atype, m, kelems, n);
-    if (!reserve(g.b, bbytes) || !reserve(g.c, cbytes) || !reserve(g.ws, wsb))
+    if (!reserve(g.ws, wsb))
+        return false;
+    // One column (decode): no DMA.  The activation row goes into a pinned, device-mapped buffer with a CPU copy (16 KiB), the
+    // GEMV reads it and writes the result row in place over PCIe, one synchronisation, a CPU copy out: two transfer set-ups
+    // (~10 us each) less per call.  (Batches keep the DMA path: their kernels may add into C with float atomics.)
+    static const bool zero_copy = getenv("LFAMD_HOST_NO_ZERO_COPY") == nullptr;
+    if (n == 1 && zero_copy && reserve_host(g_hb, bbytes) && reserve_host(g_hc, cbytes)) {
+        memcpy(g_hb.p, B, bbytes);
+        if (g.api.mul_mat(Atype, w.d_packed, m, kelems, Btype, g_hb.p, b_row_bytes, n, (float *)g_hc.p, ldc, g.ws.p, g.ws.cap,
+                          flags_now() | (w.exact_only ? LFAMD_FLAG_PRECISE : 0u), nullptr) != LFAMD_OK)
+            return false;
+        if (g.api.sync(nullptr) != LFAMD_OK)
+            return false;
+        memcpy(C, g_hc.p, cbytes); // (n = 1: exactly the m floats of the column)
+        return true;
+    }
+    if (!reserve(g.b, bbytes) || !reserve(g.c, cbytes))
         return false;
     if (g.api.h2d(g.b.p, B, bbytes, nullptr) != LFAMD_OK)
         return false;
