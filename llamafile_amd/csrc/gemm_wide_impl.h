@@ -85,19 +85,10 @@ __device__ static inline const uint8_t *uniform_ptr(const void *p) {
     return (const uint8_t *)(uintptr_t)(((uint64_t)hi << 32) | lo);
 }
 
-// The same for the LEAN load forms of gemm_ks.hip / gemm_kr.hip, whose asm carries no wait states of its own: a VALU write
-// of an SGPR (v_readfirstlane) needs five wait states before a vector-memory instruction reads that SGPR, and hipcc's hazard
-// recogniser does not see inside an asm statement — with the plain builtin it put the two v_readfirstlane directly in front
-// of `global_load_dwordx4 ..., s[44:45]` (stale base address: a memory fault on some shapes).  Here the reads and the wait
-// states are ONE asm statement; everything derived from the result is scalar arithmetic.
-__device__ static inline const uint8_t *uniform_ptr_vmem(const void *p) {
-    const uint64_t v = (uint64_t)(uintptr_t)p;
-    uint32_t lo, hi;
-    asm volatile("v_readfirstlane_b32 %0, %2\n\tv_readfirstlane_b32 %1, %3\n\ts_nop 4"
-                 : "=s"(lo), "=s"(hi)
-                 : "v"((uint32_t)v), "v"((uint32_t)(v >> 32)));
-    return (const uint8_t *)(uintptr_t)(((uint64_t)hi << 32) | lo);
-}
+// (gemm_ks.hip / gemm_kr.hip use LEAN load forms whose asm carries no wait states of its own: a VALU write of an SGPR —
+// v_readfirstlane — needs five wait states before a vector-memory instruction reads that SGPR, and hipcc's hazard recogniser
+// does not see inside an asm statement.  They follow uniform_ptr() with an `s_nop 4` fence that consumes the pointers;
+// tools/isa_hazards.py checks the rule on the final ISA.)
 
 // LDS fragment read hipcc neither counts nor moves: the K loop below keeps the next K-step's four fragments in
 // flight under the current step's MFMAs and waits with a counted lgkmcnt (left to itself hipcc reuses ONE
