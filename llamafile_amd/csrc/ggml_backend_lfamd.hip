@@ -211,6 +211,51 @@ const packed *get_packed(backend_ctx *ctx, const struct ggml_tensor *a, int64_t 
     return tmp;
 }
 
+// The struct layouts this module reads (include/ggml_backend_lfamd.h, marked RECALLED: llama.cpp is not vendored in the reference
+// tree) are cross-checked against the HOST's own accessors on every tensor an operator touches: type / ne / nb of
+// `struct ggml_tensor` through ggml_nbytes, ggml_nelements, ggml_element_size and ggml_is_contiguous (each a function of exactly
+// those fields), the buffer's `usage` field through ggml_backend_buffer_get_usage.  A host built against other layouts makes
+// them disagree: supports_op then answers no for everything (llamafile's CPU fallback) instead of computing on garbage.
+bool layout_agrees(const struct ggml_tensor *t) {
+    if (!t)
+        return true;
+    if (t->type < 0 || t->type >= 64 || lfamd_blck_size(t->type) <= 0)
+        return false;
+    const int64_t ne = t->ne[0] * t->ne[1] * t->ne[2] * t->ne[3];
+    if (g_api->ggml_nelements(t) != ne || g_api->ggml_element_size(t) != (size_t)lfamd_type_size(t->type))
+        return false;
+    size_t nbytes; // ggml_nbytes: the span the strides cover
+    const int64_t blck = lfamd_blck_size(t->type);
+    if (blck == 1) {
+        nbytes = lfamd_type_size(t->type);
+        for (int i = 0; i < 4; i++)
+            nbytes += (size_t)(t->ne[i] - 1) * t->nb[i];
+    } else {
+        nbytes = (size_t)t->ne[0] * t->nb[0] / (size_t)blck;
+        for (int i = 1; i < 4; i++)
+            nbytes += (size_t)(t->ne[i] - 1) * t->nb[i];
+    }
+    if (ne > 0 && g_api->ggml_nbytes(t) != nbytes)
+        return false;
+    const bool contiguous = t->nb[0] == (size_t)lfamd_type_size(t->type) && t->nb[1] == t->nb[0] * (size_t)t->ne[0] / (size_t)blck &&
+                            t->nb[2] == t->nb[1] * (size_t)t->ne[1] && t->nb[3] == t->nb[2] * (size_t)t->ne[2];
+    if (g_api->ggml_is_contiguous(t) != contiguous)
+        return false;
+    if (t->buffer && g_api->ggml_backend_buffer_get_usage(t->buffer) != t->buffer->usage)
+        return false;
+    return true;
+}
+bool op_layout_agrees(const struct ggml_tensor *op) {
+    static bool warned = false;
+    const bool ok = layout_agrees(op) && layout_agrees(op->src[0]) && layout_agrees(op->src[1]) && layout_agrees(op->src[2]);
+    if (!ok && !warned) {
+        warned = true;
+        logf("%s: the host's ggml structs do not match this module's layouts (%s): declining every operator\n", "ggml_backend_lfamd",
+             "include/ggml_backend_lfamd.h");
+    }
+    return ok;
+}
+
 bool mul_mat_supported(const struct ggml_tensor *op) {
     const struct ggml_tensor *a = op->src[0], *b = op->src[1];
     if (!a || !b || !type_ok(a->type) || b->type != LFAMD_TYPE_F32 || op->type != LFAMD_TYPE_F32)
@@ -375,6 +420,8 @@ GGML_CALL enum ggml_status be_graph_compute(ggml_backend_t backend, struct ggml_
     return hipDeviceSynchronize() == hipSuccess ? GGML_STATUS_SUCCESS : GGML_STATUS_FAILED;
 }
 GGML_CALL bool be_supports_op(ggml_backend_t, const struct ggml_tensor *op) {
+    if (!op_layout_agrees(op))
+        return false;
     if (op->op == g_op_mul_mat)
         return mul_mat_supported(op);
     if (op->op == g_op_mul_mat_id)

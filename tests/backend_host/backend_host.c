@@ -91,7 +91,9 @@ static GGML_CALL const char *h_type_name(int t) {
     default: return "?";
     }
 }
-static GGML_CALL size_t h_element_size(const struct ggml_tensor *t) { return lfamd_type_size(t->type); }
+/* BACKEND_HOST_SKEW=1: a host whose struct ggml_tensor differs from the module's header would make the accessors disagree with
+   what the module reads from the struct: simulated by an element size that is off by one */
+static GGML_CALL size_t h_element_size(const struct ggml_tensor *t) { return lfamd_type_size(t->type) + (getenv("BACKEND_HOST_SKEW") ? 1 : 0); }
 static GGML_CALL size_t h_row_size(int t, int64_t ne) { return lfamd_type_size(t) * ne / lfamd_blck_size(t); }
 static GGML_CALL void h_rope(int a, int b, float c, float d, float e, float f[2]) { (void)a, (void)b, (void)c, (void)d, (void)e, (void)f; }
 static GGML_CALL const char *h_op_desc(const struct ggml_tensor *t) { return h_op_name(t->op); }

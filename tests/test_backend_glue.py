@@ -30,6 +30,23 @@ def test_module_exports_the_twelve_symbols_and_links_or_declines(host_exe):
 
 
 @pytest.mark.gpu
+def test_a_host_with_other_struct_layouts_is_declined(gpu, host_exe, tmp_path):
+    """The recalled struct layouts are cross-checked through the host's own accessors (ggml_nbytes, ggml_nelements,
+    ggml_element_size, ggml_is_contiguous, ggml_backend_buffer_get_usage): when they disagree with what the module reads from the
+    structs, supports_op says no (the host program exits 11 = "supports_op says no") and the module says why, once."""
+    t, m, k, n = T.Q4_K, 64, 512, 3
+    wp, xp, op = tmp_path / "w.bin", tmp_path / "x.bin", tmp_path / "o.bin"
+    synth.random_weights(t, m, k, 7).tofile(wp)
+    synth.random_activations(n, k, 8).tofile(xp)
+    args = [host_exe, _hip.HIP_SO, "mulmat", str(t), str(m), str(k), str(n), "1", str(wp), str(xp), str(op)]
+    ok = subprocess.run(args, capture_output=True, text=True, timeout=300)
+    assert ok.returncode == 0, ok.stderr
+    bad = subprocess.run(args, capture_output=True, text=True, timeout=300, env={**os.environ, "BACKEND_HOST_SKEW": "1"})
+    assert bad.returncode == 11, (bad.returncode, bad.stderr)
+    assert "do not match this module's layouts" in bad.stderr
+
+
+@pytest.mark.gpu
 def test_matrices_only_switch_keeps_layer_buffers_on_the_host(gpu, host_exe):
     """with LFAMD_BACKEND_MATRICES_ONLY=1 only the split (matrix) buffer type is device memory, so norm
     weights, the KV cache and compute buffers stay with ggml's CPU backend."""
