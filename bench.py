@@ -763,6 +763,22 @@ def run():
                                             "achieved": round(tf, 1), "frac": round(tf / MFMA_F16_PEAK_TFLOPS, 4),
                                             "kernel": "prep_scaled_kernel + gemm_kr_kernel<Q4_K> (256x128 tile, row-split waves, scaled operands)"}
 
+    # ---- small batches (a few sequences decoding together): one call of 8 tokens on the three decode shapes of a layer
+    small_batch = None
+    if world == 1 and a.model == "llama3-8b-q4_k_m" and not a.gguf:
+        small_batch = {"tokens": 8, "kernel": "sb_prep_kernel + gemm_sb*_kernel (csrc/gemm_sb.hip: exact codes, one MFMA tile of 32 token slots)",
+                       "timing": "back-to-back calls on ONE weight tensor (the small shapes stay in the Infinity Cache); figures with the "
+                                 "weights streamed from HBM: profiles/r03_small_batch.txt, r03_small_batch16.txt"}
+        for name in ("attn_output", "ffn_gate", "ffn_down"):
+            ops8 = [q for q in runner.layers[0] if q.spec.name.endswith(name + ".weight") or q.spec.name.endswith(name)]
+            if not ops8:
+                continue
+            q = ops8[0]
+            x8 = torch.rand((8, q.k), device=dev) * 2 - 1
+            us8 = sgemm.time_mul_mat(q.W, x8.view(torch.uint8).view(8, q.k * 4), T.F32, 8, warmup=3, iters=30)
+            us1 = sgemm.time_mul_mat(q.W, x8[:1].contiguous().view(torch.uint8).view(1, q.k * 4), T.F32, 1, warmup=3, iters=30)
+            small_batch[name] = {"shape": [q.m, q.k], "type": T.NAMES[q.W.type], "us_8_tokens": round(us8, 2), "us_1_token": round(us1, 2)}
+
     if roofline_gemm and tj:
         # HBM traffic of the GEMM tiles: averages over the launches of the profiled bench (each tile serves several
         # shapes of the model), from the same PMC passes as the GEMV's
@@ -813,6 +829,8 @@ def run():
         out["invalid"] = comm_invalid
     if roofline_gemm:
         out["roofline_prefill_gemm"] = roofline_gemm
+    if small_batch:
+        out["small_batch"] = small_batch
     # ---- BASELINE configs 3 and 4 beside the headline config, so the driver's record carries them (1 GPU, default model)
     if world == 1 and a.model == "llama3-8b-q4_k_m" and not a.no_extra_configs:
         del runner, graphs
