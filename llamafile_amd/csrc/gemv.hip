@@ -14,6 +14,9 @@ hipError_t lfamd_gemv_go_q51(GEMV_GO_ARGS);
 hipError_t lfamd_gemv_ids_go_q4k(int, const gemv_mats &, int, long, const void *, size_t, hipStream_t);
 hipError_t lfamd_gemv_ids_go_q5k(int, const gemv_mats &, int, long, const void *, size_t, hipStream_t);
 hipError_t lfamd_gemv_ids_go_q6k(int, const gemv_mats &, int, long, const void *, size_t, hipStream_t);
+hipError_t lfamd_gemv_ids_pair_go_q4k(int, const gemv_mats &, const gemv_mats &, int, long, const void *, const void *, size_t, hipStream_t);
+hipError_t lfamd_gemv_ids_pair_go_q5k(int, const gemv_mats &, const gemv_mats &, int, long, const void *, const void *, size_t, hipStream_t);
+hipError_t lfamd_gemv_ids_pair_go_q6k(int, const gemv_mats &, const gemv_mats &, int, long, const void *, const void *, size_t, hipStream_t);
 hipError_t lfamd_gemv_go_q80_f32(int, const q80_mats &, long, long, const void *, size_t, long, int, int, hipStream_t);
 hipError_t lfamd_gemv_go_q80_q80(int, const q80_mats &, long, long, const void *, size_t, long, int, int, hipStream_t);
 
@@ -194,6 +197,30 @@ extern "C" hipError_t lfamd_launch_gemv_ids(int Atype, int count, const void *co
     if (Atype == LFAMD_TYPE_Q5_K)
         return lfamd_gemv_ids_go_q5k(f, mats, n_ht, k, B, b_row_bytes, s);
     return lfamd_gemv_ids_go_q6k(f, mats, n_ht, k, B, b_row_bytes, s);
+}
+
+// two experts of one tensor, each against its own activation row (ffn_down_exps at decode): one launch
+extern "C" hipError_t lfamd_launch_gemv_ids_pair(int Atype, const void *W, long expert_bytes, int experts, const int32_t *ids, int idx_a,
+                                                 int idx_b, long m, long k, int Btype, const void *Ba, const void *Bb, size_t b_row_bytes,
+                                                 float *Ca, float *Cb, hipStream_t s) {
+    if (m <= 0 || (Atype != LFAMD_TYPE_Q4_K && Atype != LFAMD_TYPE_Q5_K && Atype != LFAMD_TYPE_Q6_K) || (size_t)(k / 256) * XBLK > 150 * 1024)
+        return hipErrorInvalidValue;
+    gemv_mats ma, mb;
+    const int n_ht = (int)(((m + 31) / 32) * 2);
+    for (gemv_mats *mm : {&ma, &mb}) {
+        const bool a = mm == &ma;
+        mm->count = 1, mm->ids = ids, mm->expert_bytes = expert_bytes, mm->experts = experts;
+        for (int i = 0; i < GEMV_MAX_MATS; i++) {
+            mm->A[i] = (const uint8_t *)W, mm->C[i] = a ? Ca : Cb, mm->m[i] = i == 0 ? m : 0, mm->ldc[i] = m;
+            mm->id_idx[i] = a ? idx_a : idx_b, mm->ht_end[i] = n_ht;
+        }
+    }
+    const int f = Btype == LFAMD_TYPE_F32 ? 1 : 0;
+    if (Atype == LFAMD_TYPE_Q4_K)
+        return lfamd_gemv_ids_pair_go_q4k(f, ma, mb, n_ht, k, Ba, Bb, b_row_bytes, s);
+    if (Atype == LFAMD_TYPE_Q5_K)
+        return lfamd_gemv_ids_pair_go_q5k(f, ma, mb, n_ht, k, Ba, Bb, b_row_bytes, s);
+    return lfamd_gemv_ids_pair_go_q6k(f, ma, mb, n_ht, k, Ba, Bb, b_row_bytes, s);
 }
 
 extern "C" hipError_t lfamd_launch_gemv(int Atype, const void *A, long m, long k, int Btype, const void *B,

@@ -1454,6 +1454,20 @@ __global__ __launch_bounds__(NW * 64) void gemv_kq_kernel(const uint8_t *__restr
         gemv_kq_body<TR, NC, BT, NW, GEMV_CH, IDS>(mats, nb, B, b_row_bytes, col0, n_ht, (int)blockIdx.x, gdim, lds);
 }
 
+// Two expert GEMVs on DIFFERENT activation rows in ONE decode launch (GGML_OP_MUL_MAT_ID ffn_down_exps: every chosen expert
+// multiplies its own row): work-groups [0, grid_a) run mats_a against row Ba, the rest mats_b against row Bb.  A work-group
+// serves one of the two, so it stages one row, as in a single launch.
+template <typename TR, int BT, int NW, int GEMV_CH>
+__global__ __launch_bounds__(NW * 64) void gemv_kq_ids_pair_kernel(const uint8_t *__restrict__ Ba, const uint8_t *__restrict__ Bb,
+                                                                   size_t b_row_bytes, int nb, int n_ht_a, int n_ht_b, int grid_a, int grid_b,
+                                                                   const gemv_mats mats_a, const gemv_mats mats_b) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    if ((int)blockIdx.x < grid_a)
+        gemv_kq_body1<TR, BT, NW, GEMV_CH, true>(mats_a, nb, Ba, b_row_bytes, 0, n_ht_a, (int)blockIdx.x, grid_a, lds, nullptr, 0);
+    else
+        gemv_kq_body1<TR, BT, NW, GEMV_CH, true>(mats_b, nb, Bb, b_row_bytes, 0, n_ht_b, (int)blockIdx.x - grid_a, grid_b, lds, nullptr, 0);
+}
+
 // Two weight types in ONE decode launch (sibling mat-muls on the same activations whose types differ: attn_q/k in Q4_K
 // with attn_v in Q6_K in a Q4_K_M file): work-groups [0, grid_a) run type A's body over mats_a, the rest type B's over
 // mats_b.  A work-group is of one type, so it stages the activations once, in the (shared) Q8_K image.
@@ -1832,6 +1846,30 @@ static hipError_t launch_kq_dual(const gemv_mats &ma, int n_ht_a, const gemv_mat
     return launch_kq_dual_nw<TRA, TRB, BT, 16, 2>(ma, n_ht_a, mb, n_ht_b, nb, B, brb, s);
 }
 
+// both launches' half-tiles (n_ht each) on one grid: half of the CUs' work-groups per expert
+template <typename TR, int BT>
+static hipError_t launch_kq_ids_pair(const gemv_mats &ma, const gemv_mats &mb, int n_ht, long k, const void *Ba, const void *Bb, size_t brb,
+                                     hipStream_t s) {
+    const int nb = (int)(k / 256);
+    constexpr int NW = 16;
+    const size_t smem = (size_t)nb * XBLK + 2 * NW * 16 * sizeof(float) + (size_t)NW * XBLK;
+    const int max_wg = num_cus() / 2 > 0 ? num_cus() / 2 : 1;
+    const int per_wg = (n_ht + max_wg - 1) / max_wg;
+    const int g1 = (n_ht + per_wg - 1) / per_wg;
+    auto go = [&](auto kernel) {
+        if (smem > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            if (e != hipSuccess)
+                return e;
+        }
+        kernel<<<2 * g1, NW * 64, smem, s>>>((const uint8_t *)Ba, (const uint8_t *)Bb, brb, nb, n_ht, n_ht, g1, g1, ma, mb);
+        return hipGetLastError();
+    };
+    if (nb <= 16)
+        return go(gemv_kq_ids_pair_kernel<TR, BT, NW, 1>);
+    return go(gemv_kq_ids_pair_kernel<TR, BT, NW, 2>);
+}
+
 template <typename TR, int BT>
 static hipError_t launch_kq_ids(const gemv_mats &mats, int n_ht, long k, const void *B, size_t brb, hipStream_t s) {
     const int nb = (int)(k / 256);
@@ -2011,6 +2049,12 @@ static hipError_t launch_q80(const q80_mats &mats, long n_total, long k, const v
                                          const void *B, size_t brb, hipStream_t s) {                                   \
         return f32in ? launch_kq_dual<TRA, TRB, LFAMD_TYPE_F32>(ma, n_ht_a, mb, n_ht_b, k, B, brb, s)                  \
                      : launch_kq_dual<TRA, TRB, LFAMD_TYPE_Q8_K>(ma, n_ht_a, mb, n_ht_b, k, B, brb, s);                \
+    }
+#define GEMV_INSTANTIATE_IDS_PAIR(NAME, TRAITS)                                                                        \
+    hipError_t lfamd_gemv_ids_pair_go_##NAME(int f32in, const gemv_mats &ma, const gemv_mats &mb, int n_ht, long k, const void *Ba, \
+                                             const void *Bb, size_t brb, hipStream_t s) {                                \
+        return f32in ? launch_kq_ids_pair<TRAITS, LFAMD_TYPE_F32>(ma, mb, n_ht, k, Ba, Bb, brb, s)                       \
+                     : launch_kq_ids_pair<TRAITS, LFAMD_TYPE_Q8_K>(ma, mb, n_ht, k, Ba, Bb, brb, s);                     \
     }
 #define GEMV_INSTANTIATE_IDS(NAME, TRAITS)                                                                             \
     hipError_t lfamd_gemv_ids_go_##NAME(int f32in, const gemv_mats &mats, int n_ht, long k, const void *B, size_t brb,  \

@@ -18,6 +18,8 @@
 extern "C" int lfamd_mul_mat(int, const void *, long, long, int, const void *, size_t, long, float *, long, void *, size_t,
                              unsigned, void *);
 extern "C" size_t lfamd_mul_mat_workspace(int, long, long, long);
+extern "C" hipError_t lfamd_launch_gemv_ids_pair(int, const void *, long, int, const int32_t *, int, int, long, long, int, const void *,
+                                                 const void *, size_t, float *, float *, hipStream_t);
 extern "C" hipError_t lfamd_launch_gemv_ids(int, int, const void *const *, long, int, const int32_t *, const int *, long, long, int,
                                             const void *, size_t, float *const *, hipStream_t);
 
@@ -198,9 +200,23 @@ extern "C" hipError_t lfamd_launch_moe(int type, const void *W, long rows, long 
     if (tokens <= 4 && (type == LFAMD_TYPE_Q4_K || type == LFAMD_TYPE_Q5_K || type == LFAMD_TYPE_Q6_K) &&
         !(flags & LFAMD_FLAG_FORCE_GENERIC) &&
         (Btype == LFAMD_TYPE_F32 || Btype == LFAMD_TYPE_Q8_K) && (size_t)(cols / 256) * 384 <= 150 * 1024) {
+        static const bool no_pair = getenv("LFAMD_MOE_NO_PAIR") != nullptr; // development: A/B
         for (long t = 0; t < tokens; t++) {
             int th = 0;
             while (th < thinkers) {
+                if (tasks > 1 && th + 1 < thinkers && (th + 1) % tasks != th % tasks && !no_pair) {
+                    // two thinkers with their own activation rows (ffn_down_exps): one launch, half of the work-groups each
+                    const uint8_t *Ba = (const uint8_t *)thought + (size_t)(t * tasks + th % tasks) * b_row_bytes;
+                    const uint8_t *Bb = (const uint8_t *)thought + (size_t)(t * tasks + (th + 1) % tasks) * b_row_bytes;
+                    hipError_t e3 = lfamd_launch_gemv_ids_pair(type, W, (long)expert_bytes, experts, plan, (int)(t * thinkers + th),
+                                                               (int)(t * thinkers + th + 1), rows, cols, Btype, Ba, Bb, b_row_bytes,
+                                                               result + (size_t)(t * thinkers + th) * rows,
+                                                               result + (size_t)(t * thinkers + th + 1) * rows, s);
+                    if (e3 != hipSuccess)
+                        return e3;
+                    th += 2;
+                    continue;
+                }
                 int cnt = 1;
                 if (tasks == 1)
                     cnt = thinkers - th < 4 ? thinkers - th : 4;
