@@ -81,12 +81,12 @@ int lfamd_stream_sync(void *stream);
  * tensor exactly as GGUF/ggml stores it: `rows` rows, `raw_row_bytes` apart, each a sequence of
  * blocks (include/lfamd_blocks.h).  Packing is a device kernel: raw and packed are device
  * pointers.  lfamd_packed_size is the ONLY source of the packed byte count: Q4_K / Q5_K / Q6_K / Q4_0 images are
- * the GGUF size (+ tile round-up); Q2_K / Q3_K are compact images of 84 / 116 bytes per 256 weights (1.00x / 1.055x the file:
- * DESIGN.md section 10.10; batches expand them per call into the canonical image in the workspace); Q8_0 keeps TWO images —
+ * the GGUF size (+ tile round-up); Q2_K / Q3_K / IQ4_XS are compact images of 84 / 116 / 144 bytes per 256 weights (1.00x /
+ * 1.055x / 1.06x the file: DESIGN.md section 10.10; batches expand them per call into the canonical image in the workspace); Q8_0 keeps TWO images —
  * the GGUF-sized one the bit-exact vecdot and exact batch kernels read, and behind it what batches read: f16(d * q) rows for
  * the vendor GEMM (3.1 bytes per weight resident in all) or, where lfamd_vendor_gemm_available() is 0, the MFMA body's byte
- * image (2.1); IQ4_XS / Q4_1 / Q5_0 / Q5_1 are kept as the canonical image their MFMA and decode kernels read (272 / 192 / 192
- * / 192 bytes per 256 weights: up to 2x the file size); legacy 32-block rows that are not whole
+ * image (2.1); Q4_1 / Q5_0 / Q5_1 are kept as the canonical image their MFMA and decode kernels read (192 bytes per 256
+ * weights: 1.2 - 1.5x the file); legacy 32-block rows that are not whole
  * 256-weight groups and float tensors stay as GGUF rows. */
 size_t lfamd_packed_size(int type, long rows, long cols);
 /* 1 when batches on PLAIN 16-bit float matrices — F16 / BF16 weight tensors and the resident f16(d * q) image of Q8_0 weights — go

@@ -36,6 +36,8 @@ hipError_t lfamd_launch_rows_to_16(int dtype, const void *X, size_t x_row_bytes,
 hipError_t lfamd_launch_q80_rows_to_f16(int Btype, const void *X, size_t x_row_bytes, long n, long k, void *out, hipStream_t s);
 hipError_t lfamd_launch_q80_image(const void *raw, size_t raw_row_bytes, long rows, long cols, void *out, hipStream_t s);
 size_t lfamd_pk_bytes(int type, long rows, long cols);
+hipError_t lfamd_launch_pk4x_pack(const void *raw, size_t raw_row_bytes, long rows, long cols, void *out, hipStream_t s);
+hipError_t lfamd_launch_pk4x_expand(const void *packed, long rows, long cols, void *out, hipStream_t s);
 hipError_t lfamd_launch_pk_pack(int type, const void *raw, size_t raw_row_bytes, long rows, long cols, void *out, hipStream_t s);
 hipError_t lfamd_launch_pk_expand(int type, const void *packed, long rows, long cols, void *out, hipStream_t s);
 size_t lfamd_gemm_sb_workspace(long k);
@@ -227,8 +229,9 @@ size_t lfamd_packed_size(int type, long rows, long cols) {
     case LFAMD_TYPE_Q2_K:
     case LFAMD_TYPE_Q3_K: // PK2 / PK3: compact images (84 / 116 bytes per 256 weights) the decode GEMV reads; batches expand them
         return lfamd_pk_bytes(type, rows, cols); // into the canonical PCK image in the workspace, per call
-    case LFAMD_TYPE_IQ4_XS: // PC8
-        return lfamd_wprep8_bytes(rows, cols);
+    case LFAMD_TYPE_IQ4_XS: // codebook indices on the P4K nibble lattice + 16 header bytes per row (144 bytes per 256 weights, 1.06 x
+                            // the file); batches expand it per call into the PC8 byte image in the workspace
+        return (size_t)((rows + 31) / 32) * (size_t)(cols / 256) * P4K_TILE;
     case LFAMD_TYPE_Q4_1:
     case LFAMD_TYPE_Q5_0:
     case LFAMD_TYPE_Q5_1:
@@ -279,7 +282,7 @@ int lfamd_pack_weights(int type, long rows, long cols, const void *d_raw, size_t
         HIPCHK(lfamd_launch_pk_pack(type, d_raw, raw_row_bytes, rows, cols, d_packed, s), "pack_pk");
         break;
     case LFAMD_TYPE_IQ4_XS:
-        HIPCHK(lfamd_launch_wprep8(type, d_raw, raw_row_bytes, rows, cols, d_packed, s), "pack_pc8");
+        HIPCHK(lfamd_launch_pk4x_pack(d_raw, raw_row_bytes, rows, cols, d_packed, s), "pack_pk4x");
         break;
     case LFAMD_TYPE_Q4_1:
     case LFAMD_TYPE_Q5_0:
@@ -448,7 +451,7 @@ static size_t mul_mat_workspace_base(int Atype, long m, long k, long n) {
         return own > lt ? own : lt;
     }
     if (use_gemm_canon(Atype, n, 0)) // (+ the canonical image of a Q2_K / Q3_K matrix, rebuilt from the compact one per call)
-        return gemm_act_ws(k, n) + (Atype == LFAMD_TYPE_IQ4_XS ? 0 : align_up(lfamd_wprep16_bytes(m, k), 256));
+        return gemm_act_ws(k, n) + align_up(Atype == LFAMD_TYPE_IQ4_XS ? lfamd_wprep8_bytes(m, k) : lfamd_wprep16_bytes(m, k), 256);
     if (use_gemm_canon32(Atype, n, 0, k)) { // Xh, d8T [nb*8][n_pad], sT [nb*8][n_pad], image
         size_t n_pad = align_up((size_t)n, 128), nb = (size_t)(k / 256);
         return align_up(n_pad * (size_t)k * 2, 256) + 2 * align_up(nb * 8 * n_pad * 4, 256);
@@ -595,12 +598,12 @@ int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const v
             HIPCHK(lfamd_launch_prep_f32(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, mins16, nullptr, s), "prep_f32");
         else
             HIPCHK(lfamd_launch_prep_q8k(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, mins16, nullptr, s), "prep_q8k");
-        const void *img = d_A;
-        if (Atype != LFAMD_TYPE_IQ4_XS) { // Q2_K / Q3_K: the resident image is the compact one; the MFMA body reads the canonical form
-            void *pck = ws + gemm_act_ws(k, n);
-            HIPCHK(lfamd_launch_pk_expand(Atype, d_A, m, k, pck, s), "pk_expand");
-            img = pck;
-        }
+        // the resident image is the compact one; the MFMA body reads the canonical form, rebuilt here per call
+        void *img = ws + gemm_act_ws(k, n);
+        if (Atype == LFAMD_TYPE_IQ4_XS)
+            HIPCHK(lfamd_launch_pk4x_expand(d_A, m, k, img, s), "pk4x_expand");
+        else
+            HIPCHK(lfamd_launch_pk_expand(Atype, d_A, m, k, img, s), "pk_expand");
         HIPCHK(lfamd_launch_gemm_wide(Atype, img, m, k, Xh, d8T, Xm, n, (long)n_pad, d_C, ldc, plain, nullptr, 0, s), "gemm_wide");
         return LFAMD_OK;
     }

@@ -684,6 +684,52 @@ struct pc8_traits {
     }
 };
 
+// IQ4_XS on the RESIDENT compact image (generic.hip: pk4x_pack_kernel): codebook indices on the P4K nibble lattice, so a dword's
+// nibbles already sit in the order of the staged activation codes; the 16-entry int8 codebook (kvalues_iq4nl,
+// iqk_mul_mat.inc:601-628 looks it up with a byte shuffle too) is four registers and three v_perm per four codes: the lower
+// and the upper eight entries by the index's low three bits, then byte i of one or the other by its bit 3.
+struct iq4c_traits {
+    static constexpr int ACT = LFAMD_TYPE_Q8_K;
+    static constexpr int TILE = P4K_TILE;
+    struct chunk {
+        uint4 q0[GEMV_CH_MAX], q1[GEMV_CH_MAX], hd[GEMV_CH_MAX];
+    };
+    __device__ static inline void load(chunk &ch, int s, lfamd_rsrc r, uint32_t off, int gsel, int slot, int hrow) {
+        ch.q0[s] = buf_ld16_nt(r, off + (2 * gsel + 0) * 1024 + slot * 16);
+        ch.q1[s] = buf_ld16_nt(r, off + (2 * gsel + 1) * 1024 + slot * 16);
+        ch.hd[s] = buf_ld16(r, off + P4K_HDR + hrow * 16);
+    }
+    __device__ static inline uint32_t lut4(uint32_t n) { // four indices (one per byte) -> four codebook values
+        constexpr uint32_t T0 = 0xBFAD9881u, T1 = 0xF6EADDCFu, T2 = 0x26190D01u, T3 = 0x71594535u; // kvalues_iq4nl, 4 entries each
+        const uint32_t sel = n & 0x07070707u;
+        const uint32_t lo = __builtin_amdgcn_perm(T1, T0, sel), hi = __builtin_amdgcn_perm(T3, T2, sel);
+        return __builtin_amdgcn_perm(hi, lo, ((n >> 1) & 0x04040404u) | 0x03020100u);
+    }
+    __device__ static inline float dot(const chunk &ch, int s, const uint8_t *xb, int gsel, int h) {
+        const uint4 q0 = ch.q0[s], q1 = ch.q1[s], hd = ch.hd[s];
+        const uint32_t qw[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+        const uint4 *yq = (const uint4 *)(xb + 128 * gsel + 64 * h);
+        const uint4 ya = yq[0], yb = yq[1], yc = yq[2], yd = yq[3];
+        const uint32_t yw[16] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w,
+                                 yc.x, yc.y, yc.z, yc.w, yd.x, yd.y, yd.z, yd.w};
+        const uint32_t scw = gsel ? hd.y : hd.x; // scales of sub-blocks 4 gsel .. 4 gsel + 3
+        int sumi = 0;
+#pragma unroll
+        for (int u = 0; u < 4; u++) { // sub-block 4 gsel + u = K-steps t8 = 2u, 2u + 1 of this lane
+            int isum = 0;
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const uint32_t x = qw[2 * u + e];
+                isum = sdot4(lut4(x & 0x0F0F0F0Fu), yw[2 * (2 * u + e)], isum);
+                isum = sdot4(lut4((x >> 4) & 0x0F0F0F0Fu), yw[2 * (2 * u + e) + 1], isum);
+            }
+            sumi += (int)(int8_t)((scw >> (8 * u)) & 0xff) * isum;
+        }
+        const float d8 = *(const float *)(xb + XBLK_D);
+        return (h2f((uint16_t)(hd.z & 0xffff)) * d8) * (float)sumi;
+    }
+};
+
 // Up to GEMV_MAX_MATS weight matrices of one type and row length that consume the SAME activations
 // (attn_q/k/v, ffn_gate/up) are served by one launch: their half-tiles are concatenated.
 #define GEMV_MAX_MATS 4
@@ -1968,7 +2014,7 @@ static hipError_t launch_q51(const gemv_mats &mats, int n_ht, long k, const void
 
 template <int NC, int BT>
 static hipError_t launch_iq4xs(const gemv_mats &mats, int n_ht, long k, const void *B, size_t brb, long col0, hipStream_t s) {
-    return launch_kq_pick<pc8_traits, NC, BT>(mats, n_ht, k, B, brb, col0, s);
+    return launch_kq_pick<iq4c_traits, NC, BT>(mats, n_ht, k, B, brb, col0, s);
 }
 
 template <int NC, int BT>

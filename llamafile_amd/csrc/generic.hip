@@ -530,6 +530,97 @@ __global__ void pk_expand_kernel(const uint8_t *__restrict__ in, uint8_t *__rest
     dst[w] = v;
 }
 
+// IQ4_XS resident image (PK4X = P4K_TILE bytes per 32 x 256): the codebook INDICES on the P4K nibble lattice (K-step t = 4 g + dd of
+// lane (i, h): element j at bit 4 NIBPOS(j)), then per row {8 int8 sub-block scales (ls - 32), f16 d, pad} — 144 bytes per 256
+// weights against 136 in the file; the decode GEMV looks the 16-entry codebook up in registers.
+__global__ void pk4x_pack_kernel(const uint8_t *__restrict__ raw, size_t raw_row_bytes, long rows, int nb, uint8_t *__restrict__ out,
+                                 long n_tiles) {
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long tile = tid / 1152; // 1024 index dwords + 128 header dwords
+    const int w = (int)(tid % 1152);
+    if (tile >= n_tiles)
+        return;
+    const long rt = tile / nb;
+    const int b = (int)(tile % nb);
+    uint32_t *dst = (uint32_t *)(out + tile * P4K_TILE);
+    uint32_t v = 0;
+    if (w < 1024) {
+        const int g = w >> 8, lane = (w >> 2) & 63, dd = w & 3;
+        const int i = lane & 31, h = lane >> 5;
+        const long row = rt * 32 + i;
+        if (row < rows) {
+            const lfamd_block_iq4_xs *blk = (const lfamd_block_iq4_xs *)(raw + row * raw_row_bytes) + b;
+            const int t = 4 * g + dd;
+            for (int j = 0; j < 8; j++) {
+                const int k = 16 * t + 8 * h + j, ib = k >> 5, l = k & 31;
+                const uint8_t byte = blk->qs[16 * ib + (l & 15)];
+                v |= (uint32_t)(l < 16 ? (byte & 15) : (byte >> 4)) << (4 * NIBPOS(j));
+            }
+        }
+    } else {
+        const int s4 = w - 1024, i = s4 >> 2, q = s4 & 3; // header dwords as in the PC8 image: scales 0-3, 4-7, d, pad
+        const long row = rt * 32 + i;
+        if (row < rows && q < 3) {
+            const lfamd_block_iq4_xs *blk = (const lfamd_block_iq4_xs *)(raw + row * raw_row_bytes) + b;
+            if (q < 2) {
+                for (int e = 0; e < 4; e++) {
+                    const int ib = 4 * q + e;
+                    const int ls = ((blk->scales_l[ib / 2] >> (4 * (ib % 2))) & 0xf) | (((blk->scales_h >> (2 * ib)) & 3) << 4);
+                    v |= (uint32_t)((ls - 32) & 0xff) << (8 * e);
+                }
+            } else {
+                v = blk->d;
+            }
+        }
+    }
+    dst[w] = v;
+}
+
+// batches: compact image -> the PC8 byte image (codebook value + 128) the MFMA body reads, per call, into the workspace
+__global__ void pk4x_expand_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, long n_tiles, long rows, int nb) {
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long tile = tid / 2176; // (wprep8_iq4xs_kernel's dword order)
+    const int w = (int)(tid % 2176);
+    if (tile >= n_tiles)
+        return;
+    const uint8_t *src = in + tile * P4K_TILE;
+    uint32_t *dst = (uint32_t *)(out + tile * PC8_TILE);
+    uint32_t v = 0;
+    if (w < 2048) {
+        const int g2 = w >> 8, lane = (w >> 2) & 63, e = w & 3;
+        const int t = 2 * g2 + (e >> 1);
+        const uint32_t x = *(const uint32_t *)(src + (t >> 2) * 1024 + lane * 16 + (t & 3) * 4);
+        if ((tile / nb) * 32 + (lane & 31) < rows) // (rows past the matrix: zero bytes, like the builder from GGUF rows)
+        for (int jj = 0; jj < 4; jj++) {
+            const int j = 4 * (e & 1) + jj;
+            const int val = kvalues_iq4nl_dev[(x >> (4 * NIBPOS(j))) & 15];
+            v |= (uint32_t)((val + 128) & 0xff) << (8 * jj);
+        }
+    } else {
+        v = *(const uint32_t *)(src + P4K_HDR + (w - 2048) * 4);
+    }
+    dst[w] = v;
+}
+
+extern "C" hipError_t lfamd_launch_pk4x_pack(const void *raw, size_t raw_row_bytes, long rows, long cols, void *out, hipStream_t s) {
+    const int nb = (int)(cols / 256);
+    const long n_tiles = ((rows + 31) / 32) * nb;
+    if (n_tiles == 0)
+        return hipSuccess;
+    const long threads = n_tiles * 1152;
+    pk4x_pack_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>((const uint8_t *)raw, raw_row_bytes, rows, nb, (uint8_t *)out, n_tiles);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t lfamd_launch_pk4x_expand(const void *packed, long rows, long cols, void *out, hipStream_t s) {
+    const long n_tiles = ((rows + 31) / 32) * (cols / 256);
+    if (n_tiles == 0)
+        return hipSuccess;
+    const long threads = n_tiles * 2176;
+    pk4x_expand_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>((const uint8_t *)packed, (uint8_t *)out, n_tiles, rows, (int)(cols / 256));
+    return hipGetLastError();
+}
+
 extern "C" size_t lfamd_pk_bytes(int type, long rows, long cols) {
     return (size_t)((rows + 31) / 32) * (size_t)(cols / 256) * (type == LFAMD_TYPE_Q3_K ? PK3_TILE : PK2_TILE);
 }

@@ -51,11 +51,10 @@ def test_packed_size_is_exactly_gguf_size_for_aligned_shapes():
     assert lib.lfamd_packed_size(T.Q8_0, 64, 96) == 64 // 8 * 1088 + (64 * 96 * 2 if lib.lfamd_vendor_gemm_available() else 0)  # 3 blocks -> one P80 tile of four
     assert lib.lfamd_packed_size(T.Q4_K, 33, 256) == 2 * 4608  # rows round up to 32
     # Q2_K / Q3_K: compact resident images (84 / 116 bytes per 256 weights; the canonical image is rebuilt per batch call);
-    # IQ4_XS: the resident canonical byte image (PC8)
     assert lib.lfamd_packed_size(T.Q2_K, 4096, 4096) == 128 * 16 * 2688 == 4096 * T.row_size(T.Q2_K, 4096)
     assert lib.lfamd_packed_size(T.Q3_K, 4096, 4096) == 128 * 16 * 3712
     assert lib.lfamd_packed_size(T.Q3_K, 4096, 4096) <= 1.06 * 4096 * T.row_size(T.Q3_K, 4096)
-    assert lib.lfamd_packed_size(T.IQ4_XS, 4096, 4096) == 128 * 16 * 8704
+    assert lib.lfamd_packed_size(T.IQ4_XS, 4096, 4096) == 128 * 16 * 4608  # codebook indices on the nibble lattice: 144 B per 256 (file: 136)
     for t in (T.Q4_1, T.Q5_0, T.Q5_1):  # PCL when rows are whole 256-weight groups, RAW otherwise (like Q4_0 / P40)
         assert lib.lfamd_packed_size(t, 4096, 4096) == 128 * 16 * 6144
         assert lib.lfamd_packed_size(t, 64, 96) == 64 * T.row_size(t, 96)

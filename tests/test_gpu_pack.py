@@ -70,3 +70,29 @@ def test_compact_images_expand_to_the_canonical_image(gpu, t, shape):
     assert L.lfamd_launch_pk_expand(t, C.c_void_p(W.data.data_ptr()), C.c_long(rows), C.c_long(cols), C.c_void_p(got.data_ptr()), st) == 0
     torch.cuda.synchronize()
     assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("shape", [(64, 512), (37, 1024), (7, 256)], ids=str)
+def test_compact_iq4_xs_image_expands_to_the_byte_image(gpu, shape):
+    """IQ4_XS is resident as codebook INDICES on the nibble lattice (144 bytes per 256 weights); batches expand it per call into the
+    byte image (codebook value + 128) the MFMA body reads: pack + expand must be bit-for-bit the byte image built from the GGUF rows."""
+    import ctypes as C
+    import torch
+    from llamafile_amd import _hip
+    rows, cols = shape
+    t = T.IQ4_XS
+    raw = synth.random_weights(t, rows, cols, seed=19)
+    W = gpu.upload_weights(t, raw, rows, cols)
+    L = C.CDLL(_hip.HIP_SO)
+    L.lfamd_wprep8_bytes.restype = C.c_size_t
+    nbytes = L.lfamd_wprep8_bytes(C.c_long(rows), C.c_long(cols))
+    assert W.data.numel() < 0.6 * nbytes
+    rawd = torch.from_numpy(raw).cuda()
+    want = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+    got = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert L.lfamd_launch_wprep8(t, C.c_void_p(rawd.data_ptr()), C.c_size_t(raw.shape[1]), C.c_long(rows), C.c_long(cols),
+                                 C.c_void_p(want.data_ptr()), st) == 0
+    assert L.lfamd_launch_pk4x_expand(C.c_void_p(W.data.data_ptr()), C.c_long(rows), C.c_long(cols), C.c_void_p(got.data_ptr()), st) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
