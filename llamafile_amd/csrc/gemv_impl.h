@@ -524,66 +524,10 @@ struct pcl_traits {
     }
 };
 
-// Q2_K / Q3_K on the PCK image (lfamd_device.h): the P4K nibble lattice of (q - qmin), one int8 scale per K-step, Q2_K
-// also one uint8 min per K-step.  The reference unpacks the same 16-wide sub-blocks and takes the mins / the -4 offset
-// through the Q8_K bsums (DequantizerQ2K / DequantizerQ3K, iqk_mul_mat.inc:420-470, 513-568); here the staged
-// 8-weight group sums (XBLK_HB) play the role of bsums, as for Q6_K.
-//   Q2_K: d*d8*sum_t sc_t*<q, q8>_t - dmin*d8*sum_t mn_t*bsum_t      Q3_K: d*d8*sum_t sc_t*(<q+4, q8>_t - 4*bsum_t)
-template <int TYPE>
-struct pck_traits {
-    static constexpr int ACT = LFAMD_TYPE_Q8_K;
-    static constexpr int TILE = PCK_TILE;
-    static constexpr bool MINS = TYPE == LFAMD_TYPE_Q2_K;
-    static constexpr int OFF = TYPE == LFAMD_TYPE_Q3_K ? 4 : 0;
-    struct chunk {
-        uint4 q0[GEMV_CH_MAX], q1[GEMV_CH_MAX];
-        uint2 sc[GEMV_CH_MAX], mn[GEMV_CH_MAX];
-        uint32_t dd[GEMV_CH_MAX];
-    };
-    __device__ static inline void load(chunk &ch, int s, lfamd_rsrc r, uint32_t off, int gsel, int slot, int hrow) {
-        ch.q0[s] = buf_ld16_nt(r, off + (2 * gsel + 0) * 1024 + slot * 16);
-        ch.q1[s] = buf_ld16_nt(r, off + (2 * gsel + 1) * 1024 + slot * 16);
-        ch.sc[s] = buf_ld8(r, off + PCK_SC + hrow * 16 + gsel * 8); // scales of K-steps 8*gsel..+7
-        if constexpr (MINS)
-            ch.mn[s] = buf_ld8(r, off + PCK_MN + hrow * 16 + gsel * 8);
-        ch.dd[s] = __builtin_amdgcn_raw_buffer_load_b32(r, off + PCK_D + hrow * 4, 0, 0); // {d, dmin}
-    }
-    __device__ static inline float dot(const chunk &ch, int s, const uint8_t *xb, int gsel, int h) {
-        const uint4 q0 = ch.q0[s], q1 = ch.q1[s];
-        const uint2 scb = ch.sc[s];
-        const uint32_t dw = ch.dd[s];
-        const float d = h2f((uint16_t)(dw & 0xffff));
-        const uint32_t lw[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
-        const uint4 *yq = (const uint4 *)(xb + 128 * gsel + 64 * h);
-        const uint4 ya = yq[0], yb = yq[1], yc = yq[2], yd = yq[3];
-        const uint32_t yw[16] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w,
-                                 yc.x, yc.y, yc.z, yc.w, yd.x, yd.y, yd.z, yd.w};
-        const uint4 hbw = *(const uint4 *)(xb + XBLK_HB + 32 * gsel + 16 * h);
-        const uint32_t hbv[4] = {hbw.x, hbw.y, hbw.z, hbw.w};
-        int sumi = 0, summ = 0;
-#pragma unroll
-        for (int t8 = 0; t8 < 8; t8++) { // t8 = 4 gi + dd
-            const uint32_t x = lw[t8];
-            int isum = sdot4(x & 0x0F0F0F0F, yw[2 * t8], 0);
-            isum = sdot4((x >> 4) & 0x0F0F0F0F, yw[2 * t8 + 1], isum);
-            const int hs = (int)(int16_t)((hbv[t8 >> 1] >> (16 * (t8 & 1))) & 0xffff);
-            const int sc = (int)(int8_t)(((t8 < 4 ? scb.x : scb.y) >> (8 * (t8 & 3))) & 0xff);
-            sumi += sc * (isum - OFF * hs);
-            if constexpr (MINS) {
-                const uint2 mnb = ch.mn[s];
-                summ += (int)(((t8 < 4 ? mnb.x : mnb.y) >> (8 * (t8 & 3))) & 0xff) * hs;
-            }
-        }
-        const float d8 = *(const float *)(xb + XBLK_D);
-        if constexpr (MINS)
-            return fmaf(d * d8, (float)sumi, -(h2f((uint16_t)(dw >> 16)) * d8) * (float)summ);
-        return (d * d8) * (float)sumi;
-    }
-};
-
 // Q2_K / Q3_K on the RESIDENT compact images (lfamd_device.h: PK2 / PK3): half the bytes of the canonical image per row; two
 // K-steps come out of one code dword with an AND and a shift-AND, Q3_K's third bit with a shift, an AND and a shift-OR.
-// Then the arithmetic of pck_traits above.
+// Per 16-wide sub-block: sc * (<q + OFF, y> - OFF * sum(y)) with the staged group sums; Q2_K's mins against the same sums
+// (iqk_mul_mat.inc:432-470, 533-568).
 template <int TYPE>
 struct pk_traits {
     static constexpr int ACT = LFAMD_TYPE_Q8_K;
@@ -638,49 +582,6 @@ struct pk_traits {
         if constexpr (MINS)
             return fmaf(d * d8, (float)sumi, -(h2f((uint16_t)(dw >> 16)) * d8) * (float)summ);
         return (d * d8) * (float)sumi;
-    }
-};
-
-// IQ4_XS on the PC8 image: the codebook value + 128 as one byte per weight (DequantizerIQ4XS looks the same values up
-// with a shuffle, iqk_mul_mat.inc:601-628), eight int8 sub-block scales (ls - 32) and d per row.  The image keeps the
-// MFMA K-step order (bytes k0..k3 | k4..k7 of a lane's half K-step); the staged activation codes are ordered
-// (y0,y4,y1,y5 | y2,y6,y3,y7), so two v_perm per K-step put the weights in the same order.
-struct pc8_traits {
-    static constexpr int ACT = LFAMD_TYPE_Q8_K;
-    static constexpr int TILE = PC8_TILE;
-    struct chunk {
-        uint4 b0[GEMV_CH_MAX], b1[GEMV_CH_MAX], b2[GEMV_CH_MAX], b3[GEMV_CH_MAX], hd[GEMV_CH_MAX];
-    };
-    __device__ static inline void load(chunk &ch, int s, lfamd_rsrc r, uint32_t off, int gsel, int slot, int hrow) {
-        ch.b0[s] = buf_ld16_nt(r, off + (4 * gsel + 0) * 1024 + slot * 16);
-        ch.b1[s] = buf_ld16_nt(r, off + (4 * gsel + 1) * 1024 + slot * 16);
-        ch.b2[s] = buf_ld16_nt(r, off + (4 * gsel + 2) * 1024 + slot * 16);
-        ch.b3[s] = buf_ld16_nt(r, off + (4 * gsel + 3) * 1024 + slot * 16);
-        ch.hd[s] = buf_ld16(r, off + PC8_HDR + hrow * 16);
-    }
-    __device__ static inline float dot(const chunk &ch, int s, const uint8_t *xb, int gsel, int h) {
-        const uint4 b0 = ch.b0[s], b1 = ch.b1[s], b2 = ch.b2[s], b3 = ch.b3[s], hd = ch.hd[s];
-        const uint32_t bw[16] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
-        const uint4 *yq = (const uint4 *)(xb + 128 * gsel + 64 * h);
-        const uint4 ya = yq[0], yb = yq[1], yc = yq[2], yd = yq[3];
-        const uint32_t yw[16] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w,
-                                 yc.x, yc.y, yc.z, yc.w, yd.x, yd.y, yd.z, yd.w};
-        const uint32_t scw = gsel ? hd.y : hd.x; // scales of sub-blocks 4 gsel .. 4 gsel + 3
-        int sumi = 0;
-#pragma unroll
-        for (int u = 0; u < 4; u++) { // sub-block 4 gsel + u = K-steps t8 = 2u, 2u + 1 of this lane
-            int isum = 0;
-#pragma unroll
-            for (int e = 0; e < 2; e++) {
-                const int t8 = 2 * u + e;
-                const uint32_t lo = bw[2 * t8] ^ 0x80808080u, hi = bw[2 * t8 + 1] ^ 0x80808080u; // k0..k3, k4..k7
-                isum = sdot4(__builtin_amdgcn_perm(hi, lo, 0x05010400), yw[2 * t8], isum);     // (k0,k4,k1,k5)
-                isum = sdot4(__builtin_amdgcn_perm(hi, lo, 0x07030602), yw[2 * t8 + 1], isum); // (k2,k6,k3,k7)
-            }
-            sumi += (int)(int8_t)((scw >> (8 * u)) & 0xff) * isum;
-        }
-        const float d8 = *(const float *)(xb + XBLK_D);
-        return (h2f((uint16_t)(hd.z & 0xffff)) * d8) * (float)sumi;
     }
 };
 
