@@ -39,6 +39,8 @@ __global__ __launch_bounds__(64) void sb_prep_kernel(const uint8_t *__restrict__
             C[r * ldc + (e - r * m)] = 0.0f;
         }
     }
+    if (!B)
+        return; // (zero only: the staged codes of an earlier matrix of the same launch group are reused)
     typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
     _Float16 *xo = Xh + ((size_t)b * SB_COLS + tok) * 256;
     _Float16 *mo = Xm + ((size_t)b * SB_COLS + tok) * 16;
@@ -686,8 +688,10 @@ bool lfamd_gemm_sb_ok(int Atype, long k, long n) {
            n <= SB_COLS;
 }
 
+// reuse_stage != 0: the workspace already holds these activations staged by the previous call (sibling matrices of one launch
+// group: ffn_gate / ffn_up, attn_q / k / v): only the zeroing of this matrix's result, where its body needs it, is launched.
 hipError_t lfamd_launch_gemm_sb(int Atype, const void *A, long m, long k, int Btype, const void *B, size_t b_row_bytes, long n, float *C,
-                                long ldc, void *ws, hipStream_t s) {
+                                long ldc, void *ws, int reuse_stage, hipStream_t s) {
     const int nb = (int)(k / 256);
     uint8_t *w8 = (uint8_t *)ws;
     _Float16 *Xh = (_Float16 *)w8;
@@ -710,6 +714,11 @@ hipError_t lfamd_launch_gemm_sb(int Atype, const void *A, long m, long k, int Bt
             ksplit = 2;
     }
     float *Czero = ksplit == 1 ? nullptr : C;
+    if (reuse_stage) {
+        B = nullptr;
+        if (!Czero)
+            goto staged;
+    }
     if (Btype == LFAMD_TYPE_F32) {
         if (mins)
             sb_prep_kernel<true, true><<<pg, 64, 0, s>>>((const uint8_t *)B, b_row_bytes, (int)n, nb, Xh, d8T, Xm, Czero, m, ldc);
@@ -721,9 +730,12 @@ hipError_t lfamd_launch_gemm_sb(int Atype, const void *A, long m, long k, int Bt
         else
             sb_prep_kernel<false, false><<<pg, 64, 0, s>>>((const uint8_t *)B, b_row_bytes, (int)n, nb, Xh, d8T, Xm, Czero, m, ldc);
     }
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess)
-        return e;
+    {
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess)
+            return e;
+    }
+staged:
     const int n_rt = (int)((m + 31) / 32);
     if (ksplit) {
         const int cus = lfamd_num_cus();

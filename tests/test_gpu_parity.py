@@ -330,6 +330,20 @@ def test_mul_mat_multi_equals_separate(gpu, t, n):
         assert np.array_equal(f.cpu().numpy().view(np.uint32), sep.cpu().numpy().view(np.uint32))
 
 
+@pytest.mark.parametrize("n", [6, 8, 16])
+def test_mul_mat_multi_small_batch_shares_the_staging(gpu, n):
+    """Several tokens on sibling matrices with several row tiles per CU (ffn_gate + ffn_up): the activations are staged once and
+    every matrix runs the small-batch MFMA kernel on them — the bits of separate lfamd_mul_mat calls."""
+    from llamafile_amd import synth
+    k, ms = 512, [9000, 8300]
+    Ws = [gpu.upload_weights(T.Q4_K, synth.random_weights_torch(T.Q4_K, m, k, 80 + i).cpu().numpy(), m, k) for i, m in enumerate(ms)]
+    x = torch.from_numpy(synth.random_activations(n, k, 81)).cuda()
+    fused = gpu.mul_mat_multi(Ws, x.view(torch.uint8), T.F32, n=n)
+    for W, f in zip(Ws, fused):
+        sep = gpu.mul_mat(W, x.view(torch.uint8), T.F32, n=n)
+        assert torch.equal(f.view(torch.int32), sep.view(torch.int32))
+
+
 @pytest.mark.parametrize("ta", [T.Q4_K, T.Q5_K], ids=lambda t: T.NAMES[t])
 @pytest.mark.parametrize("k", [1024, 4096, 5120])
 @pytest.mark.parametrize("f32in", [True, False], ids=["f32", "q8k"])
