@@ -839,7 +839,7 @@ def run():
         torch.cuda.empty_cache()
         try:
             from llamafile_amd import mixtral_bench
-            out["config4"] = mixtral_bench.run(32, 20, a.prefill, dev)
+            out["config4"] = mixtral_bench.run(32, 60, a.prefill, dev)
         except Exception as e:  # noqa: BLE001 (the headline line must survive a failure of a side leg)
             out["config4"] = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
         torch.cuda.empty_cache()
