@@ -398,21 +398,30 @@ static size_t gemm_q80_mfma_ws(long m, long k, long n) { // Xh, d8T [nb*8][n_pad
     return align_up(n_pad * (size_t)k * 2, 256) + align_up(nb * 8 * n_pad * 4, 256);
 }
 
-// Small batches of Q4_K / Q5_K / Q6_K (up to 32 tokens) on gemm_sb.hip, where it is the fastest route (MI355X, profiles/
-// r03_small_batch.txt; times in us for old -> new):
-//   deep rows (k > 8192, ffn_down)          : n >= 3   (n = 8: 45 -> 16.6 Q4_K, 66 -> 20.3 Q6_K; n = 32: 28 -> 25.8)
-//   at most one row tile per CU (m <= 8192) : n >= 5   (4096 x 4096: n = 8 14.4 -> 9.4, n = 32 16.9 -> 12.2)
-//   up to four row tiles per CU             : 6 <= n <= 24, not Q6_K   (14336 x 4096: n = 8 24.3 -> 16.4 on the 16-wave body)
-// Below that the multi-column GEMV is faster (one launch, no staging pass); taller matrices (output.weight) keep the GEMV /
-// the 128-token GEMM tiles.  The testing flags that force a GEMM body or the generic kernels keep their meaning.
+// Small batches of Q4_K / Q5_K / Q6_K (up to 32 tokens) on gemm_sb.hip, where it is the fastest route (MI355X; old -> new, us).
+// Q4_K up to 8 tokens runs the int8-MFMA body, whose time barely depends on the token count (profiles/r03_small_batch_i8.txt):
+//   4096 x 4096 7.8 .. 8.5 (GEMV: 6.6 at 2 tokens, 14.8 at 8), 14336 x 4096 ~ 13 (11.1 .. 24.6), 4096 x 14336 11.9 .. 13.3
+//   (15.4 .. 45.4), 128256 x 4096 51 .. 54 (58 .. 138): from 2 tokens on deep rows and tall matrices, 3 with several row tiles
+//   per CU, 4 with one.
+// The f16 bodies (Q5_K, Q6_K, 9 .. 32 tokens; profiles/r03_small_batch.txt):
+//   deep rows (k > 8192, ffn_down)          : n >= 3   (n = 8: 66 -> 20.3 Q6_K; n = 32: 28 -> 25.8)
+//   at most one row tile per CU (m <= 8192) : n >= 5   (4096 x 4096: n = 32 16.9 -> 12.2)
+//   up to four row tiles per CU             : 6 <= n <= 24, not Q6_K
+// Below that the multi-column GEMV is faster (one launch, no staging pass); taller matrices keep the GEMV / the 128-token GEMM
+// tiles.  The testing flags that force a GEMM body or the generic kernels keep their meaning.
 static bool use_gemm_sb(int Atype, long n, unsigned flags, long k, long m) {
     if (flags & (LFAMD_FLAG_FORCE_GENERIC | LFAMD_FLAG_GEMM_NARROW | LFAMD_FLAG_GEMM_WIDE | LFAMD_FLAG_GEMM_PLAIN))
         return false;
     if (!lfamd_gemm_sb_ok(Atype, k, n))
         return false;
+    static const bool force = getenv("LFAMD_SB_FORCE") != nullptr; // development: threshold sweeps
+    if (force)
+        return true;
+    const long tiles_per_cu = ((m + 31) / 32 + 255) / 256;
+    if (Atype == LFAMD_TYPE_Q4_K && n <= 8) // the int8 body
+        return k > 8192 || tiles_per_cu > 4 ? n >= 2 : tiles_per_cu > 1 ? n >= 3 : n >= 4;
     if (k > 8192)
         return n >= 3;
-    const long tiles_per_cu = ((m + 31) / 32 + 255) / 256;
     if (tiles_per_cu <= 1)
         return n >= 5;
     return tiles_per_cu <= 4 && Atype != LFAMD_TYPE_Q6_K && n >= 6 && n <= 24;
@@ -800,11 +809,12 @@ int lfamd_mul_mat_multi(int Atype, int count, const void *const *d_A, const long
     // several tokens (6 and more) on sibling matrices that all take the small-batch MFMA kernel (ffn_gate + ffn_up): the activations
     // are staged once, then one launch per matrix — 14336 x 4096 x 2 at 8 tokens: 39.8 us on the multi-column GEMV, 32.7 us as two
     // separate calls, less with the shared staging
-    if (count > 1 && n >= 6 && (Btype == LFAMD_TYPE_F32 || Btype == lfamd_vec_dot_type(Atype)) && b_row_bytes >= lfamd_row_size(Btype, k)) {
+    const bool i8_body = Atype == LFAMD_TYPE_Q4_K && n <= 8;
+    if (count > 1 && n >= (i8_body ? 4 : 6) && (Btype == LFAMD_TYPE_F32 || Btype == lfamd_vec_dot_type(Atype)) &&
+        b_row_bytes >= lfamd_row_size(Btype, k)) {
         bool all_sb = true;
-        for (int j = 0; j < count && all_sb; j++)
-            all_sb = m[j] > 8192 && ldc[j] >= m[j] && use_gemm_sb(Atype, n, flags, k, m[j]); // (small siblings — attn_k / attn_v — are
-                                                                                          // faster on the fused GEMV: 14.9 vs 16.2 us)
+        for (int j = 0; j < count && all_sb; j++) // (small siblings — attn_k / attn_v — are faster on the fused GEMV below 8 tokens)
+            all_sb = (m[j] > 8192 || (i8_body && n >= 8)) && ldc[j] >= m[j] && use_gemm_sb(Atype, n, flags, k, m[j]);
         if (all_sb) {
             if (ws_bytes < align_up(lfamd_gemm_sb_workspace(k), 256) || !d_ws)
                 return fail(LFAMD_ERR_WORKSPACE, "mul_mat_multi: workspace too small%s", "");

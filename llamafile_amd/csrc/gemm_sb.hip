@@ -27,7 +27,9 @@
 
 // ---------------------------------------------------------------------------------------------------------------------
 // activation staging + zeroing of the result
-template <bool F32IN, bool MINS>
+// I8: the codes stay int8 and are written in the byte order of the int8 MFMA's weight operand (gemm_sb16i_kernel): sub-block
+// jb, K half h -> 16 bytes = K-step 2 jb: elements (0,4,1,5,2,6,3,7) of k = 32 jb + 8 h + j, then K-step 2 jb + 1 the same.
+template <bool F32IN, bool MINS, bool I8 = false>
 __global__ __launch_bounds__(64) void sb_prep_kernel(const uint8_t *__restrict__ B, size_t b_row_bytes, int n, int nb,
                                                       _Float16 *__restrict__ Xh, float *__restrict__ d8T, _Float16 *__restrict__ Xm,
                                                       float *__restrict__ C, long m, long ldc) {
@@ -82,8 +84,16 @@ __global__ __launch_bounds__(64) void sb_prep_kernel(const uint8_t *__restrict__
             q[e] = (int)(int8_t)(w >> (8 * e));
         d = y->d;
     }
-    const half4_t h4 = {(_Float16)(float)q[0], (_Float16)(float)q[1], (_Float16)(float)q[2], (_Float16)(float)q[3]};
-    *(half4_t *)(xo + 4 * t) = h4;
+    if constexpr (I8) {
+        // thread t holds k = 4 t + c: sub-block t >> 3, K-step half (t >> 2) & 1, K half (t >> 1) & 1, element j = 4 (t & 1) + c
+        int8_t *xq = (int8_t *)Xh + ((size_t)b * SB_COLS + tok) * 256 + (t >> 3) * 32 + ((t >> 1) & 1) * 16 + ((t >> 2) & 1) * 8 + (t & 1);
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+            xq[2 * c] = (int8_t)q[c];
+    } else {
+        const half4_t h4 = {(_Float16)(float)q[0], (_Float16)(float)q[1], (_Float16)(float)q[2], (_Float16)(float)q[3]};
+        *(half4_t *)(xo + 4 * t) = h4;
+    }
     if (t == 0)
         d8T[(size_t)b * SB_COLS + tok] = d;
     if constexpr (MINS) { // pair sum j = codes 32j .. 32j+31 = lanes 8j .. 8j+7; |S| <= 4096: S = 64 hi + lo, lo in [0, 63]
@@ -662,6 +672,152 @@ __global__ __launch_bounds__(1024) void gemm_sb16_kernel(const uint8_t *__restri
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The 16-wave body on the INT8 matrix cores (Q4_K, up to 16 tokens): `v_mfma_i32_32x32x32_i8` takes one 32-weight sub-block per
+// instruction, so the nibbles only have to become bytes (two ANDs and a shift per eight weights instead of the eleven VALU that
+// build an f16 fragment), the activation codes stay int8 (half the LDS and L2 bytes), a sub-block's sum is an exact int32 and
+// its 6-bit scale is applied with one `v_mad_i32_i24` per LIVE accumulator register (RL = 4 up to 8 tokens).  ≈ 110 VALU per
+// (tile, super-block) unit against ≈ 270 of the f16 body; same results class (exact integer dots, f32 scales: <= 2e-6).
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef int v16i_t __attribute__((ext_vector_type(16)));
+template <int KSPLIT, int RL>
+__global__ __launch_bounds__(1024) void gemm_sb16i_kernel(const uint8_t *__restrict__ A, long m, int nb, const int8_t *__restrict__ Xq,
+                                                          const float *__restrict__ d8T, const _Float16 *__restrict__ Xm, int n,
+                                                          float *__restrict__ C, long ldc, int n_rt) {
+    constexpr int TILE = P4K_TILE, NW = 16;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[]; // codes [nbl][n][256 B], then red [NW][RL][64] f32
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int i = lane & 31, h = lane >> 5;
+    const int kh = KSPLIT == 2 ? (int)(blockIdx.x & 1) : 0, wg = KSPLIT == 2 ? (int)(blockIdx.x >> 1) : (int)blockIdx.x;
+    const int n_wg = KSPLIT == 2 ? (int)(gridDim.x >> 1) : (int)gridDim.x;
+    const int half = KSPLIT == 2 ? (nb + 1) >> 1 : nb;
+    const int b0 = kh ? half : 0, b1 = kh ? nb : half, nbl = b1 - b0;
+    float *red = (float *)(lds + (size_t)nbl * n * 256);
+    for (int e = threadIdx.x; e < nbl * n * 16; e += 1024) { // 16-byte chunk c = 2 jb + h of row (bl, slot) at c ^ (slot & 15)
+        const int c = e & 15, row = e >> 4, bl = row / n, slot = row - bl * n;
+        const uint4 v = *(const uint4 *)(Xq + ((size_t)(b0 + bl) * SB_COLS + slot) * 256 + c * 16);
+        *(uint4 *)(lds + (size_t)row * 256 + ((c ^ (slot & 15)) << 4)) = v;
+    }
+    __syncthreads();
+    const int first = b0 + wave;
+    const int nmine = first < b1 ? (b1 - first + NW - 1) / NW : 0;
+    const int slot = i < n ? i : 0;
+    const uint32_t frag0 = (uint32_t)(slot * 256), sw = (uint32_t)(slot & 15);
+    const uint32_t xmoff = (uint32_t)(slot * 16 + 8 * h);
+    const float16_t_ zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const v16i_t zero16i = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+    u32x4_t qs[4], hd;
+    half8_t xm;
+    float4_t_ d8[(RL + 3) / 4];
+    int rt_n = wg, b_n = first;
+    const uint8_t *tile_n = A;
+    const _Float16 *xm_n = Xm;
+    const float *d8_n = d8T;
+    auto point = [&]() {
+        tile_n = A + ((size_t)rt_n * nb + b_n) * TILE;
+        xm_n = Xm + (size_t)b_n * SB_COLS * 16 + xmoff;
+        d8_n = d8T + (size_t)b_n * SB_COLS + 4 * h;
+    };
+    auto advance = [&]() {
+        int b2 = b_n + NW, rt2 = rt_n;
+        if (b2 >= b1)
+            b2 = first, rt2 = rt_n + n_wg;
+        if (rt2 < n_rt)
+            b_n = b2, rt_n = rt2;
+        point();
+    };
+    auto ld_qs = [&](int g) { qs[g] = __builtin_nontemporal_load((const u32x4_t *)(tile_n + g * 1024 + lane * 16)); };
+    auto ld_hd = [&]() { hd = __builtin_nontemporal_load((const u32x4_t *)(tile_n + P4K_HDR + i * 16)); };
+    auto ld_d8 = [&]() {
+#pragma unroll
+        for (int r4 = 0; r4 < (RL + 3) / 4; r4++)
+            d8[r4] = *(const float4_t_ *)(d8_n + 8 * r4);
+    };
+    if (nmine > 0) {
+        point();
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+            ld_qs(g);
+        ld_hd();
+        xm = *(const half8_t *)xm_n;
+        ld_d8();
+    }
+    for (int rt = wg; rt < n_rt; rt += n_wg) {
+        float acc[RL];
+#pragma unroll
+        for (int r = 0; r < RL; r++)
+            acc[r] = 0.0f;
+        int b = first;
+        for (int j = 0; j < nmine; j++, b += NW) {
+            const uint8_t *fr = lds + (size_t)(b - b0) * n * 256 + frag0; // this lane's code row of super-block b
+            advance();
+            const float d = h2f((uint16_t)(hd.x & 0xffff)), dmin = h2f((uint16_t)(hd.x >> 16));
+            uint32_t sc03, sc47, mn03, mn47;
+            q4k_scales_bytes(hd.y, hd.z, hd.w, sc03, sc47, mn03, mn47);
+            ld_hd();
+            int sumi[RL];
+#pragma unroll
+            for (int r = 0; r < RL; r++)
+                sumi[r] = 0;
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const uint32_t qw[4] = {qs[g].x, qs[g].y, qs[g].z, qs[g].w};
+                ld_qs(g);
+#pragma unroll
+                for (int e = 0; e < 2; e++) { // sub-block jb = 2 g + e: K-steps 4 g + 2 e, + 1
+                    const int jb = 2 * g + e;
+                    const uint32_t x0 = qw[2 * e], x1 = qw[2 * e + 1];
+                    const v4i_t wv = {(int)(x0 & 0x0F0F0F0Fu), (int)((x0 >> 4) & 0x0F0F0F0Fu), (int)(x1 & 0x0F0F0F0Fu), (int)((x1 >> 4) & 0x0F0F0F0Fu)};
+                    const v4i_t av = *(const v4i_t *)(fr + ((((uint32_t)(2 * jb) + (uint32_t)h) ^ sw) << 4));
+                    const v16i_t p = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, wv, zero16i, 0, 0, 0);
+                    const int sc = (int)(((jb < 4 ? sc03 : sc47) >> (8 * (jb & 3))) & 0xff);
+#pragma unroll
+                    for (int r = 0; r < RL; r++)
+                        sumi[r] += __mul24(p[r], sc); // (|p| <= 15 * 127 * 32, sc <= 63: 24-bit operands)
+                }
+            }
+            frag_u wm;
+            const float mscale = h ? 64.0f : 1.0f;
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                const uint32_t mw = p < 2 ? mn03 : mn47;
+                const float m0 = (float)((mw >> (16 * (p & 1))) & 0xff), m1 = (float)((mw >> (16 * (p & 1) + 8)) & 0xff);
+                const half2_t v = {(_Float16)(m0 * mscale), (_Float16)(m1 * mscale)};
+                wm.p[p] = v;
+            }
+            const float16_t_ tm = __builtin_amdgcn_mfma_f32_32x32x16_f16(xm, wm.v, zero16, 0, 0, 0);
+            xm = *(const half8_t *)xm_n;
+#pragma unroll
+            for (int r = 0; r < RL; r++) {
+                const float u = fmaf(-dmin, tm[r], d * (float)sumi[r]);
+                acc[r] = fmaf(u, d8[r >> 2][r & 3], acc[r]);
+            }
+            ld_d8();
+        }
+#pragma unroll
+        for (int r = 0; r < RL; r++)
+            red[(wave * RL + r) * 64 + lane] = acc[r];
+        __syncthreads();
+        for (int v = threadIdx.x; v < RL * 64; v += 1024) {
+            const int r = v >> 6, l = v & 63;
+            const int tok = 8 * (r >> 2) + 4 * (l >> 5) + (r & 3);
+            const long row = (long)rt * 32 + (l & 31);
+            if (tok < n && row < m) {
+                float s = 0.0f;
+#pragma unroll
+                for (int w = 0; w < NW; w++)
+                    s += red[(w * RL + r) * 64 + l];
+                if constexpr (KSPLIT == 2)
+                    unsafeAtomicAdd(C + (long)tok * ldc + row, s);
+                else
+                    C[(long)tok * ldc + row] = s;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 static int lfamd_num_cus() {
     static int cus = 0;
     if (!cus) {
@@ -707,10 +863,22 @@ hipError_t lfamd_launch_gemm_sb(int Atype, const void *A, long m, long k, int Bt
     int ksplit = 0;
     // (measured, profiles/r03_small_batch16.txt: a gain only where a work-group walks several tiles — 14336 x 4096 n = 8: 20.5 -> 16.4 us;
     //  with one tile per work-group the two-launch latency chain dominates and the 8-wave bodies are as fast)
-    if (mins && n <= 16 && !no16 && (m + 31) / 32 > lfamd_num_cus()) {
+    static const bool no_i8 = getenv("LFAMD_SB_NO_I8") != nullptr; // development: A/B against the f16 bodies
+    // Q4_K up to 8 tokens: the int8 form of the 16-wave body, on every shape (14336 x 4096: 16.6 -> 13.2 us, 4096 x 14336: 16.4 -> 13.4,
+    // 8192 x 4096: 15.1 -> 10.6, 4096 x 4096: 9.1 -> 8.5); the f16 form (Q5_K, 9 .. 16 tokens) only where a work-group walks several
+    // tiles (profiles/r03_small_batch16.txt)
+    const bool i8_ok = Atype == LFAMD_TYPE_Q4_K && n <= 8 && !no_i8;
+    if (mins && n <= 16 && !no16 && ((m + 31) / 32 > lfamd_num_cus() || i8_ok)) {
         if ((size_t)nb * n * 512 + red_bytes <= 150 * 1024 && nb <= 16)
             ksplit = 1;
         else if ((size_t)((nb + 1) / 2) * n * 512 + red_bytes <= 150 * 1024)
+            ksplit = 2;
+    }
+    const bool i8 = ksplit && i8_ok; // (the 16-token form of the int8 body spills at 128 VGPRs: f16 body there)
+    if (i8) { // int8 codes need half the LDS: whole rows of K fit where the f16 body splits
+        if ((size_t)nb * n * 256 + red_bytes <= 150 * 1024 && nb <= 16)
+            ksplit = 1;
+        else if ((size_t)((nb + 1) / 2) * n * 256 + red_bytes <= 150 * 1024)
             ksplit = 2;
     }
     float *Czero = ksplit == 1 ? nullptr : C;
@@ -719,7 +887,12 @@ hipError_t lfamd_launch_gemm_sb(int Atype, const void *A, long m, long k, int Bt
         if (!Czero)
             goto staged;
     }
-    if (Btype == LFAMD_TYPE_F32) {
+    if (i8) {
+        if (Btype == LFAMD_TYPE_F32)
+            sb_prep_kernel<true, true, true><<<pg, 64, 0, s>>>((const uint8_t *)B, b_row_bytes, (int)n, nb, Xh, d8T, Xm, Czero, m, ldc);
+        else
+            sb_prep_kernel<false, true, true><<<pg, 64, 0, s>>>((const uint8_t *)B, b_row_bytes, (int)n, nb, Xh, d8T, Xm, Czero, m, ldc);
+    } else if (Btype == LFAMD_TYPE_F32) {
         if (mins)
             sb_prep_kernel<true, true><<<pg, 64, 0, s>>>((const uint8_t *)B, b_row_bytes, (int)n, nb, Xh, d8T, Xm, Czero, m, ldc);
         else
@@ -750,6 +923,19 @@ staged:
             kernel<<<g16, 1024, smem, s>>>((const uint8_t *)A, m, nb, Xh, d8T, Xm, (int)n, C, ldc, n_rt);
             return hipGetLastError();
         };
+        if (i8) {
+            const size_t smem8 = (size_t)(ksplit == 1 ? nb : (nb + 1) / 2) * n * 256 + red_bytes;
+            auto go8 = [&](auto kernel) {
+                if (smem8 > 64 * 1024) {
+                    hipError_t e2 = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem8);
+                    if (e2 != hipSuccess)
+                        return e2;
+                }
+                kernel<<<g16, 1024, smem8, s>>>((const uint8_t *)A, m, nb, (const int8_t *)Xh, d8T, Xm, (int)n, C, ldc, n_rt);
+                return hipGetLastError();
+            };
+            return ksplit == 1 ? go8(gemm_sb16i_kernel<1, 4>) : go8(gemm_sb16i_kernel<2, 4>);
+        }
         const bool q5 = Atype == LFAMD_TYPE_Q5_K;
         if (ksplit == 1)
             return rl == 4 ? (q5 ? go(gemm_sb16_kernel<LFAMD_TYPE_Q5_K, 1, 4>) : go(gemm_sb16_kernel<LFAMD_TYPE_Q4_K, 1, 4>))

@@ -327,7 +327,10 @@ def test_mul_mat_multi_equals_separate(gpu, t, n):
     fused = gpu.mul_mat_multi(Ws, x.view(torch.uint8), T.F32, n=n)
     for W, f in zip(Ws, fused):
         sep = gpu.mul_mat(W, x.view(torch.uint8), T.F32, n=n)
-        assert np.array_equal(f.cpu().numpy().view(np.uint32), sep.cpu().numpy().view(np.uint32))
+        if n == 1 or n > 8:
+            assert np.array_equal(f.cpu().numpy().view(np.uint32), sep.cpu().numpy().view(np.uint32))
+        else:  # a few tokens: a lone matrix may take the small-batch MFMA kernel where the group stays on the fused GEMV
+            assert rel_err(f.cpu().numpy(), sep.cpu().numpy()) <= 2e-6  # (exact integer dots, f32 scales either way)
 
 
 @pytest.mark.parametrize("n", [6, 8, 16])
