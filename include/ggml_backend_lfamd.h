@@ -168,7 +168,11 @@ struct ggml_cuda_device_properties {
     char compute[8];
 };
 
-/* ---- the 12 symbols llamafile/cuda.c:726-737 imports ---- */
+/* ---- the 12 symbols llamafile/cuda.c:726-737 imports ----
+ * `device` is a LOGICAL device: 0 .. ggml_backend_cuda_get_device_count() - 1, every gfx950 device of the process unless
+ * LFAMD_BACKEND_DEVICES (comma list of HIP ordinals, repeats allowed) says otherwise.  ggml_backend_cuda_split_buffer_type is
+ * the reference's row split (ggml-cuda.cu.patch:17123-17450) when there is more than one device, the first device's ordinary
+ * buffer type otherwise; tensor_split holds GGML_CUDA_MAX_DEVICES = 16 proportions (all zero / NULL: equal shares). */
 GGML_CALL bool ggml_cuda_link(const struct ggml_backend_api *backend_api);
 GGML_CALL ggml_backend_buffer_type_t ggml_backend_cuda_host_buffer_type(void);
 GGML_CALL ggml_backend_buffer_type_t ggml_backend_cuda_buffer_type(int device);

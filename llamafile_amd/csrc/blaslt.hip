@@ -20,7 +20,9 @@ namespace {
 
 struct lt_api {
     void *so = nullptr;
-    hipblasLtHandle_t handle = nullptr;
+    hipblasLtHandle_t handle = nullptr;      // of the device current at load time
+    hipblasLtHandle_t per_device[32] = {};   // one handle per device (made with that device current, on first use there)
+    int first_device = 0;
     decltype(&hipblasLtCreate) Create = nullptr;
     decltype(&hipblasLtMatmulDescCreate) DescCreate = nullptr;
     decltype(&hipblasLtMatmulDescSetAttribute) DescSet = nullptr;
@@ -76,8 +78,11 @@ void load() {
           sym(a.so, "hipblasLtMatmulPreferenceDestroy", a.PrefDestroy) && sym(a.so, "hipblasLtMatmulAlgoGetHeuristic", a.Heuristic) &&
           sym(a.so, "hipblasLtMatmul", a.Matmul)))
         return;
+    if (hipGetDevice(&a.first_device) != hipSuccess || a.first_device < 0 || a.first_device >= 32)
+        return;
     if (a.Create(&a.handle) != HIPBLAS_STATUS_SUCCESS)
         return;
+    a.per_device[a.first_device] = a.handle;
     a.ok = true;
 }
 
@@ -187,6 +192,14 @@ hipError_t lfamd_blaslt_gemm(int dtype, const void *W, long ldw, const void *X, 
     if (!ws)
         ws_bytes = 0;
     std::lock_guard<std::mutex> lk(g_mu);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32)
+        return hipErrorInvalidDevice;
+    if (!a.per_device[dev] && a.Create(&a.per_device[dev]) != HIPBLAS_STATUS_SUCCESS) {
+        a.per_device[dev] = nullptr;
+        return hipErrorNotSupported;
+    }
+    const hipblasLtHandle_t handle = a.per_device[dev];
     const auto key = std::make_tuple(dtype, m, n, k, ldw, ldx, ldc * 2 + (ws_bytes ? 1 : 0));
     if (g_plans.size() >= 1024 && !g_plans.count(key)) { // (a KV cache as the A operand grows by a row per token: bound the cache)
         for (auto &kv : g_plans) {
@@ -216,7 +229,7 @@ hipError_t lfamd_blaslt_gemm(int dtype, const void *W, long ldw, const void *X, 
             a.LayoutCreate(&p.c, HIP_R_32F, (uint64_t)m, (uint64_t)n, ldc) == HIPBLAS_STATUS_SUCCESS &&
             a.PrefCreate(&pref) == HIPBLAS_STATUS_SUCCESS &&
             a.PrefSet(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &wsb, sizeof wsb) == HIPBLAS_STATUS_SUCCESS &&
-            a.Heuristic(a.handle, p.desc, p.a, p.b, p.c, p.c, pref, 8, res, &found) == HIPBLAS_STATUS_SUCCESS) {
+            a.Heuristic(handle, p.desc, p.a, p.b, p.c, p.c, pref, 8, res, &found) == HIPBLAS_STATUS_SUCCESS) {
             for (int r = 0; r < found && !p.ok; r++) // in order of increasing estimated time: the first that fits the workspace
                 if (res[r].state == HIPBLAS_STATUS_SUCCESS && res[r].workspaceSize <= ws_bytes) {
                     p.algo = res[r].algo;
@@ -241,7 +254,7 @@ hipError_t lfamd_blaslt_gemm(int dtype, const void *W, long ldw, const void *X, 
         return e;
     }
     const float one = 1.0f, zero = 0.0f;
-    const hipblasStatus_t st = a.Matmul(a.handle, p.desc, &one, W, p.a, X, p.b, &zero, C, p.c, C, p.c, &p.algo, ws, p.ws, s);
+    const hipblasStatus_t st = a.Matmul(handle, p.desc, &one, W, p.a, X, p.b, &zero, C, p.c, C, p.c, &p.algo, ws, p.ws, s);
     return st == HIPBLAS_STATUS_SUCCESS ? hipSuccess : hipErrorUnknown;
 }
 

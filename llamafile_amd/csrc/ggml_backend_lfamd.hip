@@ -9,6 +9,13 @@
 // Weights: the host's set_tensor delivers raw GGUF rows into the buffer; the first mat-mul that uses a tensor of a
 // WEIGHTS buffer packs it once into the module's layout (kept until the buffer is freed or the tensor rewritten); src0
 // of any other buffer (the KV cache as KQ / KQV operand) is packed per call.
+//
+// Devices: one host process drives every gfx950 device it sees (LFAMD_BACKEND_DEVICES = comma list of HIP ordinals, or "all" =
+// the default; an ordinal may repeat, which is how one GPU rehearses two).  Each logical device has its own buffer type and
+// backend (llama.cpp --split-mode layer); ggml_backend_cuda_split_buffer_type is the ROW split of the reference
+// (ggml-cuda.cu.patch:17123-17450): a matrix's rows are cut at the tensor_split fractions, each device keeps and packs its
+// slice, and a MUL_MAT whose src0 lives there runs one product per device on that device's slice (the activations are copied
+// over, every device's columns of the result are copied back into dst on the device of the backend that runs the graph).
 #include "lfamd_device.h"
 #include "../../include/ggml_backend_lfamd.h"
 #include "../../include/lfamd_hip.h"
@@ -19,12 +26,28 @@
 
 #include <mutex>
 #include <unordered_map>
+#include <vector>
 
 namespace {
 
 const ggml_backend_api *g_api = nullptr;
 int g_op_mul_mat = -1, g_op_mul_mat_id = -1;
 bool g_linked = false;
+
+#define LFAMD_MAX_DEVS 16 // GGML_CUDA_MAX_DEVICES (ggml-cuda.h.patch: the length of llama.cpp's tensor_split array)
+int g_ndev = 0;
+int g_phys[LFAMD_MAX_DEVS]; // logical device -> HIP ordinal
+
+// makes a logical device current for the scope (and puts the caller's device back: ggml's threads own no device state here)
+struct on_device {
+    int prev = 0;
+    bool ok;
+    explicit on_device(int logical) {
+        (void)hipGetDevice(&prev);
+        ok = logical >= 0 && logical < g_ndev && hipSetDevice(g_phys[logical]) == hipSuccess;
+    }
+    ~on_device() { (void)hipSetDevice(prev); }
+};
 
 void logf(const char *fmt, const char *a = "", const char *b = "") {
     if (g_api && g_api->FLAG_log_disable && *g_api->FLAG_log_disable)
@@ -76,6 +99,17 @@ void drop_range(const uint8_t *lo, const uint8_t *hi) {
 struct buffer_ctx {
     void *base;
     size_t size;
+    int dev; // logical device
+};
+
+// what a row-split product needs on a device other than the one that runs the graph
+struct peer_scratch {
+    void *x = nullptr; // the activations, dense f32 rows
+    size_t x_cap = 0;
+    void *c = nullptr; // this device's columns of the result, dense
+    size_t c_cap = 0;
+    void *ws = nullptr;
+    size_t ws_cap = 0;
 };
 
 struct backend_ctx {
@@ -86,6 +120,7 @@ struct backend_ctx {
     size_t ws_cap = 0;
     void *plan = nullptr; // contiguous copy of a strided ids tensor
     size_t plan_cap = 0;
+    peer_scratch peer[LFAMD_MAX_DEVS];
 };
 
 bool grow(void *&p, size_t &cap, size_t need) {
@@ -110,24 +145,30 @@ GGML_CALL void buf_free(ggml_backend_buffer_t buffer) {
         std::lock_guard<std::mutex> lk(g_mu);
         drop_range((const uint8_t *)c->base, (const uint8_t *)c->base + c->size);
     }
-    (void)hipFree(c->base);
+    {
+        on_device d(c->dev);
+        (void)hipFree(c->base);
+    }
     delete c;
 }
 GGML_CALL void *buf_get_base(ggml_backend_buffer_t buffer) {
     return ((buffer_ctx *)buffer->context)->base;
 }
 GGML_CALL void buf_init_tensor(ggml_backend_buffer_t, struct ggml_tensor *) {}
-GGML_CALL void buf_set_tensor(ggml_backend_buffer_t, struct ggml_tensor *tensor, const void *data, size_t offset, size_t size) {
+GGML_CALL void buf_set_tensor(ggml_backend_buffer_t buffer, struct ggml_tensor *tensor, const void *data, size_t offset, size_t size) {
+    on_device d(((buffer_ctx *)buffer->context)->dev);
     (void)hipMemcpy((uint8_t *)tensor->data + offset, data, size, hipMemcpyHostToDevice);
     std::lock_guard<std::mutex> lk(g_mu); // the tensor's packed copies are stale now
     drop_range((const uint8_t *)tensor->data, (const uint8_t *)tensor->data + g_api->ggml_nbytes(tensor));
 }
-GGML_CALL void buf_get_tensor(ggml_backend_buffer_t, const struct ggml_tensor *tensor, void *data, size_t offset, size_t size) {
+GGML_CALL void buf_get_tensor(ggml_backend_buffer_t buffer, const struct ggml_tensor *tensor, void *data, size_t offset, size_t size) {
+    on_device d(((buffer_ctx *)buffer->context)->dev);
     (void)hipMemcpy(data, (const uint8_t *)tensor->data + offset, size, hipMemcpyDeviceToHost);
 }
-GGML_CALL bool buf_cpy_tensor(ggml_backend_buffer_t, const struct ggml_tensor *src, struct ggml_tensor *dst) {
-    if (src->buffer && src->buffer->iface.get_name == buf_get_name) {
-        (void)hipMemcpy(dst->data, src->data, g_api->ggml_nbytes(src), hipMemcpyDeviceToDevice);
+GGML_CALL bool buf_cpy_tensor(ggml_backend_buffer_t buffer, const struct ggml_tensor *src, struct ggml_tensor *dst) {
+    if (src->buffer && src->buffer->iface.get_name == buf_get_name) { // (either device's memory: unified addressing)
+        on_device d(((buffer_ctx *)buffer->context)->dev);
+        (void)hipMemcpy(dst->data, src->data, g_api->ggml_nbytes(src), hipMemcpyDefault);
         std::lock_guard<std::mutex> lk(g_mu);
         drop_range((const uint8_t *)dst->data, (const uint8_t *)dst->data + g_api->ggml_nbytes(dst));
         return true;
@@ -136,6 +177,7 @@ GGML_CALL bool buf_cpy_tensor(ggml_backend_buffer_t, const struct ggml_tensor *s
 }
 GGML_CALL void buf_clear(ggml_backend_buffer_t buffer, uint8_t value) {
     buffer_ctx *c = (buffer_ctx *)buffer->context;
+    on_device d(c->dev);
     (void)hipMemset(c->base, value, c->size);
     (void)hipDeviceSynchronize();
     std::lock_guard<std::mutex> lk(g_mu); // every packed copy made from this buffer's bytes is stale now
@@ -149,12 +191,14 @@ GGML_CALL const char *buft_get_name(ggml_backend_buffer_type_t) {
     return "ROCm-lfamd";
 }
 GGML_CALL ggml_backend_buffer_t buft_alloc(ggml_backend_buffer_type_t buft, size_t size) {
+    const int dev = (int)(intptr_t)buft->context;
+    on_device d(dev);
     void *p = nullptr;
-    if (hipMalloc(&p, size ? size : 256) != hipSuccess) {
+    if (!d.ok || hipMalloc(&p, size ? size : 256) != hipSuccess) {
         logf("%s: allocating a device buffer failed\n", "ggml_backend_lfamd");
         return nullptr;
     }
-    buffer_ctx *c = new buffer_ctx{p, size};
+    buffer_ctx *c = new buffer_ctx{p, size, dev};
     return g_api->ggml_backend_buffer_init(buft, k_buffer_iface, c, size);
 }
 GGML_CALL size_t buft_alignment(ggml_backend_buffer_type_t) {
@@ -169,46 +213,202 @@ GGML_CALL size_t buft_alloc_size(ggml_backend_buffer_type_t, const struct ggml_t
         size += g_api->ggml_row_size(tensor->type, 512 - ne0 % 512);
     return size;
 }
-ggml_backend_buffer_type g_buft = {{buft_get_name, buft_alloc, buft_alignment, nullptr, buft_alloc_size, nullptr}, nullptr};
+ggml_backend_buffer_type g_bufts[LFAMD_MAX_DEVS]; // [logical device], context = its number (filled by ggml_cuda_link)
+
+
+// ------------------------------------------------------------------ row-split buffer type (--split-mode row)
+// Reference: ggml_backend_cuda_split_buffer_* (ggml-cuda.cu.patch:17123-17450).  Tensor data pointers inside such a buffer are
+// placeholders (the reference's 0x1000 base); the bytes live in one allocation per device, found through tensor->extra.
+struct split_buft_ctx {
+    float start[LFAMD_MAX_DEVS + 1]; // cumulative fractions: device d owns rows [start[d], start[d + 1]) x nrows
+};
+struct split_extra {
+    void *d[LFAMD_MAX_DEVS] = {};
+    long lo[LFAMD_MAX_DEVS + 1] = {}; // device d owns rows lo[d] .. lo[d + 1]
+    size_t row_bytes = 0;
+    size_t bytes[LFAMD_MAX_DEVS] = {};
+};
+struct split_buffer_ctx {
+    std::vector<split_extra *> extras;
+};
+std::mutex g_split_mu;
+std::vector<ggml_backend_buffer_type *> g_split_bufts; // one per distinct tensor_split (kept for the process' life, like the reference's map)
+
+// Matrices are cut by rows in multiples of 256 (whole row tiles of every packed layout); a tensor with more than one slice in
+// dims 2 / 3 (an expert stack) stays whole on the first device: MUL_MAT_ID routes per token, not per row range (the reference
+// refuses MUL_MAT_ID on split buffers outright, ggml-cuda.cu.patch:18501).
+void split_rows(const split_buft_ctx *sc, const struct ggml_tensor *t, long lo[LFAMD_MAX_DEVS + 1]) {
+    const long rows = (long)g_api->ggml_nrows(t);
+    const bool whole = t->ne[2] * t->ne[3] != 1;
+    lo[0] = 0;
+    for (int d = 1; d <= LFAMD_MAX_DEVS; d++) {
+        long r = d >= g_ndev || whole ? rows : (long)((double)sc->start[d] * (double)rows) / 256 * 256;
+        if (r > rows)
+            r = rows;
+        lo[d] = r < lo[d - 1] ? lo[d - 1] : r;
+    }
+}
+
+GGML_CALL const char *split_buf_get_name(ggml_backend_buffer_t) {
+    return "ROCm-lfamd_Split";
+}
+void split_free_extra(split_extra *e) {
+    for (int d = 0; d < g_ndev; d++)
+        if (e->d[d]) {
+            drop_range((const uint8_t *)e->d[d], (const uint8_t *)e->d[d] + e->bytes[d]);
+            on_device g(d);
+            (void)hipFree(e->d[d]);
+        }
+    delete e;
+}
+GGML_CALL void split_buf_free(ggml_backend_buffer_t buffer) {
+    split_buffer_ctx *c = (split_buffer_ctx *)buffer->context;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        for (split_extra *e : c->extras)
+            split_free_extra(e);
+    }
+    delete c;
+}
+GGML_CALL void *split_buf_get_base(ggml_backend_buffer_t) {
+    return (void *)0x1000; // placeholders for ggml-alloc's offsets; never dereferenced
+}
+GGML_CALL void split_buf_init_tensor(ggml_backend_buffer_t buffer, struct ggml_tensor *tensor) {
+    if (tensor->view_src) { // (the reference asserts: views of split tensors are not supported)
+        logf("%s: a view inside a row-split buffer is not supported\n", "ggml_backend_lfamd");
+        return;
+    }
+    split_buffer_ctx *c = (split_buffer_ctx *)buffer->context;
+    split_extra *e = new split_extra;
+    split_rows((const split_buft_ctx *)buffer->buft->context, tensor, e->lo);
+    e->row_bytes = tensor->nb[1];
+    for (int d = 0; d < g_ndev; d++) {
+        const long rows = e->lo[d + 1] - e->lo[d];
+        if (rows <= 0)
+            continue;
+        on_device g(d);
+        e->bytes[d] = (size_t)rows * e->row_bytes;
+        if (!g.ok || hipMalloc(&e->d[d], e->bytes[d] + 512) != hipSuccess) {
+            logf("%s: allocating a row slice failed\n", "ggml_backend_lfamd");
+            e->d[d] = nullptr;
+        }
+    }
+    c->extras.push_back(e);
+    tensor->extra = e;
+}
+GGML_CALL void split_buf_set_tensor(ggml_backend_buffer_t, struct ggml_tensor *tensor, const void *data, size_t offset, size_t size) {
+    split_extra *e = (split_extra *)tensor->extra;
+    if (!e || offset != 0 || size != g_api->ggml_nbytes(tensor)) { // whole tensors only (the reference asserts the same)
+        logf("%s: partial writes into a row-split tensor are not supported\n", "ggml_backend_lfamd");
+        return;
+    }
+    for (int d = 0; d < g_ndev; d++)
+        if (e->d[d]) {
+            on_device g(d);
+            (void)hipMemcpy(e->d[d], (const uint8_t *)data + (size_t)e->lo[d] * e->row_bytes, e->bytes[d], hipMemcpyHostToDevice);
+        }
+    std::lock_guard<std::mutex> lk(g_mu); // packed copies of the slices are stale now
+    for (int d = 0; d < g_ndev; d++)
+        if (e->d[d])
+            drop_range((const uint8_t *)e->d[d], (const uint8_t *)e->d[d] + e->bytes[d]);
+}
+GGML_CALL void split_buf_get_tensor(ggml_backend_buffer_t, const struct ggml_tensor *tensor, void *data, size_t offset, size_t size) {
+    const split_extra *e = (const split_extra *)tensor->extra;
+    if (!e || offset != 0 || size != g_api->ggml_nbytes(tensor)) {
+        logf("%s: partial reads of a row-split tensor are not supported\n", "ggml_backend_lfamd");
+        return;
+    }
+    for (int d = 0; d < g_ndev; d++)
+        if (e->d[d]) {
+            on_device g(d);
+            (void)hipMemcpy((uint8_t *)data + (size_t)e->lo[d] * e->row_bytes, e->d[d], e->bytes[d], hipMemcpyDeviceToHost);
+        }
+}
+GGML_CALL void split_buf_clear(ggml_backend_buffer_t buffer, uint8_t value) {
+    split_buffer_ctx *c = (split_buffer_ctx *)buffer->context;
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (split_extra *e : c->extras)
+        for (int d = 0; d < g_ndev; d++)
+            if (e->d[d]) {
+                on_device g(d);
+                (void)hipMemset(e->d[d], value, e->bytes[d]);
+                (void)hipDeviceSynchronize();
+                drop_range((const uint8_t *)e->d[d], (const uint8_t *)e->d[d] + e->bytes[d]);
+            }
+}
+const ggml_backend_buffer_i k_split_buffer_iface = {split_buf_get_name,   split_buf_free,       split_buf_get_base,
+                                                    split_buf_init_tensor, split_buf_set_tensor, split_buf_get_tensor,
+                                                    nullptr,              split_buf_clear,      nullptr};
+
+GGML_CALL const char *split_buft_get_name(ggml_backend_buffer_type_t) {
+    return "ROCm-lfamd_Split";
+}
+GGML_CALL ggml_backend_buffer_t split_buft_alloc(ggml_backend_buffer_type_t buft, size_t size) {
+    // the size ggml-alloc asks for is the sum of get_alloc_size over the tensors; the memory is allocated per tensor and
+    // device in init_tensor (like the reference, :17381-17389)
+    return g_api->ggml_backend_buffer_init(buft, k_split_buffer_iface, new split_buffer_ctx, size);
+}
+GGML_CALL size_t split_buft_alloc_size(ggml_backend_buffer_type_t, const struct ggml_tensor *tensor) {
+    return buft_alloc_size(nullptr, tensor) + 512 * (size_t)g_ndev; // (each slice carries its own tail padding)
+}
+bool is_split(const struct ggml_tensor *t) {
+    return t && t->buffer && t->buffer->iface.get_name == split_buf_get_name;
+}
+bool is_split_buft(ggml_backend_buffer_type_t buft) {
+    return buft && buft->iface.get_name == split_buft_get_name;
+}
 
 // ------------------------------------------------------------------ mat-mul nodes
 bool row_major(const struct ggml_tensor *t) { // elements of a row contiguous, rows / slices at any stride
     return t->nb[0] == g_api->ggml_type_size(t->type);
 }
 
-// packed device copy of the (i02, i03) slice of src0
-const packed *get_packed(backend_ctx *ctx, const struct ggml_tensor *a, int64_t i02, int64_t i03, packed *tmp) {
-    const uint8_t *raw = (const uint8_t *)a->data + i02 * a->nb[2] + i03 * a->nb[3];
-    const long rows = (long)a->ne[1], cols = (long)a->ne[0];
-    const size_t need = lfamd_packed_size(a->type, rows, cols);
-    const bool keep = a->buffer && g_api->ggml_backend_buffer_get_usage(a->buffer) == GGML_BACKEND_BUFFER_USAGE_WEIGHTS;
+// where a weight tensor's bytes are: its data pointer, or (a tensor of a row-split buffer that stayed whole) its first slice
+const uint8_t *weight_bytes(const struct ggml_tensor *a) {
+    return is_split(a) ? (a->extra ? (const uint8_t *)((const split_extra *)a->extra)->d[0] : nullptr) : (const uint8_t *)a->data;
+}
+
+// packed device copy of `rows` raw rows at `raw` (on the CURRENT device); kept under the raw address when `keep`
+const packed *get_packed_rows(void *&scratch, size_t &scratch_cap, int type, const uint8_t *raw, long rows, long cols, size_t row_bytes,
+                              bool keep, packed *tmp) {
+    const size_t need = lfamd_packed_size(type, rows, cols);
     if (keep) {
         auto it = g_packed.find(raw);
-        if (it != g_packed.end() && it->second.type == a->type && it->second.rows == rows && it->second.cols == cols &&
-            it->second.row_bytes == a->nb[1])
+        if (it != g_packed.end() && it->second.type == type && it->second.rows == rows && it->second.cols == cols &&
+            it->second.row_bytes == row_bytes)
             return &it->second;
     }
     packed p;
-    p.bytes = need, p.type = a->type, p.rows = rows, p.cols = cols, p.row_bytes = a->nb[1];
+    p.bytes = need, p.type = type, p.rows = rows, p.cols = cols, p.row_bytes = row_bytes;
     if (keep) {
         if (hipMalloc(&p.d, need ? need : 16) != hipSuccess)
             return nullptr;
     } else {
-        if (!grow(ctx->scratch, ctx->scratch_cap, need))
+        if (!grow(scratch, scratch_cap, need))
             return nullptr;
-        p.d = ctx->scratch;
+        p.d = scratch;
     }
-    if (lfamd_pack_weights(a->type, rows, cols, raw, a->nb[1], p.d, nullptr) != LFAMD_OK) {
+    if (lfamd_pack_weights(type, rows, cols, raw, row_bytes, p.d, nullptr) != LFAMD_OK) {
         if (keep)
             (void)hipFree(p.d);
         return nullptr;
     }
-    const int in_range = lfamd_scaled_gemm_ok(a->type, rows, cols, p.d, nullptr);
+    const int in_range = lfamd_scaled_gemm_ok(type, rows, cols, p.d, nullptr);
     p.exact_only = in_range == 0;
     if (keep)
         return &(g_packed[raw] = p);
     *tmp = p;
     return tmp;
+}
+
+// packed device copy of the (i02, i03) slice of src0
+const packed *get_packed(backend_ctx *ctx, const struct ggml_tensor *a, int64_t i02, int64_t i03, packed *tmp) {
+    const uint8_t *base = weight_bytes(a);
+    if (!base)
+        return nullptr;
+    const bool keep = a->buffer && g_api->ggml_backend_buffer_get_usage(a->buffer) == GGML_BACKEND_BUFFER_USAGE_WEIGHTS;
+    return get_packed_rows(ctx->scratch, ctx->scratch_cap, a->type, base + i02 * a->nb[2] + i03 * a->nb[3], (long)a->ne[1], (long)a->ne[0],
+                           a->nb[1], keep, tmp);
 }
 
 // The struct layouts this module reads (include/ggml_backend_lfamd.h, marked RECALLED: llama.cpp is not vendored in the reference
@@ -269,6 +469,74 @@ bool mul_mat_supported(const struct ggml_tensor *op) {
     return true;
 }
 
+// MUL_MAT with a row-split src0 (ggml_cuda_op_mul_mat with split = true, ggml-cuda.cu.patch:18060-18330): device d computes
+// columns lo[d] .. lo[d + 1] of every result row from ITS rows of the matrix.  The backend's own device reads the activations
+// and writes dst in place; every other device gets the activations copied over (f32: no device re-quantises differently), its
+// product is launched before anything is waited for (the devices run side by side), and its columns are then copied into dst.
+enum ggml_status run_mul_mat_split(backend_ctx *ctx, struct ggml_tensor *dst) {
+    const struct ggml_tensor *a = dst->src[0], *b = dst->src[1];
+    const split_extra *e = (const split_extra *)a->extra;
+    if (!e)
+        return GGML_STATUS_FAILED;
+    const long k = (long)a->ne[0], n = (long)b->ne[1];
+    const long ldc = (long)(dst->nb[1] / sizeof(float));
+    if (hipDeviceSynchronize() != hipSuccess) // the activations are complete before another device reads them
+        return GGML_STATUS_FAILED;
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (int64_t i13 = 0; i13 < b->ne[3]; i13++)
+        for (int64_t i12 = 0; i12 < b->ne[2]; i12++) {
+            const uint8_t *bp = (const uint8_t *)b->data + i12 * b->nb[2] + i13 * b->nb[3];
+            float *cp = (float *)((uint8_t *)dst->data + i12 * dst->nb[2] + i13 * dst->nb[3]);
+            for (int d = 0; d < g_ndev; d++) {
+                const long rows = e->lo[d + 1] - e->lo[d];
+                if (rows <= 0)
+                    continue;
+                if (!e->d[d])
+                    return GGML_STATUS_ALLOC_FAILED;
+                on_device g(d);
+                const bool own = d == ctx->device;
+                peer_scratch &ps = ctx->peer[d];
+                const void *B = bp;
+                size_t brb = b->nb[1];
+                float *C = cp + e->lo[d];
+                long c_ld = ldc;
+                if (!own) {
+                    if (!grow(ps.x, ps.x_cap, (size_t)n * k * 4) || !grow(ps.c, ps.c_cap, (size_t)n * rows * 4))
+                        return GGML_STATUS_ALLOC_FAILED;
+                    if (hipMemcpy2DAsync(ps.x, (size_t)k * 4, bp, b->nb[1], (size_t)k * 4, n, hipMemcpyDefault, nullptr) != hipSuccess)
+                        return GGML_STATUS_FAILED;
+                    B = ps.x, brb = (size_t)k * 4, C = (float *)ps.c, c_ld = rows;
+                }
+                packed tmp;
+                void *no_scratch = nullptr; // (split buffers hold weights: always kept)
+                size_t no_cap = 0;
+                const packed *w = get_packed_rows(no_scratch, no_cap, a->type, (const uint8_t *)e->d[d], rows, k, e->row_bytes, true, &tmp);
+                if (!w)
+                    return GGML_STATUS_ALLOC_FAILED;
+                void *&ws = own ? ctx->ws : ps.ws;
+                size_t &ws_cap = own ? ctx->ws_cap : ps.ws_cap;
+                if (!grow(ws, ws_cap, lfamd_mul_mat_workspace(a->type, rows, k, n)))
+                    return GGML_STATUS_ALLOC_FAILED;
+                if (lfamd_mul_mat(a->type, w->d, rows, k, LFAMD_TYPE_F32, B, brb, n, C, c_ld, ws, ws_cap,
+                                  (w->exact_only ? LFAMD_FLAG_PRECISE : 0u) | LFAMD_FLAG_Q0_VREGS32, nullptr) != LFAMD_OK) {
+                    logf("%s: lfamd_mul_mat (row slice): %s\n", "ggml_backend_lfamd", lfamd_last_error());
+                    return GGML_STATUS_FAILED;
+                }
+            }
+            for (int d = 0; d < g_ndev; d++) {
+                const long rows = e->lo[d + 1] - e->lo[d];
+                if (rows <= 0 || d == ctx->device)
+                    continue;
+                on_device g(d);
+                if (hipDeviceSynchronize() != hipSuccess ||
+                    hipMemcpy2D(cp + e->lo[d], (size_t)ldc * 4, ctx->peer[d].c, (size_t)rows * 4, (size_t)rows * 4, n, hipMemcpyDefault) !=
+                        hipSuccess)
+                    return GGML_STATUS_FAILED;
+            }
+        }
+    return GGML_STATUS_SUCCESS;
+}
+
 enum ggml_status run_mul_mat(backend_ctx *ctx, struct ggml_tensor *dst) {
     const struct ggml_tensor *a = dst->src[0], *b = dst->src[1];
     const long m = (long)a->ne[1], k = (long)a->ne[0], n = (long)b->ne[1];
@@ -277,6 +545,8 @@ enum ggml_status run_mul_mat(backend_ctx *ctx, struct ggml_tensor *dst) {
     // broadcast over dims 2 / 3 like ggml_compute_forward_mul_mat (upstream; ggml.c.patch:1942-2022): src1 slice (i12, i13)
     // uses src0 slice (i12 / r2, i13 / r3)
     const int64_t r2 = b->ne[2] / (a->ne[2] ? a->ne[2] : 1), r3 = b->ne[3] / (a->ne[3] ? a->ne[3] : 1);
+    if (is_split(a) && a->ne[2] * a->ne[3] == 1)
+        return run_mul_mat_split(ctx, dst);
     const size_t wsb = lfamd_mul_mat_workspace(a->type, m, k, n);
     if (!grow(ctx->ws, ctx->ws_cap, wsb))
         return GGML_STATUS_ALLOC_FAILED;
@@ -317,13 +587,16 @@ enum ggml_status run_mul_mat_id(backend_ctx *ctx, struct ggml_tensor *dst) {
     if (!rows || !tokens || !thinkers)
         return GGML_STATUS_SUCCESS;
     const size_t one = lfamd_packed_size(as->type, rows, cols);
+    const uint8_t *as_bytes = weight_bytes(as); // (an expert stack of a row-split buffer stays whole on the first device)
+    if (!as_bytes)
+        return GGML_STATUS_FAILED;
     std::lock_guard<std::mutex> lk(g_mu);
     // the whole expert stack packed back to back under the stack's address
     const packed *w = nullptr;
     packed tmp;
     {
         const bool keep = as->buffer && g_api->ggml_backend_buffer_get_usage(as->buffer) == GGML_BACKEND_BUFFER_USAGE_WEIGHTS;
-        auto it = g_packed.find(as->data);
+        auto it = g_packed.find(as_bytes);
         if (keep && it != g_packed.end() && it->second.type == as->type && it->second.rows == rows * experts && it->second.cols == cols) {
             w = &it->second;
         } else {
@@ -338,12 +611,12 @@ enum ggml_status run_mul_mat_id(backend_ctx *ctx, struct ggml_tensor *dst) {
                 p.d = ctx->scratch;
             }
             for (int e = 0; e < experts; e++)
-                if (lfamd_pack_weights(as->type, rows, cols, (const uint8_t *)as->data + (size_t)e * as->nb[2], as->nb[1],
+                if (lfamd_pack_weights(as->type, rows, cols, as_bytes + (size_t)e * as->nb[2], as->nb[1],
                                        (uint8_t *)p.d + (size_t)e * one, nullptr) != LFAMD_OK)
                     return GGML_STATUS_FAILED;
             p.exact_only = lfamd_scaled_gemm_ok(as->type, (long)experts * ((rows + 31) / 32) * 32, cols, p.d, nullptr) == 0;
             if (keep) {
-                w = &(g_packed[as->data] = p);
+                w = &(g_packed[as_bytes] = p);
             } else {
                 tmp = p;
                 w = &tmp;
@@ -378,24 +651,37 @@ GGML_CALL const char *be_get_name(ggml_backend_t) {
 }
 GGML_CALL void be_free(ggml_backend_t backend) {
     backend_ctx *c = (backend_ctx *)backend->context;
-    (void)hipDeviceSynchronize();
-    if (c->scratch)
-        (void)hipFree(c->scratch);
-    if (c->ws)
-        (void)hipFree(c->ws);
-    if (c->plan)
-        (void)hipFree(c->plan);
+    {
+        on_device d(c->device);
+        (void)hipDeviceSynchronize();
+        if (c->scratch)
+            (void)hipFree(c->scratch);
+        if (c->ws)
+            (void)hipFree(c->ws);
+        if (c->plan)
+            (void)hipFree(c->plan);
+    }
+    for (int i = 0; i < g_ndev; i++) {
+        on_device d(i);
+        for (void *p : {c->peer[i].x, c->peer[i].c, c->peer[i].ws})
+            if (p)
+                (void)hipFree(p);
+    }
     delete c;
     delete backend;
 }
-GGML_CALL ggml_backend_buffer_type_t be_default_buft(ggml_backend_t) {
-    return &g_buft;
+GGML_CALL ggml_backend_buffer_type_t be_default_buft(ggml_backend_t backend) {
+    return &g_bufts[((backend_ctx *)backend->context)->device];
 }
-GGML_CALL void be_synchronize(ggml_backend_t) {
+GGML_CALL void be_synchronize(ggml_backend_t backend) {
+    on_device d(((backend_ctx *)backend->context)->device);
     (void)hipDeviceSynchronize();
 }
 GGML_CALL enum ggml_status be_graph_compute(ggml_backend_t backend, struct ggml_cgraph *cgraph) {
     backend_ctx *c = (backend_ctx *)backend->context;
+    on_device on(c->device);
+    if (!on.ok)
+        return GGML_STATUS_FAILED;
     for (int i = 0; i < cgraph->n_nodes; i++) {
         struct ggml_tensor *node = cgraph->nodes[i];
         enum ggml_status st = GGML_STATUS_SUCCESS;
@@ -430,8 +716,8 @@ GGML_CALL bool be_supports_op(ggml_backend_t, const struct ggml_tensor *op) {
     return !strcmp(name, "NONE") || !strcmp(name, "RESHAPE") || !strcmp(name, "VIEW") || !strcmp(name, "PERMUTE") ||
            !strcmp(name, "TRANSPOSE");
 }
-GGML_CALL bool be_supports_buft(ggml_backend_t, ggml_backend_buffer_type_t buft) {
-    return buft == &g_buft;
+GGML_CALL bool be_supports_buft(ggml_backend_t backend, ggml_backend_buffer_type_t buft) {
+    return buft == &g_bufts[((backend_ctx *)backend->context)->device] || is_split_buft(buft);
 }
 GGML_CALL bool be_offload_op(ggml_backend_t, const struct ggml_tensor *) {
     return false; // weights live in this backend's buffers; nothing is pulled over per batch
@@ -478,20 +764,60 @@ GGML_CALL bool ggml_cuda_link(const struct ggml_backend_api *backend_api) {
             return false;
         }
     }
-    if (lfamd_device_count() <= 0 || lfamd_init(0) != LFAMD_OK) {
+    // the devices this process drives: LFAMD_BACKEND_DEVICES = "all" (default) or a comma list of HIP ordinals (an ordinal may
+    // repeat: two logical devices on one GPU, the single-GPU rehearsal of the multi-device paths); gfx950 only
+    const int visible = lfamd_device_count();
+    g_ndev = 0;
+    const char *want = backend_api->getenv ? backend_api->getenv("LFAMD_BACKEND_DEVICES") : nullptr;
+    auto add = [&](int ordinal) {
+        hipDeviceProp_t p;
+        if (ordinal < 0 || ordinal >= visible || g_ndev >= LFAMD_MAX_DEVS || hipGetDeviceProperties(&p, ordinal) != hipSuccess)
+            return;
+        if (strncmp(p.gcnArchName, "gfx950", 6) != 0)
+            return;
+        g_phys[g_ndev++] = ordinal;
+    };
+    if (want && *want && strcmp(want, "all") != 0) {
+        for (const char *q = want; *q;) {
+            char *end = nullptr;
+            const long v = strtol(q, &end, 10);
+            if (end == q)
+                break;
+            add((int)v);
+            q = *end == ',' ? end + 1 : end;
+            if (*end && *end != ',')
+                break;
+        }
+    } else {
+        for (int i = 0; i < visible; i++)
+            add(i);
+    }
+    if (g_ndev <= 0 || lfamd_init(g_phys[0]) != LFAMD_OK) {
+        g_ndev = 0;
         logf("%s: no MI355X (gfx950) device: %s\n", "ggml_cuda_link", lfamd_last_error());
         return false;
+    }
+    for (int i = 0; i < g_ndev; i++) {
+        g_bufts[i] = {{buft_get_name, buft_alloc, buft_alignment, nullptr, buft_alloc_size, nullptr}, (void *)(intptr_t)i};
+        on_device d(i); // peers read each other's buffers directly where the fabric allows (xGMI); copies work either way
+        for (int j = 0; j < g_ndev; j++)
+            if (g_phys[j] != g_phys[i]) {
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, g_phys[i], g_phys[j]) == hipSuccess && can)
+                    (void)hipDeviceEnablePeerAccess(g_phys[j], 0);
+                (void)hipGetLastError(); // (already enabled is not an error worth keeping)
+            }
     }
     g_linked = true;
     return true;
 }
 
 GGML_CALL int ggml_backend_cuda_get_device_count(void) {
-    return g_linked ? 1 : 0; // one backend per process and GPU (tensor parallelism: include/lfamd_hip.h, collectives)
+    return g_linked ? g_ndev : 0;
 }
 
 GGML_CALL ggml_backend_buffer_type_t ggml_backend_cuda_buffer_type(int device) {
-    if (device != 0 || !g_linked)
+    if (!g_linked || device < 0 || device >= g_ndev)
         return nullptr;
     // LFAMD_BACKEND_MATRICES_ONLY=1: the per-layer ("offload") buffer type is host memory, so that norm weights, the KV cache
     // and compute buffers stay with the CPU backend; matrices reach the device through the split buffer type below
@@ -500,19 +826,41 @@ GGML_CALL ggml_backend_buffer_type_t ggml_backend_cuda_buffer_type(int device) {
         const char *e = getenv("LFAMD_BACKEND_MATRICES_ONLY");
         return e && *e && *e != '0';
     }();
-    return matrices_only ? g_api->ggml_backend_cpu_buffer_type() : &g_buft;
+    return matrices_only ? g_api->ggml_backend_cpu_buffer_type() : &g_bufts[device];
 }
 
 GGML_CALL ggml_backend_buffer_type_t ggml_backend_cuda_host_buffer_type(void) {
     return g_api ? g_api->ggml_backend_cpu_buffer_type() : nullptr; // (plain host memory; uploads go through set_tensor)
 }
 
-GGML_CALL ggml_backend_buffer_type_t ggml_backend_cuda_split_buffer_type(const float *) {
-    return g_linked ? &g_buft : nullptr; // no row split: layers shard over processes
+GGML_CALL ggml_backend_buffer_type_t ggml_backend_cuda_split_buffer_type(const float *tensor_split) {
+    if (!g_linked)
+        return nullptr;
+    if (g_ndev == 1)
+        return &g_bufts[0]; // nothing to split over
+    // cumulative, normalised fractions (ggml-cuda.cu.patch:17432-17447); all zeros / NULL = equal shares
+    split_buft_ctx sc;
+    float sum = 0.0f;
+    for (int d = 0; tensor_split && d < g_ndev; d++)
+        sum += tensor_split[d] > 0.0f ? tensor_split[d] : 0.0f;
+    float run = 0.0f;
+    for (int d = 0; d <= LFAMD_MAX_DEVS; d++) {
+        sc.start[d] = d >= g_ndev ? 1.0f : sum > 0.0f ? run / sum : (float)d / (float)g_ndev;
+        if (d < g_ndev && sum > 0.0f)
+            run += tensor_split[d] > 0.0f ? tensor_split[d] : 0.0f;
+    }
+    std::lock_guard<std::mutex> lk(g_split_mu);
+    for (ggml_backend_buffer_type *t : g_split_bufts)
+        if (!memcmp(t->context, &sc, sizeof sc))
+            return t;
+    ggml_backend_buffer_type *t = new ggml_backend_buffer_type{
+        {split_buft_get_name, split_buft_alloc, buft_alignment, nullptr, split_buft_alloc_size, nullptr}, new split_buft_ctx(sc)};
+    g_split_bufts.push_back(t);
+    return t;
 }
 
 GGML_CALL ggml_backend_t ggml_backend_cuda_init(int device) {
-    if (!g_linked || device != 0)
+    if (!g_linked || device < 0 || device >= g_ndev)
         return nullptr;
     backend_ctx *c = new backend_ctx;
     c->device = device;
@@ -532,7 +880,7 @@ GGML_CALL int ggml_backend_cuda_reg_devices(void) {
 GGML_CALL void ggml_backend_cuda_get_device_properties(int device, struct ggml_cuda_device_properties *properties) {
     memset(properties, 0, sizeof *properties);
     hipDeviceProp_t p;
-    if (hipGetDeviceProperties(&p, device) != hipSuccess)
+    if (device < 0 || device >= g_ndev || hipGetDeviceProperties(&p, g_phys[device]) != hipSuccess)
         return;
     strncpy(properties->name, p.name, sizeof(properties->name) - 1);
     properties->totalGlobalMem = p.totalGlobalMem;
@@ -545,7 +893,7 @@ GGML_CALL void ggml_backend_cuda_get_device_properties(int device, struct ggml_c
 GGML_CALL void ggml_backend_cuda_get_device_memory(int device, size_t *free, size_t *total) {
     *free = *total = 0;
     int cur = 0;
-    if (hipGetDevice(&cur) != hipSuccess || hipSetDevice(device) != hipSuccess)
+    if (device < 0 || device >= g_ndev || hipGetDevice(&cur) != hipSuccess || hipSetDevice(g_phys[device]) != hipSuccess)
         return;
     (void)hipMemGetInfo(free, total);
     (void)hipSetDevice(cur);
@@ -562,7 +910,7 @@ GGML_CALL void ggml_backend_cuda_unregister_host_buffer(void *buffer) {
 
 GGML_CALL void ggml_backend_cuda_get_device_description(int device, char *description, size_t description_size) {
     hipDeviceProp_t p;
-    if (hipGetDeviceProperties(&p, device) == hipSuccess)
+    if (device >= 0 && device < g_ndev && hipGetDeviceProperties(&p, g_phys[device]) == hipSuccess)
         snprintf(description, description_size, "%s", p.name);
     else if (description_size)
         description[0] = 0;

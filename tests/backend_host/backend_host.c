@@ -166,7 +166,8 @@ int main(int argc, char **argv) {
         return 0;
     }
     if (!linked) { fprintf(stderr, "link failed\n"); return 5; }
-    if (reg_devices() != 1 || registered != 1) { fprintf(stderr, "reg_devices\n"); return 6; }
+    const int ndev = get_count();
+    if (ndev < 1 || reg_devices() != ndev || registered != ndev) { fprintf(stderr, "reg_devices\n"); return 6; }
     struct ggml_cuda_device_properties pr;
     get_props(0, &pr);
     size_t fr = 0, tot = 0;
@@ -176,9 +177,28 @@ int main(int argc, char **argv) {
     fprintf(stderr, "device: %s (%s) CUs=%d mem %zu / %zu MiB free; %s\n", pr.name, pr.compute, pr.multiProcessorCount, fr >> 20, tot >> 20, desc);
     if (strncmp(pr.compute, "gfx950", 6) || !tot) return 7;
 
-    ggml_backend_buffer_type_t buft = buffer_type(0);
-    ggml_backend_t be = backend_init(0);
+    /* BACKEND_HOST_MAIN: the logical device whose backend runs the graph (llama.cpp's main_gpu);
+       BACKEND_HOST_SPLIT="f0,f1,...": the weights go into ggml_backend_cuda_split_buffer_type(tensor_split) (--split-mode row) */
+    const int main_dev = getenv("BACKEND_HOST_MAIN") ? atoi(getenv("BACKEND_HOST_MAIN")) : 0;
+    if (buffer_type(ndev) || backend_init(ndev) || buffer_type(-1)) { fprintf(stderr, "a device past the count was served\n"); return 8; }
+    ggml_backend_buffer_type_t buft = buffer_type(main_dev);
+    ggml_backend_t be = backend_init(main_dev);
     if (!buft || !be) return 8;
+    ggml_backend_buffer_type_t wbuft = buft;
+    if (getenv("BACKEND_HOST_SPLIT")) {
+        ggml_backend_buffer_type_t GGML_CALL (*split_type)(const float *) = sym[4];
+        float fr[16] = {0};
+        int i = 0;
+        for (const char *q = getenv("BACKEND_HOST_SPLIT"); *q && i < 16; i++) {
+            char *end;
+            fr[i] = strtof(q, &end);
+            q = *end == ',' ? end + 1 : end;
+        }
+        wbuft = split_type(fr);
+        if (!wbuft || wbuft != split_type(fr)) { fprintf(stderr, "split buffer type\n"); return 8; }
+        if (ndev > 1 && (wbuft == buft || !be->iface.supports_buft(be, wbuft))) { fprintf(stderr, "split buffer type not served\n"); return 8; }
+        fprintf(stderr, "weights in %s\n", wbuft->iface.get_name(wbuft));
+    }
 
     struct ggml_tensor W, X, IDS, OUT;
     size_t nw, nx, ni = 0;
@@ -205,17 +225,25 @@ int main(int argc, char **argv) {
     if (h_nbytes(&W) != nw || h_nbytes(&X) != nx) { fprintf(stderr, "input size mismatch %zu %zu / %zu %zu\n", h_nbytes(&W), nw, h_nbytes(&X), nx); return 9; }
     /* a weights buffer and a compute buffer, tensors placed like ggml-alloc would (aligned offsets) */
     const size_t align = buft->iface.get_alignment(buft);
-    ggml_backend_buffer_t wbuf = buft->iface.alloc_buffer(buft, buft->iface.get_alloc_size(buft, &W) + align);
+    ggml_backend_buffer_t wbuf = wbuft->iface.alloc_buffer(wbuft, wbuft->iface.get_alloc_size(wbuft, &W) + align);
     const size_t xo = (h_nbytes(&X) + align - 1) / align * align, io = (ni + align - 1) / align * align;
     ggml_backend_buffer_t cbuf = buft->iface.alloc_buffer(buft, xo + io + h_nbytes(&OUT) + align);
     if (!wbuf || !cbuf) return 10;
     wbuf->usage = GGML_BACKEND_BUFFER_USAGE_WEIGHTS;
     W.buffer = wbuf, W.data = wbuf->iface.get_base(wbuf);
+    if (wbuf->iface.init_tensor)
+        wbuf->iface.init_tensor(wbuf, &W); /* (ggml-alloc calls it for every tensor it places) */
     uint8_t *cb = cbuf->iface.get_base(cbuf);
     X.buffer = cbuf, X.data = cb;
     IDS.buffer = cbuf, IDS.data = cb + xo;
     OUT.buffer = cbuf, OUT.data = cb + xo + io;
     wbuf->iface.set_tensor(wbuf, &W, hw, 0, nw);
+    if (getenv("BACKEND_HOST_SPLIT")) { /* a row-split tensor reads back as the bytes that were written */
+        void *back = malloc(nw);
+        wbuf->iface.get_tensor(wbuf, &W, back, 0, nw);
+        if (memcmp(back, hw, nw)) { fprintf(stderr, "split tensor read-back differs\n"); return 14; }
+        free(back);
+    }
     cbuf->iface.set_tensor(cbuf, &X, hx, 0, nx);
     if (hi)
         cbuf->iface.set_tensor(cbuf, &IDS, hi, 0, ni);

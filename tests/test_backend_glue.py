@@ -55,22 +55,7 @@ def test_matrices_only_switch_keeps_layer_buffers_on_the_host(gpu, host_exe):
         assert r.returncode == 0 and r.stdout.strip() == want, (r.stdout, r.stderr)
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("t,m,k,n,nb2", [(T.Q4_K, 96, 1024, 1, 1), (T.Q4_K, 160, 768, 40, 1), (T.Q6_K, 64, 512, 3, 2), (T.Q8_0, 72, 256, 1, 1),
-                                         (T.F16, 48, 256, 5, 3), (T.Q5_K, 32, 512, 12, 1), (T.Q4_0, 64, 256, 2, 1)],
-                         ids=lambda v: str(v))
-def test_mul_mat_node_through_the_backend_interface(gpu, oracle, host_exe, tmp_path, t, m, k, n, nb2):
-    """GGML_OP_MUL_MAT with f32 src1 and dims-2 broadcast (src1 has nb2 slices, src0 one): what
-    ggml_compute_forward_mul_mat computes — quantise src1 rows to the type's vec_dot format, llamafile_sgemm per slice."""
-    W = synth.random_weights(t, m, k, 7)
-    x = synth.random_activations(n * nb2, k, 8)
-    wp, xp, op = tmp_path / "w.bin", tmp_path / "x.bin", tmp_path / "o.bin"
-    W.tofile(wp)
-    x.tofile(xp)
-    r = subprocess.run([host_exe, _hip.HIP_SO, "mulmat", str(t), str(m), str(k), str(n), str(nb2), str(wp), str(xp), str(op)],
-                       capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stderr
-    got = np.fromfile(op, dtype=np.float32).reshape(nb2 * n, m)
+def check_mul_mat(oracle, got, t, W, x, m, k, n, nb2):
     bt = T.VEC_DOT[t]
     if t == T.F16:
         # ggml hands f16 weights their activations rounded to f16 (n > 2) or as f32 (n <= 2, tinyblas_cpu_sgemm.inc:121-136);
@@ -88,6 +73,25 @@ def test_mul_mat_node_through_the_backend_interface(gpu, oracle, host_exe, tmp_p
             assert np.array_equal(g.view(np.uint32), G.view(np.uint32))
         else:
             assert rel_err(g, G) <= (1e-3 if n > 8 else 2e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("t,m,k,n,nb2", [(T.Q4_K, 96, 1024, 1, 1), (T.Q4_K, 160, 768, 40, 1), (T.Q6_K, 64, 512, 3, 2), (T.Q8_0, 72, 256, 1, 1),
+                                         (T.F16, 48, 256, 5, 3), (T.Q5_K, 32, 512, 12, 1), (T.Q4_0, 64, 256, 2, 1)],
+                         ids=lambda v: str(v))
+def test_mul_mat_node_through_the_backend_interface(gpu, oracle, host_exe, tmp_path, t, m, k, n, nb2):
+    """GGML_OP_MUL_MAT with f32 src1 and dims-2 broadcast (src1 has nb2 slices, src0 one): what
+    ggml_compute_forward_mul_mat computes — quantise src1 rows to the type's vec_dot format, llamafile_sgemm per slice."""
+    W = synth.random_weights(t, m, k, 7)
+    x = synth.random_activations(n * nb2, k, 8)
+    wp, xp, op = tmp_path / "w.bin", tmp_path / "x.bin", tmp_path / "o.bin"
+    W.tofile(wp)
+    x.tofile(xp)
+    r = subprocess.run([host_exe, _hip.HIP_SO, "mulmat", str(t), str(m), str(k), str(n), str(nb2), str(wp), str(xp), str(op)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stderr
+    got = np.fromfile(op, dtype=np.float32).reshape(nb2 * n, m)
+    check_mul_mat(oracle, got, t, W, x, m, k, n, nb2)
 
 
 @pytest.mark.gpu
@@ -114,3 +118,61 @@ def test_mul_mat_id_node_through_the_backend_interface(gpu, oracle, host_exe, tm
     # (normwise over the whole result like the other batch tests: more than 4 tokens run the grouped MFMA launch on scaled
     # f16 operands, whose per-output error is ~7e-4 of the outputs' rms at k = 512)
     assert rel_err(got, G) <= (1e-3 if tokens > 4 else 2e-6)
+
+
+TWO = {"LFAMD_BACKEND_DEVICES": "0,0"}  # two logical devices on the one GPU of the box: the multi-device paths, rehearsed
+
+
+@pytest.mark.gpu
+def test_device_list_is_what_the_module_reports(gpu, host_exe):
+    """ggml_backend_cuda_get_device_count (ggml-cuda.cu.patch:19532): every gfx950 device of the process by default,
+    LFAMD_BACKEND_DEVICES restricts / repeats; ordinals that do not exist are dropped."""
+    for env, want in (({}, "count=1"), (TWO, "count=2"), ({"LFAMD_BACKEND_DEVICES": "0,7,0,0"}, "count=3"), ({"LFAMD_BACKEND_DEVICES": "9"}, "count=0")):
+        r = subprocess.run([host_exe, _hip.HIP_SO, "exports"], capture_output=True, text=True, timeout=120, env={**os.environ, **env})
+        assert r.returncode == 0 and r.stdout.split()[1] == want, (env, r.stdout, r.stderr)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("t,m,k,n,nb2,split,main", [(T.Q4_K, 1024, 512, 1, 1, "1,1", 0), (T.Q4_K, 1280, 512, 40, 1, "0.3,0.7", 1),
+                                                    (T.Q6_K, 768, 512, 3, 2, "1,1", 0), (T.Q8_0, 512, 256, 1, 1, "0,0", 1),
+                                                    (T.F16, 520, 256, 5, 1, "1,3", 0), (T.Q4_K, 96, 1024, 2, 1, "1,1", 0),
+                                                    (T.Q5_K, 512, 512, 12, 1, "1,0", 1)], ids=lambda v: str(v))
+def test_row_split_mul_mat_over_two_devices(gpu, oracle, host_exe, tmp_path, t, m, k, n, nb2, split, main):
+    """--split-mode row (ggml_backend_cuda_split_buffer_type, ggml-cuda.cu.patch:17123-17450; ggml_cuda_op_mul_mat with split
+    src0, :18060-18330): the matrix's rows are cut at the tensor_split fractions over the logical devices, each computes its
+    columns of the result, dst is assembled on the main device.  Same oracle, same tolerances as the one-device node; the host
+    program also checks set_tensor / get_tensor round-trip, clear() and the re-upload on the split buffer."""
+    W = synth.random_weights(t, m, k, 7)
+    x = synth.random_activations(n * nb2, k, 8)
+    wp, xp, op = tmp_path / "w.bin", tmp_path / "x.bin", tmp_path / "o.bin"
+    W.tofile(wp)
+    x.tofile(xp)
+    r = subprocess.run([host_exe, _hip.HIP_SO, "mulmat", str(t), str(m), str(k), str(n), str(nb2), str(wp), str(xp), str(op)],
+                       capture_output=True, text=True, timeout=300,
+                       env={**os.environ, **TWO, "BACKEND_HOST_SPLIT": split, "BACKEND_HOST_MAIN": str(main)})
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stderr
+    assert "weights in ROCm-lfamd_Split" in r.stderr
+    check_mul_mat(oracle, np.fromfile(op, dtype=np.float32).reshape(nb2 * n, m), t, W, x, m, k, n, nb2)
+
+
+@pytest.mark.gpu
+def test_expert_stack_in_a_split_buffer_stays_whole(gpu, oracle, host_exe, tmp_path):
+    """llama.cpp places expert tensors in the matrix buffer type too; the reference refuses MUL_MAT_ID there
+    (ggml-cuda.cu.patch:18501), this module keeps the stack whole on the first device and serves it."""
+    t, m, k, experts, thinkers, tokens, tasks = T.Q4_K, 64, 512, 6, 2, 3, 1
+    W = np.stack([synth.random_weights(t, m, k, 50 + e) for e in range(experts)])
+    x = synth.random_activations(tokens * tasks, k, 9).reshape(tokens, tasks, k)
+    rng = np.random.default_rng(4)
+    ids = np.stack([rng.permutation(experts)[:thinkers] for _ in range(tokens)]).astype(np.int32)
+    wp, xp, ip, op = (tmp_path / n for n in ("w.bin", "x.bin", "i.bin", "o.bin"))
+    W.tofile(wp), x.tofile(xp), ids.tofile(ip)
+    r = subprocess.run([host_exe, _hip.HIP_SO, "mulmatid", str(t), str(m), str(k), str(experts), str(thinkers), str(tasks), str(tokens),
+                        str(wp), str(xp), str(ip), str(op)], capture_output=True, text=True, timeout=300,
+                       env={**os.environ, **TWO, "BACKEND_HOST_SPLIT": "1,1"})
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stderr
+    got = np.fromfile(op, dtype=np.float32).reshape(tokens, thinkers, m)
+    q = oracle.quantize(T.Q8_K, x.reshape(-1, k))
+    for tk in range(tokens):
+        for th in range(thinkers):
+            ok, c = oracle.sgemm(t, W[ids[tk, th]], T.Q8_K, q[tk * tasks + th % tasks][None, :], m, 1, k)
+            assert ok == 1 and rel_err(got[tk, th], c[0]) <= 2e-6
