@@ -253,6 +253,14 @@ typedef struct lfamd_comm lfamd_comm;
 int lfamd_comm_unique_id(void *id128);
 int lfamd_comm_init(lfamd_comm **comm, int rank, int world, const void *id128);
 int lfamd_comm_destroy(lfamd_comm *comm);
+/* The single-process form (the shape of ncclCommInitAll): one host thread drives `ndev` devices,
+ * comms[i] is rank i on HIP device devices[i].  The exchange blocks are allocated here (fine-grained) and shared as plain
+ * pointers — nothing to export or attach —, every collective call below makes the rank's device current for its launch
+ * (and restores the caller's), and `stream` must be a stream of that device (or NULL).  Issue every rank's call before
+ * synchronising any of them.  RCCL communicators are added when the devices are distinct and the library has
+ * ncclCommInitAll; otherwise only messages up to max_message_bytes are served.  1 <= ndev <= 8; a device may repeat (how one
+ * GPU rehearses two).  Errors: LFAMD_ERR_INVALID (arguments), LFAMD_ERR_HIP (no device / no peer access / out of memory). */
+int lfamd_comm_init_all(lfamd_comm **comms, int ndev, const int *devices, size_t max_message_bytes);
 size_t lfamd_oneshot_bytes(size_t max_message_bytes);
 int lfamd_oneshot_alloc(void **d_block, size_t bytes);
 int lfamd_oneshot_free(void *d_block);

@@ -65,6 +65,7 @@ _SIGS = {
     "lfamd_comm_unique_id": (_i, [_vp]),
     "lfamd_comm_init": (_i, [C.POINTER(_vp), _i, _i, _vp]),
     "lfamd_comm_destroy": (_i, [_vp]),
+    "lfamd_comm_init_all": (_i, [C.POINTER(_vp), _i, C.POINTER(_i), _sz]),
     "lfamd_oneshot_bytes": (_sz, [_sz]),
     "lfamd_oneshot_alloc": (_i, [C.POINTER(_vp), _sz]),
     "lfamd_oneshot_free": (_i, [_vp]),

@@ -37,6 +37,7 @@ struct rccl_api {
     int (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t);
     int (*CommDestroy)(ncclComm_t);
     const char *(*GetErrorString)(int);
+    int (*CommInitAll)(ncclComm_t *, int, const int *); // optional (single-process form)
 } R;
 struct unique_id {
     char internal[128];
@@ -69,6 +70,7 @@ bool load_rccl() {
     SYM(CommDestroy, "ncclCommDestroy")
     SYM(GetErrorString, "ncclGetErrorString")
 #undef SYM
+    *(void **)&R.CommInitAll = dlsym(h, "ncclCommInitAll");
     R.dso = h;
     return true;
 }
@@ -99,6 +101,23 @@ struct lfamd_comm {
     size_t slot_bytes = 0;                  // one message slot (two slots: consecutive calls alternate)
     int *d_state = nullptr;                 // [0] error flag, [1 .. ONESHOT_WGS] per-work-group call counters
     long timeout_ticks = 400000000;         // 4 s of the 100 MHz wall clock (LFAMD_ONESHOT_TIMEOUT_S)
+    int device = -1;                        // >= 0: made by lfamd_comm_init_all (one process, several devices): the HIP device this
+                                            // rank's calls run on, the exchange block is the communicator's own, peers are plain pointers
+};
+
+// the single-process form launches each rank's kernels on that rank's device, whatever device the host thread has current
+struct comm_device {
+    int prev = -1;
+    explicit comm_device(const lfamd_comm *c) {
+        if (c->device >= 0 && hipGetDevice(&prev) == hipSuccess && prev != c->device)
+            (void)hipSetDevice(c->device);
+        else
+            prev = -1;
+    }
+    ~comm_device() {
+        if (prev >= 0)
+            (void)hipSetDevice(prev);
+    }
 };
 
 // exchange block: [flags: ONESHOT_MAX_WORLD x ONESHOT_WGS x 64 B][slot 0][slot 1]
@@ -194,6 +213,11 @@ __global__ __launch_bounds__(ONESHOT_THREADS) void oneshot_allreduce_kernel(cons
 
 extern "C" {
 
+int lfamd_oneshot_alloc(void **d_block, size_t bytes);
+int lfamd_oneshot_free(void *d_block);
+size_t lfamd_oneshot_bytes(size_t max_message_bytes);
+int lfamd_comm_destroy(lfamd_comm *c);
+
 int lfamd_comm_unique_id(void *id128) {
     if (!load_rccl())
         return LFAMD_ERR_UNSUPPORTED;
@@ -228,9 +252,12 @@ int lfamd_comm_init(lfamd_comm **out, int rank, int world, const void *id128) {
 int lfamd_comm_destroy(lfamd_comm *c) {
     if (!c)
         return LFAMD_OK;
+    comm_device on(c);
     for (int r = 0; r < c->world && r < ONESHOT_MAX_WORLD; r++)
-        if (c->peer[r] && r != c->rank)
+        if (c->peer[r] && r != c->rank && c->device < 0)
             (void)hipIpcCloseMemHandle(c->peer[r]);
+    if (c->device >= 0 && c->local)
+        (void)lfamd_oneshot_free(c->local);
     if (c->d_state)
         (void)hipFree(c->d_state);
     if (c->nccl)
@@ -349,6 +376,7 @@ int lfamd_comm_allreduce_add_f32(lfamd_comm *c, const float *d_partial, const fl
         return LFAMD_ERR_INVALID;
     }
     hipStream_t s = (hipStream_t)stream;
+    comm_device on(c);
     const bool aligned = (count & 3) == 0 && ((((uintptr_t)d_partial) | ((uintptr_t)d_out) | ((uintptr_t)d_residual)) & 15) == 0;
     if (c->local && aligned && (size_t)count * 4 <= c->slot_bytes) {
         oneshot_args a;
@@ -405,6 +433,7 @@ int lfamd_comm_allgather(lfamd_comm *c, const void *d_send, void *d_recv, size_t
         lfamd_set_error("lfamd_comm_allgather: no communicator");
         return LFAMD_ERR_INVALID;
     }
+    comm_device on(c);
     if (c->world == 1 && !c->nccl) {
         if (d_recv != d_send) {
             hipError_t e = hipMemcpyAsync(d_recv, d_send, bytes_per_rank, hipMemcpyDeviceToDevice, (hipStream_t)stream);
@@ -440,6 +469,96 @@ int lfamd_comm_allgather(lfamd_comm *c, const void *d_send, void *d_recv, size_t
     }
     int rc = R.AllGather(d_send, d_recv, bytes_per_rank, NCCL_INT8, c->nccl, (hipStream_t)stream);
     return rc ? nccl_fail(rc, "ncclAllGather") : LFAMD_OK;
+}
+
+// One process, several devices (one host thread, hipSetDevice per shard — ncclCommInitAll's shape): comms[i] is rank i of
+// world ndev on HIP device devices[i].  Every rank's exchange block is allocated here (fine-grained memory on its device) and
+// the peers hold each other's blocks as plain pointers (one address space: no IPC handles, no host barrier — the blocks are
+// zeroed and visible before this returns).  RCCL communicators are added when the library has ncclCommInitAll and the devices
+// are distinct; without them only messages that fit the one-shot slot are served.  A device may repeat (rehearsal on one GPU:
+// the ranks' kernels then run side by side on it, so issue every rank's call before waiting for any).
+int lfamd_comm_init_all(lfamd_comm **comms, int ndev, const int *devices, size_t max_message_bytes) {
+    if (!comms || !devices || ndev < 1 || ndev > ONESHOT_MAX_WORLD || !max_message_bytes) {
+        lfamd_set_error("lfamd_comm_init_all: 1 .. 8 devices, a list and a message size are needed");
+        return LFAMD_ERR_INVALID;
+    }
+    int visible = 0, prev = 0;
+    if (hipGetDeviceCount(&visible) != hipSuccess || visible <= 0) {
+        (void)hipGetLastError();
+        lfamd_set_error("lfamd_comm_init_all: no HIP device");
+        return LFAMD_ERR_HIP;
+    }
+    bool distinct = true;
+    for (int i = 0; i < ndev; i++) {
+        if (devices[i] < 0 || devices[i] >= visible) {
+            lfamd_set_error("lfamd_comm_init_all: device ordinal out of range");
+            return LFAMD_ERR_INVALID;
+        }
+        for (int j = 0; j < i; j++)
+            distinct = distinct && devices[j] != devices[i];
+    }
+    (void)hipGetDevice(&prev);
+    const size_t block = lfamd_oneshot_bytes(max_message_bytes);
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < ndev; i++)
+        comms[i] = nullptr;
+    for (int i = 0; i < ndev && e == hipSuccess; i++) {
+        lfamd_comm *c = new lfamd_comm;
+        comms[i] = c;
+        c->rank = i, c->world = ndev, c->device = devices[i];
+        e = hipSetDevice(devices[i]);
+        void *p = nullptr;
+        if (e == hipSuccess && lfamd_oneshot_alloc(&p, block) != LFAMD_OK)
+            e = hipErrorOutOfMemory;
+        c->local = (uint8_t *)p;
+        if (e == hipSuccess)
+            e = hipMemset(p, 0, ONESHOT_FLAGS_BYTES);
+        if (e == hipSuccess)
+            e = hipMalloc((void **)&c->d_state, (1 + ONESHOT_WGS) * sizeof(int));
+        if (e == hipSuccess)
+            e = hipMemset(c->d_state, 0, (1 + ONESHOT_WGS) * sizeof(int));
+        if (e == hipSuccess)
+            e = hipDeviceSynchronize();
+        for (int j = 0; j < ndev && e == hipSuccess; j++) // peers' blocks are read and written from this device's kernels
+            if (devices[j] != devices[i]) {
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, devices[i], devices[j]) != hipSuccess || !can) {
+                    lfamd_set_error("lfamd_comm_init_all: the devices cannot access each other's memory");
+                    e = hipErrorPeerAccessUnsupported;
+                } else if (hipDeviceEnablePeerAccess(devices[j], 0) != hipSuccess) {
+                    (void)hipGetLastError(); // (already enabled)
+                }
+            }
+        c->slot_bytes = (max_message_bytes + 255) / 256 * 256;
+        if (const char *t = getenv("LFAMD_ONESHOT_TIMEOUT_S")) {
+            const double sec = atof(t);
+            if (sec > 0.0 && sec < 3600.0)
+                c->timeout_ticks = (long)(sec * 1e8);
+        }
+    }
+    if (e == hipSuccess) {
+        for (int i = 0; i < ndev; i++)
+            for (int r = 0; r < ndev; r++)
+                comms[i]->peer[r] = comms[r]->local;
+        if (distinct && ndev > 1 && load_rccl() && R.CommInitAll) {
+            ncclComm_t all[ONESHOT_MAX_WORLD] = {};
+            if (R.CommInitAll(all, ndev, devices) == 0)
+                for (int i = 0; i < ndev; i++)
+                    comms[i]->nccl = all[i];
+        }
+    }
+    (void)hipSetDevice(prev);
+    if (e != hipSuccess) {
+        if (e != hipErrorPeerAccessUnsupported)
+            lfamd_set_error(hipGetErrorString(e));
+        for (int i = 0; i < ndev; i++) {
+            if (comms[i])
+                (void)lfamd_comm_destroy(comms[i]);
+            comms[i] = nullptr;
+        }
+        return LFAMD_ERR_HIP;
+    }
+    return LFAMD_OK;
 }
 
 // forget a latched peer-lost error (after the host has dealt with it): the next one-shot calls wait for their peers again

@@ -81,3 +81,18 @@ def test_host_plugin_answers_false_without_a_gpu():
     assert lib.llamafile_sgemm_amd_available() == 0
     lib.llamafile_sgemm_amd_error.restype = C.c_char_p
     assert lib.llamafile_sgemm_amd_error()
+
+
+def test_single_process_communicators_decline_cleanly():
+    """lfamd_comm_init_all: bad arguments are refused; without a GPU it reports an error instead of crashing."""
+    import torch
+    lib = _hip.lib()
+    comms = (C.c_void_p * 9)()
+    devs = (C.c_int * 9)(*range(9))
+    assert lib.lfamd_comm_init_all(comms, 0, devs, 65536) != 0
+    assert lib.lfamd_comm_init_all(comms, 9, devs, 65536) != 0
+    assert lib.lfamd_comm_init_all(comms, 2, devs, 0) != 0
+    assert lib.lfamd_comm_init_all(None, 2, devs, 65536) != 0
+    if not torch.cuda.is_available():
+        assert lib.lfamd_comm_init_all(comms, 2, devs, 65536) != 0
+        assert all(c is None for c in comms[:2])

@@ -99,3 +99,50 @@ def test_two_ranks_hip_shards_and_oneshot_allreduce(gpu, oracle):
         assert ok == 1
         want = G + resid[:, rows]
         assert np.abs(out0[:, rows] - want).max() <= 2e-6 * np.abs(want).max()
+
+
+def test_single_process_communicators_over_one_device(gpu):
+    """lfamd_comm_init_all (the ncclCommInitAll shape SURVEY.md section 5.8 proposes: one host thread, a device per shard),
+    rehearsed with three ranks on cuda:0: every rank's call is issued from the one thread on its own stream, the kernels meet
+    in the shared exchange blocks, every rank gets the rank-order sum (+ its residual) bit-identically; consecutive calls
+    alternate the slots; all-gather through the same protocol; a message past the slot without RCCL is refused."""
+    import ctypes as C
+    import torch
+    from llamafile_amd import _hip
+    lib = _hip.lib()
+    world, count = 3, 4096
+    comms = (C.c_void_p * world)()
+    devs = (C.c_int * world)(0, 0, 0)
+    assert lib.lfamd_comm_init_all(comms, world, devs, 64 * 1024) == 0, lib.lfamd_last_error()
+    try:
+        g = torch.Generator().manual_seed(3)
+        parts = [torch.randn(count, generator=g).cuda() for _ in range(world)]
+        resid = [torch.randn(count, generator=g).cuda() for _ in range(world)]
+        streams = [torch.cuda.Stream() for _ in range(world)]
+        torch.cuda.synchronize()
+        want = []  # the kernel's order: residual, then the ranks' partials in rank order (f32)
+        for r in range(world):
+            w = resid[r].clone()
+            for p in parts:
+                w = w + p
+            want.append(w)
+        for rep in range(4):
+            outs = [torch.empty(count, device="cuda") for _ in range(world)]
+            for r in range(world):
+                assert lib.lfamd_comm_allreduce_add_f32(comms[r], parts[r].data_ptr(), resid[r].data_ptr(), outs[r].data_ptr(), count,
+                                                        streams[r].cuda_stream) == 0, lib.lfamd_last_error()
+            torch.cuda.synchronize()
+            for r in range(world):
+                assert lib.lfamd_comm_check(comms[r]) == 0
+                assert torch.equal(outs[r], want[r])
+        gath = [torch.empty(world * count, device="cuda") for _ in range(world)]
+        for r in range(world):
+            assert lib.lfamd_comm_allgather(comms[r], parts[r].data_ptr(), gath[r].data_ptr(), count * 4, streams[r].cuda_stream) == 0
+        torch.cuda.synchronize()
+        for r in range(world):
+            assert torch.equal(gath[r], torch.cat(parts))
+        big = torch.zeros(1 << 20, device="cuda")
+        assert lib.lfamd_comm_allreduce_sum_f32(comms[0], big.data_ptr(), big.numel(), None) != 0  # no RCCL over one device
+    finally:
+        for r in range(world):
+            lib.lfamd_comm_destroy(comms[r])
