@@ -217,6 +217,13 @@ class Runner:
                     else:
                         torch.distributed.all_reduce(outs[0])
                 continue
+            if (n == 1 and len(g) == 1 and only_type is None and self.collectives and o0.spec.shard == "cols" and self.comm is not None
+                    and getattr(self.comm, "fused_ok", False) and outs[0].numel() * 4 <= self.comm.oneshot_eff):
+                # decode attn_output: the product and the all-reduce of its partial in ONE launch (lfamd_mul_mat_allreduce)
+                self.comm.mul_mat_allreduce(o0.W, x, T.F32, residual=None, out=outs[0], partial=outs[0], workspace=b["ws"])
+                launches += 1
+                nops += 1
+                continue
             rc = L.lfamd_mul_mat_multi_types(len(g), t_arr, A_arr, m_arr, o0.k, T.F32, C.c_void_p(x.data_ptr()),
                                              x.stride(0) * 4, n, C_arr, m_arr, ws, wsn, self.flags, stream)
             if rc:
@@ -405,12 +412,44 @@ def make_comm(rank, world, same_device=False):
         if abs(float(big[0].item()) - world * (world + 1) / 2) > 1e-3 or abs(float(big[-1].item()) - world * (world + 1) / 2) > 1e-3:
             raise RuntimeError("RCCL all-reduce through the C ABI returned a wrong sum")
     comm.oneshot_eff = oneshot if (oneshot and world > 1 and "self-test failed" not in comm.mode) else 0
+    # the fused form (decode product + exchange in one launch): trusted only if it gives the two-launch form's bits here
+    comm.fused_ok = False
+    comm.fused_test = "not run"
+    if comm.oneshot_eff and not os.environ.get("LFAMD_NO_FUSED_EXCHANGE"):
+        from llamafile_amd import sgemm, synth
+        m_t, k_t = 4096, 1024
+        Wt = sgemm.upload_weights(T.Q4_K, synth.random_weights(T.Q4_K, m_t, k_t, 900 + rank), m_t, k_t)
+        bad = 0
+        for it in range(8):
+            if it % 4 == 3:
+                time.sleep(1e-3 * rank)
+            xt = torch.from_numpy(synth.random_activations(1, k_t, 950 + 8 * rank + it)).cuda()
+            two = sgemm.mul_mat(Wt, xt.view(torch.uint8).view(1, k_t * 4), T.F32, n=1)
+            comm.allreduce_add(two)
+            one = comm.mul_mat_allreduce(Wt, xt, T.F32)
+            torch.cuda.synchronize()
+            if not torch.equal(one, two):
+                bad += 1
+        good = comm.check() == 0 and bad == 0
+        flag = torch.tensor([1 if good else 0])
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+        comm.fused_ok = bool(int(flag.item()))
+        comm.fused_test = "passed 8/8 on every rank" if comm.fused_ok else f"FAILED ({bad}/8 differ on rank {rank}) -> two launches"
+        # Used only on request: in the one measurement this lease allows (two ranks sharing one GPU) the fused form is SLOWER,
+        # 1.612 against 1.547 ms per decode pass (profiles/r03_fused_exchange_rehearsal.json) — every work-group pays a store
+        # acknowledgement and an atomic before it retires, which costs what the saved launch boundary gives
+        comm.fused_use = comm.fused_ok and bool(os.environ.get("LFAMD_FUSED_EXCHANGE"))
+        comm.fused_ok = comm.fused_use
+        if not good:
+            comm.clear_error()
     rccl_on = use_rccl or "self-test failed" in comm.mode
     comm.describe = lambda: (
         (f"all-reduce <= {comm.oneshot_eff} B: one-shot peer kernel in fine-grained memory (self-test {comm.selftest}); " if comm.oneshot_eff else "")
         + ("larger all-reduces and the logits all-gather: ncclAllReduce / ncclAllGather (RCCL, known-answer check passed)" if rccl_on
            else "no RCCL (ranks share a device): every size on the one-shot kernel")
-        + ", through the C ABI")
+        + ", through the C ABI"
+        + (f"; decode attn_output product + exchange in one launch: self-test {comm.fused_test}, "
+           + ("in use" if getattr(comm, "fused_use", False) else "not used (LFAMD_FUSED_EXCHANGE=1 turns it on)") if comm.fused_test != "not run" else ""))
     comm.has_rccl = use_rccl or "self-test failed" in comm.mode
     comm.oneshot = oneshot if "self-test failed" not in comm.mode else 0
     return comm

@@ -272,6 +272,16 @@ int lfamd_comm_allreduce_add_f32(lfamd_comm *comm, const float *d_partial, const
                                  void *stream);
 int lfamd_comm_allreduce_sum_f32(lfamd_comm *comm, float *d_inout, long count, void *stream);
 int lfamd_comm_allgather(lfamd_comm *comm, const void *d_send, void *d_recv, size_t bytes_per_rank, void *stream);
+/* The decode step of a column-sharded matrix (attn_output / ffn_down) with its exchange in ONE launch:
+ *   d_out = (d_residual ? d_residual : 0) + sum over ranks of (A_rank . b_rank);   d_partial: m floats of scratch
+ * b = one activation row (Btype f32, or the vec-dot type of Atype).  Fused — the product's last work-group to finish runs
+ * the one-shot exchange — when the one-shot path is attached, m * 4 fits its slot, m % 4 == 0 and Atype is Q4_K / Q5_K /
+ * Q6_K; otherwise lfamd_mul_mat + lfamd_comm_allreduce_add_f32.  Bit-identical either way (and on every rank);
+ * LFAMD_NO_FUSED_EXCHANGE=1 forces the two launches.  Replaces the peer copies + main-GPU add of
+ * ggml-cuda.cu.patch:18077-18121.  hipGraph-capturable like the calls above. */
+int lfamd_mul_mat_allreduce(lfamd_comm *comm, int Atype, const void *d_A_packed, long m, long k, int Btype, const void *d_B,
+                            size_t b_row_bytes, const float *d_residual, float *d_partial, float *d_out, void *d_workspace,
+                            size_t workspace_bytes, unsigned flags, void *stream);
 int lfamd_comm_check(lfamd_comm *comm);
 int lfamd_comm_clear_error(lfamd_comm *comm);
 

@@ -75,6 +75,7 @@ _SIGS = {
     "lfamd_comm_allreduce_sum_f32": (_i, [_vp, _vp, _l, _vp]),
     "lfamd_comm_allgather": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "lfamd_comm_check": (_i, [_vp]),
+    "lfamd_mul_mat_allreduce": (_i, [_vp, _i, _vp, _l, _l, _i, _vp, _sz, _vp, _vp, _vp, _vp, _sz, _u, _vp]),
     "lfamd_comm_clear_error": (_i, [_vp]),
     "lfamd_time_mul_mat": (_i, [_i, _vp, _l, _l, _i, _vp, _sz, _l, _vp, _l, _vp, _sz, _u, _vp, _i, _i,
                                 C.POINTER(C.c_float)]),

@@ -13,6 +13,7 @@
 //     14 latency-bound hops at world 8.  Every spin is bounded (a lost peer sets an error flag instead of hanging).
 #include "lfamd_device.h"
 #include "../../include/lfamd_hip.h"
+#include "oneshot_impl.h"
 
 #include <dlfcn.h>
 #include <stdio.h>
@@ -24,6 +25,13 @@
 
 extern "C" void lfamd_set_error(const char *msg);
 hipError_t lfamd_launch_add_f32(float *y, const float *r, long n, hipStream_t s);
+extern "C" hipError_t lfamd_launch_gemv_fx(int Atype, const void *A, long m, long k, int Btype, const void *B, size_t b_row_bytes,
+                                           float *partial, const void *fx_args, hipStream_t s);
+struct gemv_fx { // (gemv_impl.h)
+    oneshot_args a;
+    const float *residual;
+    float *out;
+};
 
 namespace {
 
@@ -84,9 +92,7 @@ int nccl_fail(int rc, const char *where) {
 
 } // namespace
 
-#define ONESHOT_MAX_WORLD 8
-#define ONESHOT_WGS 8      // work-groups per launch; WG w owns chunk w of the message and flag column w
-#define ONESHOT_THREADS 256
+#include "oneshot_impl.h"
 
 // exchange blocks handed out by lfamd_oneshot_alloc (fine-grained / uncached device memory): attach accepts no other
 static std::mutex g_blocks_mu;
@@ -119,39 +125,6 @@ struct comm_device {
             (void)hipSetDevice(prev);
     }
 };
-
-// exchange block: [flags: ONESHOT_MAX_WORLD x ONESHOT_WGS x 64 B][slot 0][slot 1]
-#define ONESHOT_FLAGS_BYTES (ONESHOT_MAX_WORLD * ONESHOT_WGS * 64)
-
-struct oneshot_args {
-    uint8_t *peer[ONESHOT_MAX_WORLD];
-    int rank, world;
-    size_t slot_bytes;
-    long count; // floats
-    long timeout_ticks; // of the 100 MHz wall clock
-    int *state; // [0] error flag, [1 + w] the number of calls work-group w has served: the call's sequence number lives on
-                // the DEVICE, so a captured launch advances it on every graph replay (every rank issues the same calls)
-};
-
-// system-scope accesses (write-through stores, cache-bypassing loads): the only forms another GPU can observe / that
-// observe another GPU's stores inside a running kernel
-__device__ static inline void st_sys16(void *p, float4 f) {
-    const float4_t_ v = {f.x, f.y, f.z, f.w};
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
-}
-__device__ static inline float4 ld_sys16(const void *p) {
-    float4_t_ v;
-    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
-    return make_float4(v.x, v.y, v.z, v.w);
-}
-__device__ static inline void st_sys4(void *p, uint32_t v) {
-    asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
-}
-__device__ static inline uint32_t ld_sys4(const void *p) {
-    uint32_t v;
-    asm volatile("global_load_dword %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
-    return v;
-}
 
 // out[i] = (residual ? residual[i] : 0) + sum over ranks r = 0 .. world-1 of partial_r[i]     (count % 4 == 0)
 // GATHER: out[r * count + i] = partial_r[i] instead (the vocabulary shards of the logits; same publish / flag protocol)
@@ -215,6 +188,8 @@ extern "C" {
 
 int lfamd_oneshot_alloc(void **d_block, size_t bytes);
 int lfamd_oneshot_free(void *d_block);
+int lfamd_comm_allreduce_add_f32(lfamd_comm *c, const float *d_partial, const float *d_residual, float *d_out, long count,
+                                 void *stream);
 size_t lfamd_oneshot_bytes(size_t max_message_bytes);
 int lfamd_comm_destroy(lfamd_comm *c);
 
@@ -344,9 +319,9 @@ int lfamd_oneshot_attach(lfamd_comm *c, void *d_local_block, size_t block_bytes,
     if (e == hipSuccess)
         e = hipDeviceSynchronize();
     if (e == hipSuccess && !c->d_state)
-        e = hipMalloc((void **)&c->d_state, (1 + ONESHOT_WGS) * sizeof(int));
+        e = hipMalloc((void **)&c->d_state, (2 + ONESHOT_WGS) * sizeof(int));
     if (e == hipSuccess)
-        e = hipMemset(c->d_state, 0, (1 + ONESHOT_WGS) * sizeof(int));
+        e = hipMemset(c->d_state, 0, (2 + ONESHOT_WGS) * sizeof(int));
     for (int r = 0; r < c->world && e == hipSuccess; r++) {
         if (r == c->rank) {
             c->peer[r] = (uint8_t *)d_local_block;
@@ -471,6 +446,50 @@ int lfamd_comm_allgather(lfamd_comm *c, const void *d_send, void *d_recv, size_t
     return rc ? nccl_fail(rc, "ncclAllGather") : LFAMD_OK;
 }
 
+// One activation row against this rank's column shard of a matrix AND the all-reduce of the f32 partials, residual added:
+//   d_out = (d_residual ? d_residual : 0) + sum over ranks of (A_rank . b_rank)
+// One launch when the one-shot exchange is attached, the message fits its slot and the type has the fused kernel (Q4_K, Q5_K,
+// Q6_K: the decode GEMV whose last work-group runs the exchange); otherwise lfamd_mul_mat followed by
+// lfamd_comm_allreduce_add_f32 — the same bits either way.  d_partial (m floats) is scratch for the two-launch form.
+int lfamd_mul_mat_allreduce(lfamd_comm *c, int Atype, const void *d_A_packed, long m, long k, int Btype, const void *d_B,
+                            size_t b_row_bytes, const float *d_residual, float *d_partial, float *d_out, void *d_ws, size_t ws_bytes,
+                            unsigned flags, void *stream) {
+    if (!c || !d_partial || !d_out || m <= 0) {
+        lfamd_set_error("lfamd_mul_mat_allreduce: bad arguments");
+        return LFAMD_ERR_INVALID;
+    }
+    static const bool no_fuse = getenv("LFAMD_NO_FUSED_EXCHANGE") && atoi(getenv("LFAMD_NO_FUSED_EXCHANGE"));
+    const bool aligned = (m & 3) == 0 && ((((uintptr_t)d_partial) | ((uintptr_t)d_out) | ((uintptr_t)d_residual)) & 15) == 0;
+    if (!no_fuse && c->local && aligned && (size_t)m * 4 <= c->slot_bytes) {
+        comm_device on(c);
+        gemv_fx fx;
+        for (int r = 0; r < ONESHOT_MAX_WORLD; r++)
+            fx.a.peer[r] = c->peer[r < c->world ? r : 0];
+        fx.a.rank = c->rank, fx.a.world = c->world;
+        fx.a.slot_bytes = c->slot_bytes;
+        fx.a.count = m;
+        fx.a.timeout_ticks = c->timeout_ticks;
+        fx.a.state = c->d_state;
+        fx.residual = d_residual, fx.out = d_out;
+        hipError_t e = lfamd_launch_gemv_fx(Atype, d_A_packed, m, k, Btype, d_B, b_row_bytes, d_partial, &fx, (hipStream_t)stream);
+        if (e == hipSuccess)
+            return LFAMD_OK;
+        (void)hipGetLastError();
+        if (e != hipErrorNotSupported) {
+            lfamd_set_error(hipGetErrorString(e));
+            return LFAMD_ERR_HIP;
+        }
+    }
+    int rc;
+    {
+        comm_device on(c);
+        rc = lfamd_mul_mat(Atype, d_A_packed, m, k, Btype, d_B, b_row_bytes, 1, d_partial, m, d_ws, ws_bytes, flags, stream);
+    }
+    if (rc != LFAMD_OK)
+        return rc;
+    return lfamd_comm_allreduce_add_f32(c, d_partial, d_residual, d_out, m, stream);
+}
+
 // One process, several devices (one host thread, hipSetDevice per shard — ncclCommInitAll's shape): comms[i] is rank i of
 // world ndev on HIP device devices[i].  Every rank's exchange block is allocated here (fine-grained memory on its device) and
 // the peers hold each other's blocks as plain pointers (one address space: no IPC handles, no host barrier — the blocks are
@@ -514,9 +533,9 @@ int lfamd_comm_init_all(lfamd_comm **comms, int ndev, const int *devices, size_t
         if (e == hipSuccess)
             e = hipMemset(p, 0, ONESHOT_FLAGS_BYTES);
         if (e == hipSuccess)
-            e = hipMalloc((void **)&c->d_state, (1 + ONESHOT_WGS) * sizeof(int));
+            e = hipMalloc((void **)&c->d_state, (2 + ONESHOT_WGS) * sizeof(int));
         if (e == hipSuccess)
-            e = hipMemset(c->d_state, 0, (1 + ONESHOT_WGS) * sizeof(int));
+            e = hipMemset(c->d_state, 0, (2 + ONESHOT_WGS) * sizeof(int));
         if (e == hipSuccess)
             e = hipDeviceSynchronize();
         for (int j = 0; j < ndev && e == hipSuccess; j++) // peers' blocks are read and written from this device's kernels

@@ -50,6 +50,15 @@ def _worker(rank, world, port, q):
                 out = torch.empty_like(part)
                 comm.allreduce_add(part, rd, out)
                 outs.append(out)
+            # the same step as ONE launch (the product's last work-group runs the exchange), alternating with the two-launch
+            # form: same protocol state, same bits
+            xb = torch.from_numpy(xl).cuda().view(torch.uint8).view(1, kl * 4)
+            part2 = torch.zeros_like(part)
+            for rep in range(3):
+                outs.append(comm.mul_mat_allreduce(W, xb, T.F32, residual=rd, partial=part2))
+                out = torch.empty_like(part)
+                comm.allreduce_add(part, rd, out)
+                outs.append(out)
             torch.cuda.synchronize()
             assert comm.check() == 0
             assert all(torch.equal(outs[0], o) for o in outs[1:])
