@@ -1373,6 +1373,8 @@ __device__ __forceinline__ void gemv_kq_body1(const gemv_mats &mats, int nb, con
     // then run after the stream has ended)
     // pairs of items without a branch inside (a conditionally skipped consume leaves its buffer's loads "pending" at
     // the loop header for hipcc's wait-count pass, which then drains vmcnt(0) before every issue), then the odd one
+    // (measured and rejected, round 3: FOUR items in flight per wave for launches whose work-groups walk many small items — the
+    // Mixtral gate + up experts, 14 half-tiles of 37 KB per work-group: decode pass 1.820 -> 1.883 ms)
     for (;;) {
         kq_cursor cn = cc;
         KQ_ADVANCE(cn);
@@ -1878,6 +1880,7 @@ static hipError_t launch_kq_ids_pair(const gemv_mats &ma, const gemv_mats &mb, i
         kernel<<<2 * g1, NW * 64, smem, s>>>((const uint8_t *)Ba, (const uint8_t *)Bb, brb, nb, n_ht, n_ht, g1, g1, ma, mb);
         return hipGetLastError();
     };
+    // (round 3, 8 waves x two work-groups per CU for this launch: Mixtral decode pass 1.712 -> 1.919 ms; 16 waves stay)
     if (nb <= 16)
         return go(gemv_kq_ids_pair_kernel<TR, BT, NW, 1>);
     return go(gemv_kq_ids_pair_kernel<TR, BT, NW, 2>);
@@ -1891,7 +1894,17 @@ static hipError_t launch_kq_ids(const gemv_mats &mats, int n_ht, long k, const v
     const int max_wg = num_cus();
     const int per_wg = (n_ht + max_wg - 1) / max_wg;
     const int grid = (n_ht + per_wg - 1) / per_wg;
-    if (nb <= 16) {
+    // gate + up experts in one launch (4 x 896 half-tiles of 16 super-blocks, 14 per 16-wave work-group): every item ends in a
+    // work-group barrier, and two independent 8-wave work-groups per CU hide each other's — Mixtral decode pass 1.823 ->
+    // 1.706 ms (548 -> 586 tokens/s).  Shorter walks keep the 16-wave form (see launch_kq_pick).
+    static const bool no_nw8 = getenv("LFAMD_IDS_NO_NW8") && atoi(getenv("LFAMD_IDS_NO_NW8"));
+    if (nb <= 16 && !no_nw8 && n_ht >= 8 * num_cus()) {
+        constexpr int NW8 = 8;
+        const size_t smem8 = (size_t)nb * XBLK + 2 * NW8 * 16 * sizeof(float) + (size_t)NW8 * XBLK;
+        const int max8 = 2 * num_cus(), per8 = (n_ht + max8 - 1) / max8, grid8 = (n_ht + per8 - 1) / per8;
+        auto kernel = gemv_kq_kernel<TR, 1, BT, NW8, 2, true>;
+        kernel<<<grid8, NW8 * 64, smem8, s>>>((const uint8_t *)B, brb, 0, nb, n_ht, grid8, mats.A[0], 0, mats);
+    } else if (nb <= 16) {
         auto kernel = gemv_kq_kernel<TR, 1, BT, NW, 1, true>;
         kernel<<<grid, NW * 64, smem, s>>>((const uint8_t *)B, brb, 0, nb, n_ht, grid, mats.A[0], 0 /* expert picked on the device: no early issue */, mats);
     } else {
@@ -1919,6 +1932,9 @@ static hipError_t launch_kq_pick(const gemv_mats &mats, int n_ht, long k, const 
         // (the same form for f32 and pre-quantised rows: the two launches stay bit-identical)
         if (n_ht <= num_cus() && nb <= 32)
             return launch_kq<TR, NC, BT, 8, 2>(mats, n_ht, k, B, brb, col0, s);
+        // (round 3, 8 waves for launches of MANY items too: 14336 x 4096 8.30 vs 9.10 us, 28672 13.3 vs 14.2, 32000 (Q6_K) 23.5 vs
+        // 24.3, 128256 83.7 vs 84.2 — the 16-wave form keeps them; only at 57344 rows, 14 half-tiles per work-group, does
+        // the 8-wave form win (24.4 -> 23.5), which is the expert launch below)
         if (nb <= 16)
             return launch_kq<TR, NC, BT, 16, 1>(mats, n_ht, k, B, brb, col0, s);
         return launch_kq<TR, NC, BT, 16, 2>(mats, n_ht, k, B, brb, col0, s);
