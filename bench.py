@@ -415,7 +415,8 @@ def make_comm(rank, world, same_device=False):
     # the fused form (decode product + exchange in one launch): trusted only if it gives the two-launch form's bits here
     comm.fused_ok = False
     comm.fused_test = "not run"
-    if comm.oneshot_eff and not os.environ.get("LFAMD_NO_FUSED_EXCHANGE"):
+    # (run only on request — LFAMD_FUSED_EXCHANGE=1 — so that a default scaling run executes nothing round 2 did not)
+    if comm.oneshot_eff and os.environ.get("LFAMD_FUSED_EXCHANGE") and not os.environ.get("LFAMD_NO_FUSED_EXCHANGE"):
         from llamafile_amd import sgemm, synth
         m_t, k_t = 4096, 1024
         Wt = sgemm.upload_weights(T.Q4_K, synth.random_weights(T.Q4_K, m_t, k_t, 900 + rank), m_t, k_t)
@@ -449,7 +450,8 @@ def make_comm(rank, world, same_device=False):
            else "no RCCL (ranks share a device): every size on the one-shot kernel")
         + ", through the C ABI"
         + (f"; decode attn_output product + exchange in one launch: self-test {comm.fused_test}, "
-           + ("in use" if getattr(comm, "fused_use", False) else "not used (LFAMD_FUSED_EXCHANGE=1 turns it on)") if comm.fused_test != "not run" else ""))
+           + ("in use" if getattr(comm, "fused_use", False) else "not used") if comm.fused_test != "not run"
+           else "; attn_output product and exchange as two launches (the fused form, LFAMD_FUSED_EXCHANGE=1, measured slower)" if comm.oneshot_eff else ""))
     comm.has_rccl = use_rccl or "self-test failed" in comm.mode
     comm.oneshot = oneshot if "self-test failed" not in comm.mode else 0
     return comm
