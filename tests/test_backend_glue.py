@@ -127,7 +127,10 @@ TWO = {"LFAMD_BACKEND_DEVICES": "0,0"}  # two logical devices on the one GPU of 
 def test_device_list_is_what_the_module_reports(gpu, host_exe):
     """ggml_backend_cuda_get_device_count (ggml-cuda.cu.patch:19532): every gfx950 device of the process by default,
     LFAMD_BACKEND_DEVICES restricts / repeats; ordinals that do not exist are dropped."""
-    for env, want in (({}, "count=1"), (TWO, "count=2"), ({"LFAMD_BACKEND_DEVICES": "0,7,0,0"}, "count=3"), ({"LFAMD_BACKEND_DEVICES": "9"}, "count=0")):
+    import torch
+    visible = torch.cuda.device_count()
+    for env, want in (({}, f"count={visible}"), (TWO, "count=2"), ({"LFAMD_BACKEND_DEVICES": "0,99,0,0"}, "count=3"),
+                      ({"LFAMD_BACKEND_DEVICES": "99"}, "count=0")):
         r = subprocess.run([host_exe, _hip.HIP_SO, "exports"], capture_output=True, text=True, timeout=120, env={**os.environ, **env})
         assert r.returncode == 0 and r.stdout.split()[1] == want, (env, r.stdout, r.stderr)
 
