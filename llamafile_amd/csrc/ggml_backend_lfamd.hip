@@ -121,6 +121,7 @@ struct backend_ctx {
     void *plan = nullptr; // contiguous copy of a strided ids tensor
     size_t plan_cap = 0;
     peer_scratch peer[LFAMD_MAX_DEVS];
+    long sibling_calls = 0; // calls that served more than one node (LFAMD_BACKEND_STATS=1 prints it when the backend is freed)
 };
 
 bool grow(void *&p, size_t &cap, size_t need) {
@@ -580,48 +581,63 @@ bool mul_mat_id_supported(const struct ggml_tensor *op) {
     return as->ne[0] % lfamd_blck_size(as->type) == 0 && lfamd_packed_size(as->type, (long)as->ne[1], (long)as->ne[0]) != 0;
 }
 
-enum ggml_status run_mul_mat_id(backend_ctx *ctx, struct ggml_tensor *dst) {
+// the whole expert stack packed back to back under the stack's address (g_mu held)
+const packed *get_packed_stack(backend_ctx *ctx, const struct ggml_tensor *as, packed *tmp) {
+    const long rows = (long)as->ne[1], cols = (long)as->ne[0];
+    const int experts = (int)as->ne[2];
+    const size_t one = lfamd_packed_size(as->type, rows, cols);
+    const uint8_t *as_bytes = weight_bytes(as); // (an expert stack of a row-split buffer stays whole on the first device)
+    if (!as_bytes)
+        return nullptr;
+    const bool keep = as->buffer && g_api->ggml_backend_buffer_get_usage(as->buffer) == GGML_BACKEND_BUFFER_USAGE_WEIGHTS;
+    auto it = g_packed.find(as_bytes);
+    if (keep && it != g_packed.end() && it->second.type == as->type && it->second.rows == rows * experts && it->second.cols == cols)
+        return &it->second;
+    packed p;
+    p.bytes = one * experts, p.type = as->type, p.rows = rows * experts, p.cols = cols, p.row_bytes = as->nb[1];
+    if (keep) {
+        if (hipMalloc(&p.d, p.bytes) != hipSuccess)
+            return nullptr;
+    } else {
+        if (!grow(ctx->scratch, ctx->scratch_cap, p.bytes))
+            return nullptr;
+        p.d = ctx->scratch;
+    }
+    for (int e = 0; e < experts; e++)
+        if (lfamd_pack_weights(as->type, rows, cols, as_bytes + (size_t)e * as->nb[2], as->nb[1], (uint8_t *)p.d + (size_t)e * one,
+                               nullptr) != LFAMD_OK) {
+            if (keep)
+                (void)hipFree(p.d);
+            return nullptr;
+        }
+    p.exact_only = lfamd_scaled_gemm_ok(as->type, (long)experts * ((rows + 31) / 32) * 32, cols, p.d, nullptr) == 0;
+    if (keep)
+        return &(g_packed[as_bytes] = p);
+    *tmp = p;
+    return tmp;
+}
+
+// `count` MUL_MAT_ID nodes over the same activations and routing table (count == 1: the plain node; 2: ffn_gate_exps +
+// ffn_up_exps of a layer, which the graph holds back to back — one launch at decode, lfamd_mul_mat_id_multi)
+enum ggml_status run_mul_mat_id(backend_ctx *ctx, struct ggml_tensor *const *dsts, int count) {
+    struct ggml_tensor *dst = dsts[0];
     const struct ggml_tensor *as = dst->src[0], *b = dst->src[1], *ids = dst->src[2];
     const long rows = (long)as->ne[1], cols = (long)as->ne[0], tokens = (long)b->ne[2];
     const int experts = (int)as->ne[2], thinkers = (int)ids->ne[0], tasks = (int)b->ne[1];
     if (!rows || !tokens || !thinkers)
         return GGML_STATUS_SUCCESS;
-    const size_t one = lfamd_packed_size(as->type, rows, cols);
-    const uint8_t *as_bytes = weight_bytes(as); // (an expert stack of a row-split buffer stays whole on the first device)
-    if (!as_bytes)
-        return GGML_STATUS_FAILED;
     std::lock_guard<std::mutex> lk(g_mu);
-    // the whole expert stack packed back to back under the stack's address
-    const packed *w = nullptr;
-    packed tmp;
-    {
-        const bool keep = as->buffer && g_api->ggml_backend_buffer_get_usage(as->buffer) == GGML_BACKEND_BUFFER_USAGE_WEIGHTS;
-        auto it = g_packed.find(as_bytes);
-        if (keep && it != g_packed.end() && it->second.type == as->type && it->second.rows == rows * experts && it->second.cols == cols) {
-            w = &it->second;
-        } else {
-            packed p;
-            p.bytes = one * experts, p.type = as->type, p.rows = rows * experts, p.cols = cols, p.row_bytes = as->nb[1];
-            if (keep) {
-                if (hipMalloc(&p.d, p.bytes) != hipSuccess)
-                    return GGML_STATUS_ALLOC_FAILED;
-            } else {
-                if (!grow(ctx->scratch, ctx->scratch_cap, p.bytes))
-                    return GGML_STATUS_ALLOC_FAILED;
-                p.d = ctx->scratch;
-            }
-            for (int e = 0; e < experts; e++)
-                if (lfamd_pack_weights(as->type, rows, cols, as_bytes + (size_t)e * as->nb[2], as->nb[1],
-                                       (uint8_t *)p.d + (size_t)e * one, nullptr) != LFAMD_OK)
-                    return GGML_STATUS_FAILED;
-            p.exact_only = lfamd_scaled_gemm_ok(as->type, (long)experts * ((rows + 31) / 32) * 32, cols, p.d, nullptr) == 0;
-            if (keep) {
-                w = &(g_packed[as_bytes] = p);
-            } else {
-                tmp = p;
-                w = &tmp;
-            }
-        }
+    const void *wp[4];
+    float *rp[4];
+    unsigned flags = LFAMD_FLAG_Q0_VREGS32;
+    for (int j = 0; j < count; j++) {
+        packed tmp;
+        const packed *w = get_packed_stack(ctx, dsts[j]->src[0], &tmp);
+        if (!w)
+            return GGML_STATUS_ALLOC_FAILED;
+        wp[j] = w->d, rp[j] = (float *)dsts[j]->data;
+        if (w->exact_only)
+            flags |= LFAMD_FLAG_PRECISE;
     }
     // routing table as contiguous int32 [tokens][thinkers]
     const int32_t *plan = (const int32_t *)ids->data;
@@ -636,10 +652,85 @@ enum ggml_status run_mul_mat_id(backend_ctx *ctx, struct ggml_tensor *dst) {
     const size_t wsb = lfamd_mul_mat_id_workspace(as->type, rows, cols, experts, tokens, thinkers);
     if (!grow(ctx->ws, ctx->ws_cap, wsb))
         return GGML_STATUS_ALLOC_FAILED;
-    if (lfamd_mul_mat_id(as->type, w->d, rows, cols, experts, LFAMD_TYPE_F32, b->data, b->nb[1], tasks, tokens, plan, thinkers,
-                         (float *)dst->data, ctx->ws, ctx->ws_cap, (w->exact_only ? LFAMD_FLAG_PRECISE : 0u) | LFAMD_FLAG_Q0_VREGS32,
-                         nullptr) != LFAMD_OK) {
+    const int rc = count == 1 ? lfamd_mul_mat_id(as->type, wp[0], rows, cols, experts, LFAMD_TYPE_F32, b->data, b->nb[1], tasks, tokens, plan,
+                                                 thinkers, rp[0], ctx->ws, ctx->ws_cap, flags, nullptr)
+                              : lfamd_mul_mat_id_multi(as->type, count, wp, rows, cols, experts, LFAMD_TYPE_F32, b->data, b->nb[1], tasks,
+                                                       tokens, plan, thinkers, rp, ctx->ws, ctx->ws_cap, flags, nullptr);
+    if (rc != LFAMD_OK) {
         logf("%s: lfamd_mul_mat_id: %s\n", "ggml_backend_lfamd", lfamd_last_error());
+        return GGML_STATUS_FAILED;
+    }
+    return GGML_STATUS_SUCCESS;
+}
+
+// Sibling nodes (ggml-cuda.cu.patch:18945 walks the node list one by one; llama.cpp builds attn_q / attn_k / attn_v and
+// ffn_gate / ffn_up back to back over the same src1): how many nodes from `i` on can run as ONE call.
+//   MUL_MAT: plain 2-D weights of this device, the same src1 tensor, at most 8 activation rows -> lfamd_mul_mat_multi_types
+//   MUL_MAT_ID: the same src1 and ids, one type and shape, at most 4 tokens                    -> lfamd_mul_mat_id_multi
+int sibling_run(const struct ggml_cgraph *g, int i) {
+    static const bool off = getenv("LFAMD_BACKEND_NO_SIBLING_FUSION") && atoi(getenv("LFAMD_BACKEND_NO_SIBLING_FUSION"));
+    const struct ggml_tensor *first = g->nodes[i];
+    const struct ggml_tensor *a0 = first->src[0], *b0 = first->src[1];
+    if (off || !a0 || !b0)
+        return 1;
+    const bool id = first->op == g_op_mul_mat_id;
+    const int limit = id ? 2 : 4;
+    if (id ? (b0->ne[2] > 4 || b0->ne[1] != 1 || !mul_mat_id_supported(first))
+           : (b0->ne[1] > 8 || b0->ne[2] * b0->ne[3] != 1 || a0->ne[2] * a0->ne[3] != 1 || is_split(a0) || !mul_mat_supported(first) ||
+              b0->nb[1] % 16 || first->nb[1] != (size_t)a0->ne[1] * 4))
+        return 1;
+    int n = 1;
+    while (n < limit && i + n < g->n_nodes) {
+        const struct ggml_tensor *t = g->nodes[i + n];
+        if (t->op != first->op || t->src[1] != b0 || !t->src[0])
+            break;
+        const struct ggml_tensor *a = t->src[0];
+        if (id) {
+            if (t->src[2] != first->src[2] || a->type != a0->type || a->ne[0] != a0->ne[0] || a->ne[1] != a0->ne[1] || a->ne[2] != a0->ne[2] ||
+                !mul_mat_id_supported(t))
+                break;
+        } else if (a->ne[2] * a->ne[3] != 1 || is_split(a) || !mul_mat_supported(t) || t->nb[1] != (size_t)a->ne[1] * 4 ||
+                   lfamd_vec_dot_type(a->type) != lfamd_vec_dot_type(a0->type)) {
+            break;
+        }
+        n++;
+    }
+    return n;
+}
+
+enum ggml_status run_mul_mat_siblings(backend_ctx *ctx, struct ggml_tensor *const *dsts, int count) {
+    const struct ggml_tensor *b = dsts[0]->src[1];
+    const long k = (long)b->ne[0], n = (long)b->ne[1];
+    if (n == 0)
+        return GGML_STATUS_SUCCESS;
+    int types[4];
+    const void *A[4];
+    long m[4], ldc[4];
+    float *C[4];
+    size_t wsb = 0;
+    unsigned flags = LFAMD_FLAG_Q0_VREGS32;
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (int j = 0; j < count; j++) {
+        const struct ggml_tensor *a = dsts[j]->src[0];
+        packed tmp;
+        // (a matrix outside a weights buffer is packed into the one scratch area: it cannot share a call with another)
+        const bool keep = a->buffer && g_api->ggml_backend_buffer_get_usage(a->buffer) == GGML_BACKEND_BUFFER_USAGE_WEIGHTS;
+        if (!keep)
+            return GGML_STATUS_ABORTED;
+        const packed *w = get_packed(ctx, a, 0, 0, &tmp);
+        if (!w)
+            return GGML_STATUS_ALLOC_FAILED;
+        types[j] = a->type, A[j] = w->d, m[j] = (long)a->ne[1], ldc[j] = (long)a->ne[1], C[j] = (float *)dsts[j]->data;
+        if (w->exact_only)
+            flags |= LFAMD_FLAG_PRECISE;
+        const size_t need = lfamd_mul_mat_workspace(a->type, m[j], k, n);
+        wsb = need > wsb ? need : wsb;
+    }
+    if (!grow(ctx->ws, ctx->ws_cap, wsb))
+        return GGML_STATUS_ALLOC_FAILED;
+    if (lfamd_mul_mat_multi_types(count, types, A, m, k, LFAMD_TYPE_F32, b->data, b->nb[1], n, C, ldc, ctx->ws, ctx->ws_cap, flags,
+                                  nullptr) != LFAMD_OK) {
+        logf("%s: lfamd_mul_mat_multi_types: %s\n", "ggml_backend_lfamd", lfamd_last_error());
         return GGML_STATUS_FAILED;
     }
     return GGML_STATUS_SUCCESS;
@@ -651,6 +742,8 @@ GGML_CALL const char *be_get_name(ggml_backend_t) {
 }
 GGML_CALL void be_free(ggml_backend_t backend) {
     backend_ctx *c = (backend_ctx *)backend->context;
+    if (g_api && g_api->getenv && g_api->getenv("LFAMD_BACKEND_STATS"))
+        fprintf(stderr, "ggml_backend_lfamd: %ld sibling calls\n", c->sibling_calls);
     {
         on_device d(c->device);
         (void)hipDeviceSynchronize();
@@ -685,11 +778,20 @@ GGML_CALL enum ggml_status be_graph_compute(ggml_backend_t backend, struct ggml_
     for (int i = 0; i < cgraph->n_nodes; i++) {
         struct ggml_tensor *node = cgraph->nodes[i];
         enum ggml_status st = GGML_STATUS_SUCCESS;
-        if (node->op == g_op_mul_mat)
-            st = run_mul_mat(c, node);
-        else if (node->op == g_op_mul_mat_id)
-            st = run_mul_mat_id(c, node);
-        else if (g_api->ggml_is_empty(node))
+        if (node->op == g_op_mul_mat || node->op == g_op_mul_mat_id) {
+            const int run = sibling_run(cgraph, i);
+            if (node->op == g_op_mul_mat_id) {
+                st = run_mul_mat_id(c, &cgraph->nodes[i], run);
+                i += run - 1;
+                c->sibling_calls += run > 1;
+            } else {
+                st = run > 1 ? run_mul_mat_siblings(c, &cgraph->nodes[i], run) : GGML_STATUS_ABORTED;
+                if (st == GGML_STATUS_ABORTED) // (not a sibling run after all: node by node)
+                    st = run_mul_mat(c, node);
+                else
+                    i += run - 1, c->sibling_calls += 1;
+            }
+        } else if (g_api->ggml_is_empty(node))
             continue;
         else {
             const char *name = g_api->ggml_op_name(node->op);

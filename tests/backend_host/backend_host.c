@@ -248,8 +248,23 @@ int main(int argc, char **argv) {
     if (hi)
         cbuf->iface.set_tensor(cbuf, &IDS, hi, 0, ni);
     if (!be->iface.supports_op(be, &OUT)) { fprintf(stderr, "supports_op says no\n"); return 11; }
-    struct ggml_tensor *nodes[1] = {&OUT};
-    struct ggml_cgraph g = {1, 1, 0, nodes, NULL, NULL};
+    /* BACKEND_HOST_PAIR: a second node over the SAME src1 (and ids) with its own copy of the weights, right behind the first
+       (attn_q / attn_k, ffn_gate / ffn_up): the module may run the two as one call; both results must be the same bytes */
+    struct ggml_tensor W2, OUT2;
+    struct ggml_tensor *nodes[2] = {&OUT, &OUT2};
+    const int pair = getenv("BACKEND_HOST_PAIR") != NULL;
+    ggml_backend_buffer_t wbuf2 = NULL, cbuf2 = NULL;
+    if (pair) {
+        W2 = W, OUT2 = OUT;
+        wbuf2 = buft->iface.alloc_buffer(buft, buft->iface.get_alloc_size(buft, &W2) + align);
+        cbuf2 = buft->iface.alloc_buffer(buft, h_nbytes(&OUT) + align);
+        if (!wbuf2 || !cbuf2) return 10;
+        wbuf2->usage = GGML_BACKEND_BUFFER_USAGE_WEIGHTS;
+        W2.buffer = wbuf2, W2.data = wbuf2->iface.get_base(wbuf2), W2.extra = NULL;
+        wbuf2->iface.set_tensor(wbuf2, &W2, hw, 0, nw);
+        OUT2.buffer = cbuf2, OUT2.data = cbuf2->iface.get_base(cbuf2), OUT2.src[0] = &W2;
+    }
+    struct ggml_cgraph g = {2, pair ? 2 : 1, 0, nodes, NULL, NULL};
     for (int rep = 0; rep < 2; rep++) /* the second run uses the kept packed weights */
         if (be->iface.graph_compute(be, &g) != GGML_STATUS_SUCCESS) { fprintf(stderr, "graph_compute failed\n"); return 12; }
     be->iface.synchronize(be);
@@ -267,6 +282,14 @@ int main(int argc, char **argv) {
     if (be->iface.graph_compute(be, &g) != GGML_STATUS_SUCCESS) return 12;
     be->iface.synchronize(be);
     cbuf->iface.get_tensor(cbuf, &OUT, ho, 0, no);
+    if (pair) {
+        void *ho2 = malloc(no);
+        cbuf2->iface.get_tensor(cbuf2, &OUT2, ho2, 0, no);
+        if (memcmp(ho, ho2, no)) { fprintf(stderr, "sibling nodes over the same weights and activations differ\n"); return 15; }
+        free(ho2);
+        cbuf2->iface.free_buffer(cbuf2);
+        wbuf2->iface.free_buffer(wbuf2);
+    }
     FILE *f = fopen(outpath, "wb");
     fwrite(ho, 1, no, f);
     fclose(f);

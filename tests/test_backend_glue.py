@@ -179,3 +179,57 @@ def test_expert_stack_in_a_split_buffer_stays_whole(gpu, oracle, host_exe, tmp_p
         for th in range(thinkers):
             ok, c = oracle.sgemm(t, W[ids[tk, th]], T.Q8_K, q[tk * tasks + th % tasks][None, :], m, 1, k)
             assert ok == 1 and rel_err(got[tk, th], c[0]) <= 2e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("t,m,k,n", [(T.Q4_K, 1024, 1024, 1), (T.Q6_K, 512, 512, 1), (T.Q4_K, 768, 512, 5), (T.Q8_0, 256, 256, 1), (T.F16, 128, 256, 2),
+                                     (T.Q4_K, 512, 512, 20)], ids=lambda v: str(v))
+def test_sibling_mul_mat_nodes_run_as_one_call(gpu, oracle, host_exe, tmp_path, t, m, k, n):
+    """graph_compute (ggml-cuda.cu.patch:18945) sees attn_q / attn_k / attn_v and ffn_gate / ffn_up back to back over one src1:
+    up to four such MUL_MAT nodes with at most 8 activation rows go out as ONE lfamd_mul_mat_multi_types call.  The host
+    program puts a second node with its own copy of the weights behind the first and requires identical bytes from both;
+    the result is held against the oracle as for a single node; LFAMD_BACKEND_NO_SIBLING_FUSION=1 runs them one by one."""
+    W = synth.random_weights(t, m, k, 7)
+    x = synth.random_activations(n, k, 8)
+    wp, xp, op = tmp_path / "w.bin", tmp_path / "x.bin", tmp_path / "o.bin"
+    W.tofile(wp)
+    x.tofile(xp)
+    outs = []
+    for env in ({}, {"LFAMD_BACKEND_NO_SIBLING_FUSION": "1"}):
+        r = subprocess.run([host_exe, _hip.HIP_SO, "mulmat", str(t), str(m), str(k), str(n), "1", str(wp), str(xp), str(op)],
+                           capture_output=True, text=True, timeout=300,
+                           env={**os.environ, "BACKEND_HOST_PAIR": "1", "LFAMD_BACKEND_STATS": "1", **env})
+        assert r.returncode == 0 and r.stdout.strip() == "ok", r.stderr
+        # (the host program computes the graph four times; more than 8 rows: no fusion, the batch bodies take one matrix each)
+        assert f"{0 if env or n > 8 else 4} sibling calls" in r.stderr, r.stderr
+        outs.append(np.fromfile(op, dtype=np.float32).reshape(n, m))
+        check_mul_mat(oracle, outs[-1], t, W, x, m, k, n, 1)
+    if n == 1:
+        assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))  # one column: the fused launch is the same arithmetic
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tokens", [1, 3, 12])
+def test_sibling_mul_mat_id_nodes_run_as_one_call(gpu, oracle, host_exe, tmp_path, tokens):
+    """ffn_gate_exps and ffn_up_exps of a layer (same src1, same ids) behind each other: one lfamd_mul_mat_id_multi call up to 4 tokens."""
+    t, m, k, experts, thinkers, tasks = T.Q4_K, 64, 512, 6, 2, 1
+    W = np.stack([synth.random_weights(t, m, k, 50 + e) for e in range(experts)])
+    x = synth.random_activations(tokens * tasks, k, 9).reshape(tokens, tasks, k)
+    rng = np.random.default_rng(4)
+    ids = np.stack([rng.permutation(experts)[:thinkers] for _ in range(tokens)]).astype(np.int32)
+    wp, xp, ip, op = (tmp_path / n for n in ("w.bin", "x.bin", "i.bin", "o.bin"))
+    W.tofile(wp), x.tofile(xp), ids.tofile(ip)
+    r = subprocess.run([host_exe, _hip.HIP_SO, "mulmatid", str(t), str(m), str(k), str(experts), str(thinkers), str(tasks), str(tokens),
+                        str(wp), str(xp), str(ip), str(op)], capture_output=True, text=True, timeout=300,
+                       env={**os.environ, "BACKEND_HOST_PAIR": "1", "LFAMD_BACKEND_STATS": "1"})
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stderr
+    assert f"{4 if tokens <= 4 else 0} sibling calls" in r.stderr, r.stderr
+    got = np.fromfile(op, dtype=np.float32).reshape(tokens, thinkers, m)
+    q = oracle.quantize(T.Q8_K, x.reshape(-1, k))
+    G = np.zeros_like(got)
+    for tk in range(tokens):
+        for th in range(thinkers):
+            ok, c = oracle.sgemm(t, W[ids[tk, th]], T.Q8_K, q[tk * tasks + th % tasks][None, :], m, 1, k)
+            assert ok == 1
+            G[tk, th] = c[0]
+    assert rel_err(got, G) <= (1e-3 if tokens > 4 else 2e-6)
