@@ -394,8 +394,9 @@ const packed *get_packed_rows(void *&scratch, size_t &scratch_cap, int type, con
             (void)hipFree(p.d);
         return nullptr;
     }
-    const int in_range = lfamd_scaled_gemm_ok(type, rows, cols, p.d, nullptr);
-    p.exact_only = in_range == 0;
+    // (only the K-quant batch bodies have a scaled-operand form whose range must be checked; the check synchronises the stream)
+    const bool scaled_form = type == LFAMD_TYPE_Q4_K || type == LFAMD_TYPE_Q5_K || type == LFAMD_TYPE_Q6_K;
+    p.exact_only = scaled_form && lfamd_scaled_gemm_ok(type, rows, cols, p.d, nullptr) == 0;
     if (keep)
         return &(g_packed[raw] = p);
     *tmp = p;
@@ -552,10 +553,16 @@ enum ggml_status run_mul_mat(backend_ctx *ctx, struct ggml_tensor *dst) {
     if (!grow(ctx->ws, ctx->ws_cap, wsb))
         return GGML_STATUS_ALLOC_FAILED;
     std::lock_guard<std::mutex> lk(g_mu);
+    packed tmp;
+    const packed *w = nullptr;
+    int64_t have02 = -1, have03 = -1; // (broadcast heads share a src0 slice: packed once, not once per head)
     for (int64_t i13 = 0; i13 < b->ne[3]; i13++)
         for (int64_t i12 = 0; i12 < b->ne[2]; i12++) {
-            packed tmp;
-            const packed *w = get_packed(ctx, a, i12 / (r2 ? r2 : 1), i13 / (r3 ? r3 : 1), &tmp);
+            const int64_t i02 = i12 / (r2 ? r2 : 1), i03 = i13 / (r3 ? r3 : 1);
+            if (!w || i02 != have02 || i03 != have03) {
+                w = get_packed(ctx, a, i02, i03, &tmp);
+                have02 = i02, have03 = i03;
+            }
             if (!w)
                 return GGML_STATUS_ALLOC_FAILED;
             const uint8_t *bp = (const uint8_t *)b->data + i12 * b->nb[2] + i13 * b->nb[3];
