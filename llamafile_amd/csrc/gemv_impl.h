@@ -1159,7 +1159,7 @@ __device__ static inline float kq_sum_rows(float v) {
     return p + q;
 }
 
-template <typename TR, int BT, int NW, int GEMV_CH, bool IDS, bool EARLY = false, bool FX = false>
+template <typename TR, int BT, int NW, int GEMV_CH, bool IDS, bool EARLY = false, bool FX = false, bool PAIR = false>
 __device__ __forceinline__ void gemv_kq_body1(const gemv_mats &mats, int nb, const uint8_t *__restrict__ B,
                                               size_t b_row_bytes, long col0, int n_ht, const int bid, int gdim,
                                               uint8_t *lds, const uint8_t *A0_pre, int cnt_pre, float *fx_row = nullptr) {
@@ -1167,7 +1167,8 @@ __device__ __forceinline__ void gemv_kq_body1(const gemv_mats &mats, int nb, con
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int i16 = lane & 15, h = (lane >> 4) & 1, gsel = lane >> 5;
-    float *red = (float *)(lds + (size_t)nb * XBLK); // [2][NW][16]
+    constexpr int RW = PAIR ? 32 : 16; // result rows per item: a half-tile, or (PAIR) both half-tiles of a 32-row tile
+    float *red = (float *)(lds + (size_t)nb * XBLK); // [2][NW][RW]
 #if GEMV_DIAG
     int stamp_n = 0;
     unsigned long long gwg_clk0 = 0;
@@ -1210,6 +1211,8 @@ __device__ __forceinline__ void gemv_kq_body1(const gemv_mats &mats, int nb, con
     // a single-matrix launch (attn_output, ffn_down) knows its weights from the preloaded arguments: its first item goes
     // out BEFORE the argument table's scalar loads have returned (~0.4 us earlier); both branches issue the same loads
     typename TR::chunk bufA, bufB;
+    typename TR::chunk bufA2, bufB2; // (PAIR: the second half-tile of the item; dead otherwise)
+    static_assert(!(PAIR && (EARLY || IDS || FX)), "the paired item is a variant of the plain launch");
     constexpr bool early = EARLY && !IDS; // (a kernel variant, not a run-time branch: hipcc merges its wait counts at a join)
     (void)cnt_pre;
     if constexpr (early) {
@@ -1226,13 +1229,14 @@ __device__ __forceinline__ void gemv_kq_body1(const gemv_mats &mats, int nb, con
     const int cpt = (sb_per_wave + GEMV_CH - 1) / GEMV_CH; // chunks per tile
     const uint32_t rt_bytes = (uint32_t)nb * TR::TILE;
 
-    float acc = 0.0f;
+    float acc = 0.0f, acc2 = 0.0f;
     int par = 0;
-    kq_cursor ci{bid, 0}, cc{bid, 0};
+    constexpr int HT_STEP = PAIR ? 2 : 1; // (PAIR: a cursor points at the even half-tile of its tile)
+    kq_cursor ci{HT_STEP * bid, 0}, cc{HT_STEP * bid, 0};
 #define KQ_ADVANCE(c)                                                                                                  \
     do {                                                                                                               \
         if (++(c).chunk == cpt)                                                                                        \
-            (c).chunk = 0, (c).ht += gdim;                                                                             \
+            (c).chunk = 0, (c).ht += HT_STEP * gdim;                                                                   \
     } while (0)
     // (measured and rejected: s_setprio 3 around the load issue, and a work-group barrier between every wave's activation
     // loads and the first weight loads — the youngest waves of a k = 14336 row still issue 1.5-3 us after the oldest, the
@@ -1240,6 +1244,10 @@ __device__ __forceinline__ void gemv_kq_body1(const gemv_mats &mats, int nb, con
 #define KQ_ISSUE(buf)                                                                                                  \
     do {                                                                                                               \
         kq_issue<TR, NW, GEMV_CH, IDS>(buf, mats, tab, ci, n_ht, rt_bytes, wave, i16, h, gsel);                            \
+        if constexpr (PAIR) {                                                                                          \
+            const kq_cursor c2{ci.ht + 1, ci.chunk};                                                                   \
+            kq_issue<TR, NW, GEMV_CH, IDS>(buf##2, mats, tab, c2, n_ht, rt_bytes, wave, i16, h, gsel);                 \
+        }                                                                                                              \
         KQ_ADVANCE(ci);                                                                                                \
     } while (0)
     // one chunk of this wave against its own image blocks; at the end of a tile: 4 lanes per row (h, gsel), then the
@@ -1252,23 +1260,33 @@ __device__ __forceinline__ void gemv_kq_body1(const gemv_mats &mats, int nb, con
             /* a super-block beyond the row was loaded as zeros; its image slot belongs to nobody: discard */          \
             const float t = TR::dot(buf, s, lds + (size_t)(b < nb ? b : 0) * XBLK, gsel, h);                           \
             acc += b < nb ? t : 0.0f;                                                                                  \
+            if constexpr (PAIR) {                                                                                      \
+                const float t2 = TR::dot(buf##2, s, lds + (size_t)(b < nb ? b : 0) * XBLK, gsel, h);                   \
+                acc2 += b < nb ? t2 : 0.0f;                                                                            \
+            }                                                                                                          \
         }                                                                                                              \
         if (cc.chunk == cpt - 1) {                                                                                     \
-            float *rb = red + par * (NW * 16);                                                                         \
+            float *rb = red + par * (NW * RW);                                                                         \
             par ^= 1;                                                                                                  \
             float v = kq_sum_rows(acc); /* lanes i16, i16 + 16, i16 + 32, i16 + 48 */                                  \
             if (lane < 16)                                                                                             \
-                rb[wave * 16 + lane] = v;                                                                              \
+                rb[wave * RW + lane] = v;                                                                              \
             acc = 0.0f;                                                                                                \
+            if constexpr (PAIR) {                                                                                      \
+                float v2 = kq_sum_rows(acc2);                                                                          \
+                if (lane < 16)                                                                                         \
+                    rb[wave * RW + 16 + lane] = v2;                                                                    \
+                acc2 = 0.0f;                                                                                           \
+            }                                                                                                          \
             GSTAMP();                                                                                                  \
             __syncthreads();                                                                                           \
             GSTAMP();                                                                                                  \
-            if (threadIdx.x < 16) {                                                                                    \
+            if (threadIdx.x < RW) {                                                                                    \
                 const int i = threadIdx.x;                                                                             \
                 float t = 0.0f;                                                                                        \
-                _Pragma("unroll") for (int w = 0; w < NW; w++) t += rb[w * 16 + i];                                    \
+                _Pragma("unroll") for (int w = 0; w < NW; w++) t += rb[w * RW + i];                                    \
                 const kq_sel p = kq_pick(tab, cc.ht);                                                               \
-                const long row = (long)(p.ht >> 1) * 32 + (p.ht & 1) * 16 + i;                                         \
+                const long row = (long)(p.ht >> 1) * 32 + (p.ht & 1) * 16 + i; /* (PAIR: p.ht even, i < 32) */         \
                 bool ok = true;                                                                                        \
                 if constexpr (IDS) { /* an out-of-range expert id leaves its result row untouched */                   \
                     const int ex = mats.ids[p.idx];                                                                    \
@@ -1289,7 +1307,7 @@ __device__ __forceinline__ void gemv_kq_body1(const gemv_mats &mats, int nb, con
         // staging is straight-line code (a block past the row is loaded as zeros through the descriptor and staged
         // into the wave's dummy slot): with a branch per block hipcc merges its vmcnt bookkeeping at the joins and
         // makes the second block wait for the WEIGHTS.
-        uint8_t *dummy = (uint8_t *)(red + 2 * NW * 16) + (size_t)wave * XBLK;
+        uint8_t *dummy = (uint8_t *)(red + 2 * NW * RW) + (size_t)wave * XBLK;
         if constexpr (early)
             KQ_ADVANCE(ci);
         else
@@ -1343,7 +1361,7 @@ __device__ __forceinline__ void gemv_kq_body1(const gemv_mats &mats, int nb, con
             }
         } else if constexpr (PRE1) {
             { // both half-waves, straight-line (a block past the row was fetched as zeros and lands in the dummy slot)
-                uint8_t *dummy = (uint8_t *)(red + 2 * NW * 16) + (size_t)wave * XBLK;
+                uint8_t *dummy = (uint8_t *)(red + 2 * NW * RW) + (size_t)wave * XBLK;
                 uint8_t *dst = pre_b < nb ? lds + (size_t)pre_b * XBLK : dummy;
                 const int grp = lane & 31;
                 const int hs = put_group(dst, grp, pq.x, pq.y);
@@ -1394,7 +1412,7 @@ __device__ __forceinline__ void gemv_kq_body1(const gemv_mats &mats, int nb, con
 #undef KQ_CONSUME
 }
 
-template <typename TR, int NC, int BT, int NW, int GEMV_CH, bool IDS = false, bool EARLY = false>
+template <typename TR, int NC, int BT, int NW, int GEMV_CH, bool IDS = false, bool EARLY = false, bool PAIR = false>
 __global__ __launch_bounds__(NW * 64) void gemv_kq_kernel(const uint8_t *__restrict__ B, size_t b_row_bytes, long col0, int nb,
                                                           int n_ht, int gdim, const uint8_t *__restrict__ A0, int cnt,
                                                           const gemv_mats mats) {
@@ -1402,7 +1420,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_kq_kernel(const uint8_t *__restr
     // first weight loads without waiting for the argument table)
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     if constexpr (NC == 1)
-        gemv_kq_body1<TR, BT, NW, GEMV_CH, IDS, EARLY>(mats, nb, B, b_row_bytes, col0, n_ht, (int)blockIdx.x, gdim, lds, A0, cnt);
+        gemv_kq_body1<TR, BT, NW, GEMV_CH, IDS, EARLY, false, PAIR>(mats, nb, B, b_row_bytes, col0, n_ht, (int)blockIdx.x, gdim, lds, A0, cnt);
     else
         gemv_kq_body<TR, NC, BT, NW, GEMV_CH, IDS>(mats, nb, B, b_row_bytes, col0, n_ht, (int)blockIdx.x, gdim, lds);
 }
@@ -1786,6 +1804,26 @@ static hipError_t launch_kq(const gemv_mats &mats, int n_ht, long k, const void 
         kernel<<<grid, NW * 64, smem, s>>>((const uint8_t *)B, brb, col0, nb, n_ht, grid, mats.A[0], mats.count, mats);
         return hipGetLastError();
     };
+    if constexpr (NC == 1 && NW == 16 && CH == 1) {
+        // Long walks (output.weight: 63 half-tiles per work-group) take items of a full 32-row tile — both half-tiles in
+        // flight together, ONE barrier + reduce + store per 74 KB instead of per 37 KB; same arithmetic per row, same bits.
+        // 128256 x 4096 Q6_K: 82.8 -> 73.6 us (5.2 -> 5.9 TB/s); 32000 x 4096: 23.6 -> 22.8.  Short walks lose to the
+        // coarser division of the tiles over the work-groups (28672 x 4096, 3.5 tiles each: 13.1 -> 14.3 us), hence the bound.
+        // LFAMD_GEMV_PAIR_MIN=<half-tiles per work-group> moves it (0 = never).
+        static const int pair_min = getenv("LFAMD_GEMV_PAIR_MIN") ? atoi(getenv("LFAMD_GEMV_PAIR_MIN")) : 16;
+        if (pair_min > 0 && per_wg >= pair_min) {
+            const int n_t = n_ht / 2, per_t = (n_t + max_wg - 1) / max_wg, grid_t = (n_t + per_t - 1) / per_t;
+            const size_t smem_t = smem + 2 * NW * 16 * sizeof(float);
+            auto kernel = gemv_kq_kernel<TR, NC, BT, NW, CH, false, false, true>;
+            if (smem_t > 64 * 1024) {
+                hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_t);
+                if (e != hipSuccess)
+                    return e;
+            }
+            kernel<<<grid_t, NW * 64, smem_t, s>>>((const uint8_t *)B, brb, col0, nb, n_ht, grid_t, mats.A[0], mats.count, mats);
+            return hipGetLastError();
+        }
+    }
     if constexpr (NC == 1) {
         if (mats.count == 1) // one matrix: the variant that issues its first weight loads from the preloaded arguments
             return go(gemv_kq_kernel<TR, NC, BT, NW, CH, false, true>);
@@ -1898,6 +1936,7 @@ static hipError_t launch_kq_ids(const gemv_mats &mats, int n_ht, long k, const v
     // work-group barrier, and two independent 8-wave work-groups per CU hide each other's — Mixtral decode pass 1.823 ->
     // 1.706 ms (548 -> 586 tokens/s).  Shorter walks keep the 16-wave form (see launch_kq_pick).
     static const bool no_nw8 = getenv("LFAMD_IDS_NO_NW8") && atoi(getenv("LFAMD_IDS_NO_NW8"));
+    // (the 16-wave form with 32-row items, seven per work-group, was measured too: 1.748 ms per pass against 1.702 for this one)
     if (nb <= 16 && !no_nw8 && n_ht >= 8 * num_cus()) {
         constexpr int NW8 = 8;
         const size_t smem8 = (size_t)nb * XBLK + 2 * NW8 * 16 * sizeof(float) + (size_t)NW8 * XBLK;
