@@ -3,6 +3,8 @@ row depth and the number of half-tiles: 8 waves x 2 super-blocks (<= one half-ti
 x 1 (more half-tiles, <= 16 super-blocks), 16 waves x 2 (deeper rows), the multi-column body (n > 1) — with f32
 activations (quantised in the kernel: one block per wave, two blocks per pass) and pre-quantised ones, against the oracle.
 The f32 and the pre-quantised launch must agree bit for bit (same integer dots, same f32 order)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -11,6 +13,7 @@ from llamafile_amd import ggml_types as T, synth
 from helpers import rel_err
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 TYPES = [T.Q4_K, T.Q5_K, T.Q6_K, T.Q2_K, T.Q3_K, T.IQ4_XS, T.Q4_0, T.Q4_1, T.Q5_0, T.Q5_1]
 # (m, k): k/256 = 3, 17, 32, 40, 56 super-blocks; m = 8208 rows = 513 half-tiles (> one per CU: the 16-wave forms)
@@ -97,3 +100,38 @@ def test_small_batch_respects_the_result_stride(gpu, oracle):
     assert (got[:, m:] == 7.0).all()
     ok, G = oracle.sgemm(t, raw, T.Q8_K, synth.quantize_activations(T.Q8_K, x), m, n, k, nth=4)
     assert ok == 1 and rel_err(got[:, :m], G) <= 2e-6
+
+
+@pytest.mark.gpu
+def test_32_row_items_give_the_same_bits(gpu, tmp_path):
+    """gemv_kq_body1<..., PAIR>: long walks take both half-tiles of a 32-row tile as one item (one barrier per tile).  The
+    launch rule needs >= 16 half-tiles per work-group (output.weight); LFAMD_GEMV_PAIR_MIN=1 forces the form on every
+    16-wave / one-super-block launch, here 8192 x 4096 and 8200 x 2048 (ragged last tile) in Q4_K and Q6_K, and a two-matrix
+    launch: every result must be the bytes the 16-row items give (the env is read once per process: two child processes)."""
+    import subprocess
+    import sys
+    script = tmp_path / "pair_items.py"
+    script.write_text(
+        "import sys, numpy as np, torch\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "from llamafile_amd import ggml_types as T, sgemm, synth\n"
+        "sgemm.init(0)\n"
+        "outs = []\n"
+        "for t, m, k in ((T.Q4_K, 8192, 4096), (T.Q6_K, 8192, 4096), (T.Q4_K, 8200, 2048), (T.Q6_K, 8200, 2048)):\n"
+        "    W = sgemm.upload_weights(t, synth.random_weights(t, m, k, 3), m, k)\n"
+        "    x = torch.from_numpy(synth.random_activations(1, k, 4)).cuda()\n"
+        "    outs.append(sgemm.mul_mat(W, x.view(torch.uint8).view(1, k * 4), T.F32, n=1).cpu().numpy())\n"
+        "Ws = [sgemm.upload_weights(T.Q4_K, synth.random_weights(T.Q4_K, m, 4096, 5 + i), m, 4096) for i, m in enumerate((6144, 5120))]\n"
+        "x = torch.from_numpy(synth.random_activations(1, 4096, 6)).cuda()\n"
+        "outs += [o.cpu().numpy() for o in sgemm.mul_mat_multi(Ws, x.view(torch.uint8).view(1, 4096 * 4), T.F32, n=1)]\n"
+        "np.savez(sys.argv[1], *outs)\n")
+    res = []
+    for name, env in (("items16", {"LFAMD_GEMV_PAIR_MIN": "0"}), ("items32", {"LFAMD_GEMV_PAIR_MIN": "1"})):
+        out = tmp_path / (name + ".npz")
+        r = subprocess.run([sys.executable, str(script), str(out)], capture_output=True, text=True, timeout=600, env={**os.environ, **env})
+        assert r.returncode == 0, r.stderr[-2000:]
+        res.append(np.load(out))
+    assert len(res[0].files) == 6
+    for f in res[0].files:
+        assert np.array_equal(res[0][f].view(np.uint32), res[1][f].view(np.uint32)), f
+        assert np.isfinite(res[0][f]).all() and np.abs(res[0][f]).max() > 0
