@@ -1787,6 +1787,26 @@ static int num_cus() {
     return g_num_cus;
 }
 
+// which types take 32-row items on long walks (launch_kq): the ones whose dot is long enough for a second, independent one to
+// fill its gaps.  128256 x 4096, 16-row -> 32-row items: Q6_K 82.0 -> 73.7 us, Q2_K 44.6 -> 40.8, Q3_K 50.3 -> 44.9, IQ4_XS
+// 58.1 -> 55.4; the light dots lose a little: Q4_K 47.4 -> 47.7, Q5_K 58.1 -> 58.5, Q4_0 46.0 -> 47.6 (65536 rows: 27.0 -> 28.2)
+template <typename TR>
+struct kq_pair_items {
+    static constexpr bool value = false;
+};
+template <>
+struct kq_pair_items<q6k_traits> {
+    static constexpr bool value = true;
+};
+template <int TYPE>
+struct kq_pair_items<pk_traits<TYPE>> {
+    static constexpr bool value = true;
+};
+template <>
+struct kq_pair_items<iq4c_traits> {
+    static constexpr bool value = true;
+};
+
 template <typename TR, int NC, int BT, int NW, int CH>
 static hipError_t launch_kq(const gemv_mats &mats, int n_ht, long k, const void *B, size_t brb, long col0, hipStream_t s) {
     int nb = (int)(k / 256);
@@ -1804,10 +1824,10 @@ static hipError_t launch_kq(const gemv_mats &mats, int n_ht, long k, const void 
         kernel<<<grid, NW * 64, smem, s>>>((const uint8_t *)B, brb, col0, nb, n_ht, grid, mats.A[0], mats.count, mats);
         return hipGetLastError();
     };
-    if constexpr (NC == 1 && NW == 16 && CH == 1) {
+    if constexpr (NC == 1 && NW == 16 && CH == 1 && kq_pair_items<TR>::value) {
         // Long walks (output.weight: 63 half-tiles per work-group) take items of a full 32-row tile — both half-tiles in
         // flight together, ONE barrier + reduce + store per 74 KB instead of per 37 KB; same arithmetic per row, same bits.
-        // 128256 x 4096 Q6_K: 82.8 -> 73.6 us (5.2 -> 5.9 TB/s); 32000 x 4096: 23.6 -> 22.8.  Short walks lose to the
+        // 128256 x 4096 Q6_K: 82.8 -> 73.6 us (5.2 -> 5.9 TB/s); 32000 x 4096: 23.6 -> 22.8 (types: kq_pair_items).  Short walks lose to the
         // coarser division of the tiles over the work-groups (28672 x 4096, 3.5 tiles each: 13.1 -> 14.3 us), hence the bound.
         // LFAMD_GEMV_PAIR_MIN=<half-tiles per work-group> moves it (0 = never).
         static const int pair_min = getenv("LFAMD_GEMV_PAIR_MIN") ? atoi(getenv("LFAMD_GEMV_PAIR_MIN")) : 16;

@@ -105,9 +105,10 @@ def test_small_batch_respects_the_result_stride(gpu, oracle):
 @pytest.mark.gpu
 def test_32_row_items_give_the_same_bits(gpu, tmp_path):
     """gemv_kq_body1<..., PAIR>: long walks take both half-tiles of a 32-row tile as one item (one barrier per tile).  The
-    launch rule needs >= 16 half-tiles per work-group (output.weight); LFAMD_GEMV_PAIR_MIN=1 forces the form on every
-    16-wave / one-super-block launch, here 8192 x 4096 and 8200 x 2048 (ragged last tile) in Q4_K and Q6_K, and a two-matrix
-    launch: every result must be the bytes the 16-row items give (the env is read once per process: two child processes)."""
+    launch rule needs >= 16 half-tiles per work-group (output.weight) and a type with a long dot (Q6_K, Q2_K, Q3_K, IQ4_XS:
+    gemv_impl.h kq_pair_items); LFAMD_GEMV_PAIR_MIN=1 forces the form on every 16-wave / one-super-block launch of those types,
+    here 8192 x 4096 and 8200 x 2048 (ragged last tile) and a two-matrix launch: every result must be the bytes the 16-row
+    items give (Q4_K rides along unchanged; the env is read once per process: two child processes)."""
     import subprocess
     import sys
     script = tmp_path / "pair_items.py"
@@ -117,11 +118,11 @@ def test_32_row_items_give_the_same_bits(gpu, tmp_path):
         "from llamafile_amd import ggml_types as T, sgemm, synth\n"
         "sgemm.init(0)\n"
         "outs = []\n"
-        "for t, m, k in ((T.Q4_K, 8192, 4096), (T.Q6_K, 8192, 4096), (T.Q4_K, 8200, 2048), (T.Q6_K, 8200, 2048)):\n"
+        "for t, m, k in ((T.Q6_K, 8192, 4096), (T.Q2_K, 8192, 4096), (T.Q3_K, 8200, 2048), (T.IQ4_XS, 8200, 2048), (T.Q4_K, 8192, 4096)):\n"
         "    W = sgemm.upload_weights(t, synth.random_weights(t, m, k, 3), m, k)\n"
         "    x = torch.from_numpy(synth.random_activations(1, k, 4)).cuda()\n"
         "    outs.append(sgemm.mul_mat(W, x.view(torch.uint8).view(1, k * 4), T.F32, n=1).cpu().numpy())\n"
-        "Ws = [sgemm.upload_weights(T.Q4_K, synth.random_weights(T.Q4_K, m, 4096, 5 + i), m, 4096) for i, m in enumerate((6144, 5120))]\n"
+        "Ws = [sgemm.upload_weights(T.Q6_K, synth.random_weights(T.Q6_K, m, 4096, 5 + i), m, 4096) for i, m in enumerate((6144, 5120))]\n"
         "x = torch.from_numpy(synth.random_activations(1, 4096, 6)).cuda()\n"
         "outs += [o.cpu().numpy() for o in sgemm.mul_mat_multi(Ws, x.view(torch.uint8).view(1, 4096 * 4), T.F32, n=1)]\n"
         "np.savez(sys.argv[1], *outs)\n")
@@ -131,7 +132,7 @@ def test_32_row_items_give_the_same_bits(gpu, tmp_path):
         r = subprocess.run([sys.executable, str(script), str(out)], capture_output=True, text=True, timeout=600, env={**os.environ, **env})
         assert r.returncode == 0, r.stderr[-2000:]
         res.append(np.load(out))
-    assert len(res[0].files) == 6
+    assert len(res[0].files) == 7
     for f in res[0].files:
         assert np.array_equal(res[0][f].view(np.uint32), res[1][f].view(np.uint32)), f
         assert np.isfinite(res[0][f]).all() and np.abs(res[0][f]).max() > 0
