@@ -462,7 +462,12 @@ def config3_q8_0(a, dev):
     pass, 8.5 GB of packed weights, hipGraph replays timed with events."""
     layers = LS.llama3_8b_q8_0()
     r = Runner(layers, 0, 1, (a.prefill, 1), dev)
-    res = {"model": "llama3-8b-q8_0", "weight_bytes": r.weight_bytes()}
+    resident = sum(o.W.resident_bytes for ops in r.layers for o in ops)
+    res = {"model": "llama3-8b-q8_0", "weight_bytes": resident,  # what the tensors occupy in HBM (the images the kernels read)
+           "gguf_bytes": r.weight_bytes(),  # the tensors' size in the file: what the decode roofline below counts
+           "resident_images": "P80 (bit-exact vecdot) + the byte image of the MFMA batch body" +
+                              (" replaced by f16(d*q) rows for hipBLASLt (LFAMD_USE_BLASLT=1)" if _hip.lib().lfamd_vendor_gemm_available() else ""),
+           "batch_gemm": "hipBLASLt (opt-in)" if _hip.lib().lfamd_vendor_gemm_available() else "module's MFMA body (gemm_wide Q8_0 branch)"}
     for n, reps, key in ((1, 20, "decode"), (a.prefill, 2, "prefill")):
         r.run_pass(n)
         torch.cuda.synchronize()
@@ -496,7 +501,46 @@ def config3_q8_0(a, dev):
     return res
 
 
+def spawn_ranks(n):
+    """`python3 bench.py --gpus N` invoked bare (no launcher, WORLD_SIZE unset): this process touches no GPU; it starts N fresh
+    child ranks of this script (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment — what
+    torch.distributed.run would have set), relays rank 0's JSON line and fails if any rank fails."""
+    import socket
+    import subprocess
+
+    have = torch.cuda.device_count()  # (counts devices without initialising one)
+    shared = os.environ.get("LFAMD_DIST_BACKEND", "nccl") != "nccl"  # gloo rehearsal: the ranks may share device 0
+    if have == 0:
+        print(f"bench.py: --gpus {n} needs {n} MI355X devices; this machine shows none (torch.cuda.device_count() == 0)", file=sys.stderr)
+        return 1
+    if have < n and not shared:
+        print(f"bench.py: --gpus {n} needs {n} devices, {have} visible (for a rehearsal of the ranks on one device set "
+              f"LFAMD_DIST_BACKEND=gloo)", file=sys.stderr)
+        return 1
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    line = procs[0].stdout.read()
+    codes = [p.wait() for p in procs]
+    if line:
+        os.write(1, line)
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
+        return next(c for _, c in bad) if all(c > 0 for _, c in bad) else 1
+    return 0
+
+
 def main():
+    a0 = parse()
+    if a0.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(a0.gpus))
     # ONE JSON line on stdout: anything else a library prints there from C++ (gloo: "[Gloo] Rank 0 is connected ...") goes
     # to stderr — file descriptor 1 is pointed at stderr for the run and the line is written to the saved descriptor
     sys.stdout.flush()
@@ -518,8 +562,9 @@ def run():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus != world and world == 1 and a.gpus > 1:
-        print("bench.py: --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)", file=sys.stderr)
+    if a.gpus != world and a.gpus > 1:
+        print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch one rank per GPU (or leave WORLD_SIZE unset: the "
+              f"script then starts its own ranks)", file=sys.stderr)
         sys.exit(2)
     # one rank per GPU (the driver's launch); for a rehearsal on a 1-GPU box ranks may share device 0 with
     # LFAMD_DIST_BACKEND=gloo (RCCL refuses two ranks on one device)

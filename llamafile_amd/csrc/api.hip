@@ -77,6 +77,10 @@ hipError_t lfamd_launch_quantize(int, const float *, long, long, size_t, void *,
 hipError_t lfamd_launch_moe(int, const void *, long, long, int, size_t, int, const void *, size_t, int, long,
                             const int32_t *, int, float *, void *, size_t, unsigned, hipStream_t);
 size_t lfamd_moe_workspace(int, long, long, int, long, int);
+int lfamd_gemm_i8_ok(int Atype, long row_blocks128, long n);
+size_t lfamd_gemm_i8_workspace(long k, long n);
+hipError_t lfamd_launch_gemm_i8(int count, const void *const *A, const long *m, long k, int Btype, const void *B, size_t b_row_bytes, long n,
+                                float *const *C, const long *ldc, void *ws, const int32_t *src_idx, hipStream_t s);
 }
 
 static thread_local char g_err[512] = "";
@@ -427,6 +431,14 @@ static bool use_gemm_sb(int Atype, long n, unsigned flags, long k, long m) {
     return tiles_per_cu <= 4 && Atype != LFAMD_TYPE_Q6_K && n >= 6 && n <= 24;
 }
 
+// Q4_K batches on the int8 matrix cores (gemm_i8.hip): exact integer dots; every launch whose 128 x 64 tiles fill at least half
+// the CUs, unless a testing flag asks for one of the f16 bodies
+static bool use_gemm_i8(int Atype, long n, unsigned flags, long k, long row_blocks) {
+    if (flags & (LFAMD_FLAG_FORCE_GENERIC | LFAMD_FLAG_GEMM_NARROW | LFAMD_FLAG_GEMM_WIDE | LFAMD_FLAG_GEMM_PLAIN | LFAMD_FLAG_PRECISE))
+        return false;
+    return n > 8 && k > 0 && k % 256 == 0 && lfamd_gemm_i8_ok(Atype, row_blocks, n);
+}
+
 static bool use_gemv(int Atype, long n, unsigned flags, long k) {
     if (flags & LFAMD_FLAG_FORCE_GENERIC)
         return false;
@@ -511,6 +523,11 @@ int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const v
         size_t need = lfamd_mul_mat_workspace(Atype, m, k, n);
         if (ws_bytes < need || !d_ws)
             return fail(LFAMD_ERR_WORKSPACE, "mul_mat: workspace too small%s", "");
+        if (use_gemm_i8(Atype, n, flags, k, (m + 127) / 128) && (Btype == LFAMD_TYPE_F32 || Btype == LFAMD_TYPE_Q8_K)) {
+            const void *A1 = d_A;
+            HIPCHK(lfamd_launch_gemm_i8(1, &A1, &m, k, Btype, d_B, b_row_bytes, n, &d_C, &ldc, d_ws, nullptr, s), "gemm_i8");
+            return LFAMD_OK;
+        }
         size_t n_pad = align_up((size_t)n, 128), nb = (size_t)(k / 256);
         uint8_t *ws = (uint8_t *)d_ws;
         void *Xh = ws;
@@ -622,9 +639,15 @@ int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const v
         uint8_t *ws8 = (uint8_t *)d_ws;
         const void *img = (const uint8_t *)d_A + q80_p80_bytes(m, k); // f16(d * q) rows, built once by lfamd_pack_weights
         HIPCHK(lfamd_launch_q80_rows_to_f16(Btype, d_B, b_row_bytes, n, k, ws8, s), "q80_rows_to_f16");
-        HIPCHK(lfamd_blaslt_gemm(LFAMD_TYPE_F16, img, k, ws8, k, m, n, k, d_C, ldc, ws8 + align_up((size_t)n * (size_t)k * 2, 256),
-                                 lfamd_blaslt_workspace(), s),
-               "blaslt_gemm (Q8_0)");
+        if (lfamd_blaslt_gemm(LFAMD_TYPE_F16, img, k, ws8, k, m, n, k, d_C, ldc, ws8 + align_up((size_t)n * (size_t)k * 2, 256),
+                              lfamd_blaslt_workspace(), s) == hipSuccess)
+            return LFAMD_OK;
+        // the library declined this shape or this device: the bit-exact kernel on the resident P80 image (the workspace is sized for
+        // either, mul_mat_workspace_base)
+        (void)hipGetLastError();
+        if (ws_bytes < align_up(lfamd_gemm_q80_workspace(k, n), 256))
+            return fail(LFAMD_ERR_WORKSPACE, "mul_mat: workspace too small%s", "");
+        HIPCHK(lfamd_launch_gemm_q80(d_A, m, k, Btype, d_B, b_row_bytes, n, d_C, ldc, d_ws, vregs32, precise, s), "gemm_q80 (library declined)");
         return LFAMD_OK;
     }
     if (use_gemm_q80_mfma(Atype, n, flags, k)) {

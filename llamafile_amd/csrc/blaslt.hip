@@ -10,6 +10,7 @@
 #include "lfamd_device.h"
 
 #include <dlfcn.h>
+#include <stdlib.h>
 #include <hipblaslt/hipblaslt.h>
 
 #include <map>
@@ -57,7 +58,10 @@ bool sym(void *so, const char *name, F &f) {
 }
 
 void load() {
-    if (getenv("LFAMD_NO_BLASLT"))
+    // opt-in (round 4): the module's own kernels are the default for every type; LFAMD_USE_BLASLT=1 selects the vendor GEMM for
+    // plain 16-bit float weights and Q8_0 batches (a yardstick, and a second resident image for Q8_0: lfamd_packed_size)
+    const char *use = getenv("LFAMD_USE_BLASLT");
+    if (!use || atoi(use) == 0 || getenv("LFAMD_NO_BLASLT"))
         return;
     int devices = 0; // (hipblasLtCreate ends the process when there is no device)
     if (hipGetDeviceCount(&devices) != hipSuccess || devices <= 0) {

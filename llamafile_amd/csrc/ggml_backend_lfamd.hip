@@ -693,8 +693,13 @@ int sibling_run(const struct ggml_cgraph *g, int i) {
             break;
         const struct ggml_tensor *a = t->src[0];
         if (id) {
+            // (stacks outside a weights buffer are packed into the context's ONE scratch image per call: two of them cannot be live
+            // together, so such nodes run one by one)
+            const auto kept = [](const struct ggml_tensor *w) {
+                return w->buffer && g_api->ggml_backend_buffer_get_usage(w->buffer) == GGML_BACKEND_BUFFER_USAGE_WEIGHTS;
+            };
             if (t->src[2] != first->src[2] || a->type != a0->type || a->ne[0] != a0->ne[0] || a->ne[1] != a0->ne[1] || a->ne[2] != a0->ne[2] ||
-                !mul_mat_id_supported(t))
+                !mul_mat_id_supported(t) || !kept(a0) || !kept(a))
                 break;
         } else if (a->ne[2] * a->ne[3] != 1 || is_split(a) || !mul_mat_supported(t) || t->nb[1] != (size_t)a->ne[1] * 4 ||
                    lfamd_vec_dot_type(a->type) != lfamd_vec_dot_type(a0->type)) {

@@ -229,7 +229,10 @@ int main(int argc, char **argv) {
     const size_t xo = (h_nbytes(&X) + align - 1) / align * align, io = (ni + align - 1) / align * align;
     ggml_backend_buffer_t cbuf = buft->iface.alloc_buffer(buft, xo + io + h_nbytes(&OUT) + align);
     if (!wbuf || !cbuf) return 10;
-    wbuf->usage = GGML_BACKEND_BUFFER_USAGE_WEIGHTS;
+    /* BACKEND_HOST_NO_WEIGHTS_USAGE: the matrices live in an ordinary buffer (no packed copy is kept: the module packs per call) */
+    const int weights_usage = getenv("BACKEND_HOST_NO_WEIGHTS_USAGE") == NULL;
+    if (weights_usage)
+        wbuf->usage = GGML_BACKEND_BUFFER_USAGE_WEIGHTS;
     W.buffer = wbuf, W.data = wbuf->iface.get_base(wbuf);
     if (wbuf->iface.init_tensor)
         wbuf->iface.init_tensor(wbuf, &W); /* (ggml-alloc calls it for every tensor it places) */
@@ -259,7 +262,8 @@ int main(int argc, char **argv) {
         wbuf2 = buft->iface.alloc_buffer(buft, buft->iface.get_alloc_size(buft, &W2) + align);
         cbuf2 = buft->iface.alloc_buffer(buft, h_nbytes(&OUT) + align);
         if (!wbuf2 || !cbuf2) return 10;
-        wbuf2->usage = GGML_BACKEND_BUFFER_USAGE_WEIGHTS;
+        if (weights_usage)
+            wbuf2->usage = GGML_BACKEND_BUFFER_USAGE_WEIGHTS;
         W2.buffer = wbuf2, W2.data = wbuf2->iface.get_base(wbuf2), W2.extra = NULL;
         wbuf2->iface.set_tensor(wbuf2, &W2, hw, 0, nw);
         OUT2.buffer = cbuf2, OUT2.data = cbuf2->iface.get_base(cbuf2), OUT2.src[0] = &W2;

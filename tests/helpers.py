@@ -32,8 +32,8 @@ def elem_err(C, G, rtol=1e-3):
 
 
 def q80_batch_tol():
-    """Q8_0 batches (n > 8), default flags: with hipBLASLt loadable they are a library GEMM on f16(d * q) x f16(d8 * code) — one f16
-    rounding per operand, the scaled-operand tolerance of the north star (1e-3, measured 2-4e-4); without it the exact-code MFMA
-    body (2e-6).  The bit-exact kernel is LFAMD_FLAG_Q80_EXACT either way."""
-    from llamafile_amd import _hip
-    return 1e-3 if _hip.lib().lfamd_vendor_gemm_available() else 2e-6
+    """Q8_0 batches (n > 8), default flags: the module's MFMA body on exact integer codes with per-block f32 scaling (2e-6).  Only a
+    process that opted into the vendor GEMM (LFAMD_USE_BLASLT=1: f16(d * q) x f16(d8 * code), one f16 rounding per operand) gets the
+    scaled-operand tolerance of the north star (1e-3, measured 2-4e-4).  The bit-exact kernel is LFAMD_FLAG_Q80_EXACT either way."""
+    import os
+    return 1e-3 if os.environ.get("LFAMD_USE_BLASLT", "0") not in ("", "0") else 2e-6

@@ -79,10 +79,10 @@ def test_q8_0_bit_exact(gpu, oracle, variant, precise, shape):
 @pytest.mark.parametrize("shape", [(128, 64, 512), (96, 100, 1024), (33, 9, 256), (256, 512, 2048), (64, 130, 768), (300, 40, 4096)], ids=str)
 @pytest.mark.parametrize("f32in", [False, True], ids=["q80", "f32"])
 def test_q8_0_batches_default(gpu, oracle, shape, f32in):
-    """Q8_0, n > 8, default flags.  hipBLASLt loadable (the GPU box): the vendor GEMM on the resident f16(d * q) image against
-    f16(d8 * code) activations, <= 1e-3 like the scaled K-quant batches; not loadable (LFAMD_NO_BLASLT=1: the subprocess test
-    below): the MFMA body on exact integer codes with per-block f32 scaling, 2e-6 normwise AND element-wise.  Neither is
-    bit-exact: LFAMD_FLAG_Q80_EXACT gives the bit-exact kernel (test_q8_0_bit_exact)."""
+    """Q8_0, n > 8, default flags: the module's MFMA body on exact integer codes with per-block f32 scaling, 2e-6 normwise AND
+    element-wise.  A process that opted into the vendor GEMM (LFAMD_USE_BLASLT=1: the subprocess test below) runs hipBLASLt on the
+    resident f16(d * q) image against f16(d8 * code) activations, <= 1e-3 like the scaled K-quant batches.  Neither is bit-exact:
+    LFAMD_FLAG_Q80_EXACT gives the bit-exact kernel (test_q8_0_bit_exact)."""
     from llamafile_amd import synth
     from helpers import q80_batch_tol
     m, n, k = shape
@@ -101,15 +101,16 @@ def test_q8_0_batches_default(gpu, oracle, shape, f32in):
     assert frac == 0.0, (frac, worst)
 
 
-def test_q8_0_batches_without_the_vendor_library(gpu):
-    """The same cases in a process that cannot load hipBLASLt: the module's own MFMA body on the PC8-form byte image (2e-6)."""
+def test_q8_0_batches_with_the_vendor_library(gpu):
+    """The same cases in a process that opted into hipBLASLt (LFAMD_USE_BLASLT=1): the library GEMM on the f16(d * q) image, <= 1e-3.
+    The default (this process) is the module's own MFMA body on the PC8-form byte image (2e-6)."""
     import os
     import subprocess
     import sys
-    if os.environ.get("LFAMD_NO_BLASLT"):
-        pytest.skip("already the no-library process")
+    if os.environ.get("LFAMD_USE_BLASLT"):
+        pytest.skip("already the opted-in process")
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", __file__, "-k", "test_q8_0_batches_default or test_float_types_mfma_gemm",
-                        "-p", "no:cacheprovider"], env={**os.environ, "LFAMD_NO_BLASLT": "1"}, capture_output=True, text=True, timeout=900)
+                        "-p", "no:cacheprovider"], env={**os.environ, "LFAMD_USE_BLASLT": "1"}, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
