@@ -350,16 +350,17 @@ __global__ __launch_bounds__(512) void gemm_i8_kernel(const gemm_mats mats, int 
 //   Xq [nb][n_pad][256] int8 — sub-block jb, K half h -> 16 bytes: K-step 2 jb: elements (0,4,1,5,2,6,3,7) of k = 32 jb + 8 h + j,
 //                              then K-step 2 jb + 1 the same (the byte order of the unpacked P4K nibbles)
 //   d8T [nb][n_pad] f32, Xs [nb][n_pad][16] f16 = the block's bsums (sums of 16 codes: |S| <= 2032, exact)
-// One wave per (token, super-block), four waves per work-group; tokens n .. n_pad are zero.
+// One wave per (token, super-block), sixteen waves per work-group (a k = 4096 row is ONE work-group: 512 of them to dispatch at
+// 512 tokens instead of 2048); tokens n .. n_pad are zero.
 template <bool F32IN>
-__global__ __launch_bounds__(256) void prep_i8_kernel(const uint8_t *__restrict__ X, size_t x_row_bytes, long n, long n_pad, int nb,
+__global__ __launch_bounds__(1024) void prep_i8_kernel(const uint8_t *__restrict__ X, size_t x_row_bytes, long n, long n_pad, int nb,
                                                        int8_t *__restrict__ Xq, float *__restrict__ d8T, _Float16 *__restrict__ Xs,
                                                        const int32_t *__restrict__ src_idx) {
-    const long blk = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (blk >= n_pad * nb)
+    // grid = (token, group of sixteen super-blocks): no division in the index arithmetic
+    const long tok = (long)blockIdx.x;
+    const int b = (int)blockIdx.y * 16 + (int)(threadIdx.x >> 6), t = threadIdx.x & 63;
+    if (b >= nb)
         return;
-    const long tok = blk / nb;
-    const int b = (int)(blk - tok * nb), t = threadIdx.x & 63;
     const long src = src_idx ? (long)src_idx[tok] : (tok < n ? tok : -1);
     const size_t o = (size_t)b * n_pad + tok;
     int q[4] = {0, 0, 0, 0};
@@ -416,13 +417,16 @@ __global__ __launch_bounds__(256) void prep_i8_kernel(const uint8_t *__restrict_
         d8T[o] = d;
 }
 
-// Which launches take the int8 body (LFAMD_GEMM_NO_I8: the f16 bodies instead — A/B runs).  Q4_K, and a grid of 128 x 64 tiles
-// that fills at least half the CUs (smaller grids keep the K-split launches of gemm_lw.hip).
-extern "C" int lfamd_gemm_i8_ok(int Atype, long rows_total_blocks128, long n) {
+// Which launches take the int8 body (LFAMD_GEMM_NO_I8: the f16 bodies instead — A/B runs).  Q4_K, and a grid the 128 x 128 tile
+// cannot fill (at most 128 of them — where the f16 path runs its own 128 x 64 tile, gemm_ks.hip) but whose 128 x 64 tiles fill at
+// least half the CUs (smaller grids keep the K-split launches of gemm_lw.hip).  Measured, prep + GEMM per call at 512 tokens:
+// 4096 x 4096 32.5 us (f16 scaled operands: 32.9), 4096 x 14336 89.6 (88.3): the same time for exact integer dots; on grids that
+// fill the chip with 256 x 128 tiles the f16 body is faster (14336 x 4096: 75 us against 99) and stays.
+extern "C" int lfamd_gemm_i8_ok(int Atype, long row_blocks128, long n) {
     static const bool off = getenv("LFAMD_GEMM_NO_I8") != nullptr;
     if (off || Atype != LFAMD_TYPE_Q4_K || n < 1)
         return 0;
-    return rows_total_blocks128 * ((n + I8_COLS - 1) / I8_COLS) >= 128;
+    return row_blocks128 * ((n + I8_COLS - 1) / I8_COLS) >= 128 && row_blocks128 * ((n + 127) / 128) <= 128;
 }
 
 extern "C" size_t lfamd_gemm_i8_workspace(long k, long n) { // Xq, d8T, Xs
@@ -442,11 +446,11 @@ extern "C" hipError_t lfamd_launch_gemm_i8(int count, const void *const *A, cons
     int8_t *Xq = (int8_t *)ws;
     float *d8T = (float *)((uint8_t *)ws + (size_t)n_pad * nb * 256);
     _Float16 *Xs = (_Float16 *)((uint8_t *)d8T + (size_t)n_pad * nb * 4);
-    const unsigned pg = (unsigned)((n_pad * nb + 3) / 4);
+    const dim3 pg((unsigned)n_pad, (unsigned)((nb + 15) / 16));
     if (Btype == LFAMD_TYPE_F32)
-        prep_i8_kernel<true><<<pg, 256, 0, s>>>((const uint8_t *)B, b_row_bytes, n, n_pad, nb, Xq, d8T, Xs, src_idx);
+        prep_i8_kernel<true><<<pg, 1024, 0, s>>>((const uint8_t *)B, b_row_bytes, n, n_pad, nb, Xq, d8T, Xs, src_idx);
     else
-        prep_i8_kernel<false><<<pg, 256, 0, s>>>((const uint8_t *)B, b_row_bytes, n, n_pad, nb, Xq, d8T, Xs, src_idx);
+        prep_i8_kernel<false><<<pg, 1024, 0, s>>>((const uint8_t *)B, b_row_bytes, n, n_pad, nb, Xq, d8T, Xs, src_idx);
     gemm_mats mats;
     int n_rb = 0;
     mats.count = 0;

@@ -158,7 +158,8 @@ def test_qkv_two_types_one_gemm_launch(gpu, ta):
     """attn_q / attn_k (Q4_K or Q5_K) and attn_v (Q6_K) at 512 tokens through lfamd_mul_mat_multi_types: 192 tiles of
     128 x 128 in ONE launch whose work-groups run their own type's body.  Against the three separate calls (which run
     128 x 64 tiles): bit-identical where both run the loader-wave body (Q5_K, Q6_K); the separate Q4_K calls run the
-    K-split-waves body (gemm_ks.hip, another f32 order of the same products: <= 4e-6 of the output scale)."""
+    K-split-waves body (gemm_ks.hip, another f32 order of the same products: <= 4e-6 of the output scale) or, the 4096-row one, the
+    int8 body (gemm_i8.hip: exact integer dots, so the scaled-operand launch is <= 1e-3 away)."""
     from llamafile_amd import synth
     k = 4096
     specs = [(ta, 4096), (T.Q6_K, 1024), (ta, 1024)]
@@ -170,7 +171,14 @@ def test_qkv_two_types_one_gemm_launch(gpu, ta):
         sep = gpu.mul_mat(W, xb, T.F32)
         assert torch.isfinite(f).all()
         if W.type == T.Q4_K:
-            assert float((f - sep).abs().max()) / float(sep.abs().max()) <= 4e-6, (T.NAMES[W.type], W.rows)
+            # (a separate 4096 x 4096 call takes the int8 body since round 4 — exact integer dots — while the fused launch runs the
+            # scaled-operand f16 body: one f16 rounding per operand apart)
+            import ctypes as C
+            from llamafile_amd import _hip
+            ok_fn = _hip.lib().lfamd_gemm_i8_ok
+            ok_fn.argtypes, ok_fn.restype = (C.c_int, C.c_long, C.c_long), C.c_int
+            tol = 1e-3 if ok_fn(W.type, (W.rows + 127) // 128, PREFILL) else 4e-6
+            assert float((f - sep).abs().max()) / float(sep.abs().max()) <= tol, (T.NAMES[W.type], W.rows)
         else:
             assert torch.equal(_bits(f), _bits(sep)), (T.NAMES[W.type], W.rows)
 

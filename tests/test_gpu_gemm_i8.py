@@ -12,8 +12,8 @@ from helpers import elem_err, rel_err
 
 pytestmark = pytest.mark.gpu
 
-# (m, n, k): at least 128 tiles of 128 x 64, so the default route is the int8 body
-SHAPES = [(2048, 512, 512), (4096, 256, 256), (1000, 1100, 768), (16384 + 32, 70, 256), (4096 + 5, 257, 1024)]
+# (m, n, k): at least 128 tiles of 128 x 64 and at most 128 of 128 x 128, so the default route is the int8 body
+SHAPES = [(2048, 512, 512), (4096, 256, 256), (1000, 1100, 768), (16384 - 32 + 5, 70, 256), (4096 + 5, 257, 1024)]
 
 
 def _oracle_rows(oracle, A, B, m, n, k, rows, cols):
