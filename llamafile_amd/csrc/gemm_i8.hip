@@ -30,6 +30,7 @@
 typedef int v4i_t __attribute__((ext_vector_type(4)));
 typedef int v16i_t __attribute__((ext_vector_type(16)));
 typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
 #define I8_COLS 64
 #define I8_WQS 0         // 4 row tiles x 4096 B of packed nibbles
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(512) void gemm_i8_kernel(const gemm_mats mats, int 
     //   sub-blocks ahead, SF[2] the bsums fragments, DF[4] a token tile's d8.  A stage ENDS by fetching HD, Q[0], XF[0], XF[1] of
     //   the next one (landed: the barrier at the top of THIS stage said so) and waiting for them, so nothing in flight crosses the
     //   loop's back edge (where hipcc may copy registers).
-    u32x4 HD, Q[2], XF[4][2], SF[2], DF[4];
+    u32x4 HD, Q[2], XF[4][2], SF[2], DF[8];
     {
         i8_dsr<0>(HD, adH);
         i8_dsr<0>(Q[0], adQ);
@@ -242,14 +243,19 @@ __global__ __launch_bounds__(512) void gemm_i8_kernel(const gemm_mats mats, int 
                 i8_dsr<8192>(XF[(jb + 2) & 3][1], adX[jb + 2] + so);
                 if ((jb & 1) == 0)
                     i8_dsr<0>(Q[((jb >> 1) + 1) & 1], adQ + so + (uint32_t)(((jb >> 1) + 1) * 1024));
-            } else if (jb == 6) { // the bsums fragments
+            }
+            if (jb == 4) { // the bsums fragments (their MFMAs go right behind the K loop's last)
                 i8_dsr<0>(SF[0], adS + so);
                 i8_dsr<1024>(SF[1], adS + so);
-            } else { // jb == 7: token tile 0's d8
+            } else if (jb == 6) { // both token tiles' d8, early enough to have landed when the epilogue starts
                 i8_dsr<0>(DF[0], adD + so);
                 i8_dsr<32>(DF[1], adD + so);
                 i8_dsr<64>(DF[2], adD + so);
                 i8_dsr<96>(DF[3], adD + so);
+                i8_dsr<128>(DF[4], adD + so);
+                i8_dsr<160>(DF[5], adD + so);
+                i8_dsr<192>(DF[6], adD + so);
+                i8_dsr<224>(DF[7], adD + so);
             }
             // counted wait for XF[jb & 3] (and, at even jb, Q[(jb >> 1) & 1]): what was issued after them may stay in flight
             u32x4 &xa = XF[jb & 3][0], &xb = XF[jb & 3][1];
@@ -258,17 +264,24 @@ __global__ __launch_bounds__(512) void gemm_i8_kernel(const gemm_mats mats, int 
                 asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(xa), "+v"(xb), "+v"(qg));
             else if (jb == 1)
                 asm volatile("" : "+v"(xa), "+v"(xb)); // (older than what the wait at jb = 0 left in flight)
-            else if (jb < 6)
+            else if (jb < 4)
                 asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(xa), "+v"(xb), "+v"(qg));
+            else if (jb < 6)
+                asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(xa), "+v"(xb), "+v"(qg));
             else if (jb == 6)
-                asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(xa), "+v"(xb), "+v"(qg));
+                asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(xa), "+v"(xb), "+v"(qg));
             else
-                asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(xa), "+v"(xb));
+                asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(xa), "+v"(xb), "+v"(SF[0]), "+v"(SF[1]));
             const int e = jb & 1;
             const uint32_t x0 = e ? qg.z : qg.x, x1 = e ? qg.w : qg.y;
             const uint32_t r0 = x0 & 0x0F0F0F0Fu, r1 = (x0 >> 4) & 0x0F0F0F0Fu, r2 = x1 & 0x0F0F0F0Fu, r3 = (x1 >> 4) & 0x0F0F0F0Fu;
-            const uint32_t sel = 0x0c000c00u | (uint32_t)(jb & 3) | ((uint32_t)(jb & 3) << 16); // [byte, 0, byte, 0]
-            const uint32_t pa = __builtin_amdgcn_perm(0u, jb < 4 ? a03 : a47, sel), pb = __builtin_amdgcn_perm(0u, jb < 4 ? b03 : b47, sel);
+            // the scales of sub-blocks jb, jb ^ 1 as the two 16-bit halves of one register ([a_even, 0, a_odd, 0]); the multiply takes
+            // its half for both products through op_sel (a perm per sub-block PAIR and factor instead of one per sub-block)
+            const uint32_t sel2 = 0x0c000c00u | (uint32_t)(jb & 2) | ((uint32_t)((jb & 2) + 1) << 16);
+            const u16x2_t pa2 = __builtin_bit_cast(u16x2_t, __builtin_amdgcn_perm(0u, jb < 4 ? a03 : a47, sel2));
+            const u16x2_t pb2 = __builtin_bit_cast(u16x2_t, __builtin_amdgcn_perm(0u, jb < 4 ? b03 : b47, sel2));
+            const uint32_t pa = __builtin_bit_cast(uint32_t, (jb & 1) ? __builtin_shufflevector(pa2, pa2, 1, 1) : __builtin_shufflevector(pa2, pa2, 0, 0));
+            const uint32_t pb = __builtin_bit_cast(uint32_t, (jb & 1) ? __builtin_shufflevector(pb2, pb2, 1, 1) : __builtin_shufflevector(pb2, pb2, 0, 0));
             const v4i_t whi = {(int)pk_mul_u16(r0, pa), (int)pk_mul_u16(r1, pa), (int)pk_mul_u16(r2, pa), (int)pk_mul_u16(r3, pa)};
             const v4i_t wlo = {(int)pk_mul_u16(r0, pb), (int)pk_mul_u16(r1, pb), (int)pk_mul_u16(r2, pb), (int)pk_mul_u16(r3, pb)};
             const v4i_t av0 = __builtin_bit_cast(v4i_t, xa), av1 = __builtin_bit_cast(v4i_t, xb);
@@ -285,7 +298,6 @@ __global__ __launch_bounds__(512) void gemm_i8_kernel(const gemm_mats mats, int 
             for (int p = 0; p < 4; p++)
                 wm.p[p] = as_half2(__builtin_amdgcn_perm(0x64646464u, mw, 0x04000400u | (uint32_t)p | ((uint32_t)p << 16))) + m1024;
         }
-        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(SF[0]), "+v"(SF[1]));
         const float16_t_ tm0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, SF[0]), wm.v, zero16, 0, 0, 0);
         const float16_t_ tm1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, SF[1]), wm.v, zero16, 0, 0, 0);
         // acc += d8 * (d * I - dmin * M)  (register r = token 8 (r >> 2) + 4 h + (r & 3) of the token tile)
@@ -293,32 +305,39 @@ __global__ __launch_bounds__(512) void gemm_i8_kernel(const gemm_mats mats, int 
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 // (whole-vector cast: __builtin_bit_cast(float, DF[g].y) on a vector ELEMENT reads element 0 with this hipcc)
-                const float4_t_ d8f = __builtin_bit_cast(float4_t_, DF[g]);
+                const float4_t_ d8f = __builtin_bit_cast(float4_t_, DF[4 * t + g]);
                 const float d8v[4] = {d8f.x, d8f.y, d8f.z, d8f.w};
+#ifndef I8_SCALAR_EPILOGUE // two outputs per v_pk_mul_f32 / v_pk_fma_f32 (the same roundings: every operation is the scalar one, twice)
+#pragma unroll
+                for (int e = 0; e < 4; e += 2) {
+                    const int r = 4 * g + e;
+                    const f32x2_t If = {(float)((hi[t][r] << 3) + lo[t][r]), (float)((hi[t][r + 1] << 3) + lo[t][r + 1])};
+                    const f32x2_t tm2 = {tm[r], tm[r + 1]}, d2 = {d, d}, nd2 = {-dmin, -dmin}, d82 = {d8v[e], d8v[e + 1]};
+                    f32x2_t a2 = {acc[t][r], acc[t][r + 1]};
+                    const f32x2_t u = __builtin_elementwise_fma(nd2, tm2, d2 * If);
+                    a2 = __builtin_elementwise_fma(u, d82, a2);
+                    acc[t][r] = a2.x, acc[t][r + 1] = a2.y;
+                }
+#else
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
                     const int r = 4 * g + e;
                     const float u = fmaf(-dmin, tm[r], d * (float)((hi[t][r] << 3) + lo[t][r]));
                     acc[t][r] = fmaf(u, d8v[e], acc[t][r]);
                 }
+#endif
             }
         };
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(DF[0]), "+v"(DF[1]), "+v"(DF[2]), "+v"(DF[3]));
-        epilogue(0, tm0);
-        // token tile 1's d8 into the same registers, and the next stage's first operands (this stage's once more at the very end:
-        // never used)
-        asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][5]), "+v"(acc[0][10]), "+v"(acc[0][15])); // (tile 0's uses of DF are behind us)
-        i8_dsr<128>(DF[0], adD + so);
-        i8_dsr<160>(DF[1], adD + so);
-        i8_dsr<192>(DF[2], adD + so);
-        i8_dsr<224>(DF[3], adD + so);
+        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(DF[0]), "+v"(DF[1]), "+v"(DF[2]), "+v"(DF[3]));
+        // the next stage's first operands (this stage's once more at the very end: never used)
         i8_dsr<0>(HD, adH + so_n);
         i8_dsr<0>(Q[0], adQ + so_n);
         i8_dsr<0>(XF[0][0], adX[0] + so_n);
         i8_dsr<8192>(XF[0][1], adX[0] + so_n);
         i8_dsr<0>(XF[1][0], adX[1] + so_n);
         i8_dsr<8192>(XF[1][1], adX[1] + so_n);
-        asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(DF[0]), "+v"(DF[1]), "+v"(DF[2]), "+v"(DF[3]));
+        epilogue(0, tm0);
+        asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(DF[4]), "+v"(DF[5]), "+v"(DF[6]), "+v"(DF[7]));
         epilogue(1, tm1);
         // nothing in flight crosses the back edge
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(HD), "+v"(Q[0]), "+v"(XF[0][0]), "+v"(XF[0][1]), "+v"(XF[1][0]), "+v"(XF[1][1]));
@@ -350,71 +369,96 @@ __global__ __launch_bounds__(512) void gemm_i8_kernel(const gemm_mats mats, int 
 //   Xq [nb][n_pad][256] int8 — sub-block jb, K half h -> 16 bytes: K-step 2 jb: elements (0,4,1,5,2,6,3,7) of k = 32 jb + 8 h + j,
 //                              then K-step 2 jb + 1 the same (the byte order of the unpacked P4K nibbles)
 //   d8T [nb][n_pad] f32, Xs [nb][n_pad][16] f16 = the block's bsums (sums of 16 codes: |S| <= 2032, exact)
-// One wave per (token, super-block), sixteen waves per work-group (a k = 4096 row is ONE work-group: 512 of them to dispatch at
-// 512 tokens instead of 2048); tokens n .. n_pad are zero.
+// Half a wave per (token, super-block): lane l holds the EIGHT values 8 (l & 31) + e of block (l >> 5) — one whole 8-code group —
+// so the fixed part of the quantiser (DPP maximum, the two IEEE divisions) is paid once per two blocks, and the group's two
+// dwords (j0, j4, j1, j5), (j2, j6, j3, j7) are built in the lane (the one-wave-per-block form needed ~220 instructions per block
+// and ran 6.2 us at 512 x 4096; this one ~75 per block).  Eight waves per work-group = sixteen super-blocks of one token;
+// tokens n .. n_pad are zero.
 template <bool F32IN>
-__global__ __launch_bounds__(1024) void prep_i8_kernel(const uint8_t *__restrict__ X, size_t x_row_bytes, long n, long n_pad, int nb,
+__global__ __launch_bounds__(512) void prep_i8_kernel(const uint8_t *__restrict__ X, size_t x_row_bytes, long n, long n_pad, int nb,
                                                        int8_t *__restrict__ Xq, float *__restrict__ d8T, _Float16 *__restrict__ Xs,
                                                        const int32_t *__restrict__ src_idx) {
     // grid = (token, group of sixteen super-blocks): no division in the index arithmetic
     const long tok = (long)blockIdx.x;
-    const int b = (int)blockIdx.y * 16 + (int)(threadIdx.x >> 6), t = threadIdx.x & 63;
-    if (b >= nb)
-        return;
+    const int lane = threadIdx.x & 63, grp = lane & 31;
+    const bool hi = lane >= 32;
+    const int b = (int)blockIdx.y * 16 + 2 * (int)(threadIdx.x >> 6) + (hi ? 1 : 0);
+    const bool live = b < nb; // (a block past the row: its half-wave computes on zeros and stores nothing)
     const long src = src_idx ? (long)src_idx[tok] : (tok < n ? tok : -1);
-    const size_t o = (size_t)b * n_pad + tok;
-    int q[4] = {0, 0, 0, 0};
+    const size_t o = (size_t)(live ? b : 0) * n_pad + tok;
+    uint32_t y0 = 0, y1 = 0;
     float d = 0.0f;
-    if (src >= 0) {
-        if constexpr (F32IN) {
-            const float4 f = *(const float4 *)((const float *)(X + src * x_row_bytes) + (size_t)b * 256 + 4 * t);
-            const float v[4] = {f.x, f.y, f.z, f.w};
-            // block maximum by DPP, then the FIRST lane / element that reaches it (quantize_row_q8_K: the first element of largest
-            // magnitude gives the sign of iscale = -128 / max; nearest-even codes clamped at 127; d = 1 / iscale)
-            const float a0 = fabsf(v[0]), a1 = fabsf(v[1]), a2 = fabsf(v[2]), a3 = fabsf(v[3]);
-            float am = fmaxf(fmaxf(a0, a1), fmaxf(a2, a3));
-            am = fmaxf(am, dpp_f32<DPP_XOR1>(am));
-            am = fmaxf(am, dpp_f32<DPP_XOR2>(am));
-            am = fmaxf(am, dpp_f32<DPP_HALF_MIRROR>(am));
-            am = fmaxf(am, dpp_f32<DPP_MIRROR>(am));
-            const float amax = fmaxf(fmaxf(readlane_f32(am, 0), readlane_f32(am, 16)), fmaxf(readlane_f32(am, 32), readlane_f32(am, 48)));
-            const bool m0 = a0 == amax, m1 = a1 == amax, m2 = a2 == amax, m3 = a3 == amax;
-            const unsigned long long ball = __builtin_amdgcn_ballot_w64(m0 || m1 || m2 || m3);
-            const float cand = m0 ? v[0] : (m1 ? v[1] : (m2 ? v[2] : v[3]));
-            const float val = readlane_f32(cand, ball ? __builtin_ctzll(ball) : 0);
-            if (amax != 0.0f) {
-                const float iscale = -128.0f / val;
+    int S = 0; // sum of this lane's eight codes
+    if constexpr (F32IN) {
+        float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (src >= 0 && live) {
+            const float4 *p = (const float4 *)((const float *)(X + src * x_row_bytes) + (size_t)b * 256 + 8 * grp);
+            const float4 va = p[0], vb = p[1];
+            v[0] = va.x, v[1] = va.y, v[2] = va.z, v[3] = va.w, v[4] = vb.x, v[5] = vb.y, v[6] = vb.z, v[7] = vb.w;
+        }
+        // quantize_row_q8_K: the FIRST element of largest magnitude gives the sign of iscale = -128 / max; nearest-even codes
+        // clamped at 127; d = 1 / iscale  (the arithmetic of gemv_impl.h: stage_f32_q8k_wave2)
+        float a[8];
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const int c = (int)rintf(iscale * v[e]);
-                    q[e] = c > 127 ? 127 : c;
-                }
-                d = 1.0f / iscale;
-            }
-        } else {
+        for (int e = 0; e < 8; e++)
+            a[e] = fabsf(v[e]);
+        float am = fmaxf(fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])), fmaxf(fmaxf(a[4], a[5]), fmaxf(a[6], a[7])));
+        am = fmaxf(am, dpp_f32<DPP_XOR1>(am));
+        am = fmaxf(am, dpp_f32<DPP_XOR2>(am));
+        am = fmaxf(am, dpp_f32<DPP_HALF_MIRROR>(am));
+        am = fmaxf(am, dpp_f32<DPP_MIRROR>(am));
+        const float amax_lo = fmaxf(readlane_f32(am, 0), readlane_f32(am, 16)), amax_hi = fmaxf(readlane_f32(am, 32), readlane_f32(am, 48));
+        const float amax = hi ? amax_hi : amax_lo;
+        bool any = false;
+        float cand = v[7];
+#pragma unroll
+        for (int e = 7; e >= 0; e--) { // the FIRST element that reaches the maximum wins
+            const bool me = a[e] == amax;
+            cand = me ? v[e] : cand;
+            any = any || me;
+        }
+        const unsigned long long ball = __builtin_amdgcn_ballot_w64(any);
+        const uint32_t blo = (uint32_t)ball, bhi = (uint32_t)(ball >> 32);
+        const int first_lo = blo ? __builtin_ctz(blo) : 0, first_hi = 32 + (bhi ? __builtin_ctz(bhi) : 0);
+        const float val_lo = readlane_f32(cand, first_lo), val_hi = readlane_f32(cand, first_hi);
+        const bool nz = amax != 0.0f;
+        const float val = nz ? (hi ? val_hi : val_lo) : 1.0f;
+        const float iscale = -128.0f / val;
+        // bytes (j0, j4, j1, j5) | (j2, j6, j3, j7)
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            int q = (int)rintf(iscale * v[e]);
+            q = q > 127 ? 127 : q;
+            q = nz ? q : 0;
+            S += q;
+            const int pos = (e >> 2) + 2 * (e & 1); // byte of element e inside its dword: e = 0, 4 -> 0, 1; 1, 5 -> 2, 3; ...
+            if (((e >> 1) & 1) == 0)
+                y0 |= (uint32_t)(q & 0xff) << (8 * pos);
+            else
+                y1 |= (uint32_t)(q & 0xff) << (8 * pos);
+        }
+        d = nz ? 1.0f / iscale : 0.0f;
+    } else {
+        if (src >= 0 && live) {
             const lfamd_block_q8_K *y = (const lfamd_block_q8_K *)(X + src * x_row_bytes) + b;
-            const uint32_t w = *(const uint32_t *)((const uint8_t *)y->qs + 4 * t); // 292-byte blocks are 4-aligned
+            const uint32_t w0 = *(const uint32_t *)((const uint8_t *)y->qs + 8 * grp), w1 = *(const uint32_t *)((const uint8_t *)y->qs + 8 * grp + 4);
+            y0 = __builtin_amdgcn_perm(w1, w0, 0x05010400u); // (j0, j4, j1, j5)
+            y1 = __builtin_amdgcn_perm(w1, w0, 0x07030602u); // (j2, j6, j3, j7)
 #pragma unroll
             for (int e = 0; e < 4; e++)
-                q[e] = (int)(int8_t)(w >> (8 * e));
+                S += (int)(int8_t)(w0 >> (8 * e)) + (int)(int8_t)(w1 >> (8 * e));
             d = y->d;
         }
     }
-    // lanes (t, t ^ 1) hold elements j = 0..3 / 4..7 of one (sub-block, K-step, K half) group of eight: the even lane writes
-    // bytes (j0, j4, j1, j5), the odd lane (j2, j6, j3, j7)
-    const uint32_t own = (uint32_t)(q[0] & 0xff) | ((uint32_t)(q[1] & 0xff) << 8) | ((uint32_t)(q[2] & 0xff) << 16) | ((uint32_t)(q[3] & 0xff) << 24);
-    const uint32_t oth = dpp_u32<DPP_XOR1>(own);
-    const uint32_t lo4 = (t & 1) ? oth : own, hi4 = (t & 1) ? own : oth; // elements 0..3, 4..7
-    const uint32_t word = (t & 1) ? __builtin_amdgcn_perm(hi4, lo4, 0x07030602u) : __builtin_amdgcn_perm(hi4, lo4, 0x05010400u);
-    // group position: sub-block t >> 3 (32 B), K half (t >> 1) & 1 (16 B), K-step (t >> 2) & 1 (8 B), then this lane's dword
-    *(uint32_t *)(Xq + o * 256 + (t >> 3) * 32 + ((t >> 1) & 1) * 16 + ((t >> 2) & 1) * 8 + (t & 1) * 4) = word;
-    int S = q[0] + q[1] + q[2] + q[3]; // bsums[t / 4]: codes 16 (t / 4) .. + 15
-    S += (int)dpp_u32<DPP_XOR1>((uint32_t)S);
-    S += (int)dpp_u32<DPP_XOR2>((uint32_t)S);
-    if ((t & 3) == 0)
-        Xs[o * 16 + (t >> 2)] = (_Float16)(float)S;
-    if (t == 0)
-        d8T[o] = d;
+    // group grp = codes 8 grp .. 8 grp + 7: sub-block grp >> 2, K-step (grp >> 1) & 1, K half grp & 1
+    S += (int)dpp_u32<DPP_XOR1>((uint32_t)S); // bsums[grp / 2]: codes 16 (grp / 2) .. + 15
+    if (live) {
+        *(uint2 *)(Xq + o * 256 + (grp >> 2) * 32 + (grp & 1) * 16 + ((grp >> 1) & 1) * 8) = make_uint2(y0, y1);
+        if ((grp & 1) == 0)
+            Xs[o * 16 + (grp >> 1)] = (_Float16)(float)S;
+        if (grp == 0)
+            d8T[o] = d;
+    }
 }
 
 // Which launches take the int8 body (LFAMD_GEMM_NO_I8: the f16 bodies instead — A/B runs).  Q4_K, and a grid the 128 x 128 tile
@@ -448,9 +492,9 @@ extern "C" hipError_t lfamd_launch_gemm_i8(int count, const void *const *A, cons
     _Float16 *Xs = (_Float16 *)((uint8_t *)d8T + (size_t)n_pad * nb * 4);
     const dim3 pg((unsigned)n_pad, (unsigned)((nb + 15) / 16));
     if (Btype == LFAMD_TYPE_F32)
-        prep_i8_kernel<true><<<pg, 1024, 0, s>>>((const uint8_t *)B, b_row_bytes, n, n_pad, nb, Xq, d8T, Xs, src_idx);
+        prep_i8_kernel<true><<<pg, 512, 0, s>>>((const uint8_t *)B, b_row_bytes, n, n_pad, nb, Xq, d8T, Xs, src_idx);
     else
-        prep_i8_kernel<false><<<pg, 1024, 0, s>>>((const uint8_t *)B, b_row_bytes, n, n_pad, nb, Xq, d8T, Xs, src_idx);
+        prep_i8_kernel<false><<<pg, 512, 0, s>>>((const uint8_t *)B, b_row_bytes, n, n_pad, nb, Xq, d8T, Xs, src_idx);
     gemm_mats mats;
     int n_rb = 0;
     mats.count = 0;

@@ -60,7 +60,9 @@ extern "C" int lfamd_debug_kr_oob(unsigned long long *dst) {
 #endif
 
 // mats.rb_end counts 256-ROW blocks here (lfamd_kr_go)
-template <int TYPE>
+// MOE: GGML_OP_MUL_MAT_ID batches (gemm_mats: token slots grouped by expert; the grid covers the worst case, work-groups beyond an
+// expert's rows exit at once; slot -> result row through moe_slot_row)
+template <int TYPE, bool MOE = false>
 __global__ __launch_bounds__(512) void gemm_kr_kernel(const gemm_mats mats, int nb, const _Float16 *__restrict__ Xh,
                                                       const float *__restrict__ d8T, const _Float16 *__restrict__ Xm, long n,
                                                       long n_pad, int n_rb, int n_ct) {
@@ -74,24 +76,36 @@ __global__ __launch_bounds__(512) void gemm_kr_kernel(const gemm_mats mats, int 
     const int np = 2 * nb; // periods
 
     // ---- tile of this work-group: XCD-aware super-tiles (gemm_common.h tile_of) over (256-row block, 128-token tile)
-    int rb, ct;
-    {
+    int rb, ct, mj = 0, moe_left = 0;
+    long n0;
+    const uint8_t *__restrict__ A;
+    if constexpr (MOE) { // (expert, row block) fastest, token tile slowest: the order of gemm_lw's grouped launch
+        const int per_ct = (int)gridDim.x / mats.moe_ct_max;
+        ct = (int)blockIdx.x / per_ct;
+        const int rem = (int)blockIdx.x - ct * per_ct;
+        const int e = rem / n_rb;
+        rb = rem - e * n_rb;
+        moe_left = mats.moe_cnt[e] - ct * KR_COLS;
+        if (moe_left <= 0)
+            return;
+        A = mats.A[0] + (size_t)e * mats.expert_bytes;
+        n0 = (long)mats.moe_poff[e] + (long)ct * KR_COLS;
+    } else {
         const int n_wg = n_rb * n_ct;
         const int id = (int)blockIdx.x, q8 = n_wg >> 3, r8 = n_wg & 7, xcd = id & 7;
         const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3);
         tile_of(L, n_rb, n_ct, rb, ct);
-    }
-    int mj = 0;
 #pragma unroll
-    for (int jj = 1; jj < GEMM_MAX_MATS; jj++)
-        if (jj < mats.count && rb >= mats.rb_end[jj - 1])
-            mj = jj;
-    if (mj > 0)
-        rb -= mats.rb_end[mj - 1];
-    const uint8_t *__restrict__ A = mats.A[mj];
+        for (int jj = 1; jj < GEMM_MAX_MATS; jj++)
+            if (jj < mats.count && rb >= mats.rb_end[jj - 1])
+                mj = jj;
+        if (mj > 0)
+            rb -= mats.rb_end[mj - 1];
+        A = mats.A[mj];
+        n0 = (long)ct * KR_COLS;
+    }
     float *__restrict__ C = mats.C[mj];
     const long m = mats.m[mj], ldc = mats.ldc[mj];
-    const long n0 = (long)ct * KR_COLS;
     const long n_row_tiles = (m + 31) / 32;
     const long rt = (long)rb * 8 + wave;
     const bool active = rt < n_row_tiles;
@@ -481,13 +495,14 @@ __global__ __launch_bounds__(512) void gemm_kr_kernel(const gemm_mats mats, int 
 #pragma unroll
         for (int nt = 0; nt < 4; nt++) {
             const long tok = n0 + nt * 32 + i;
-            if (tok >= n)
+            if (MOE ? nt * 32 + i >= moe_left : tok >= n)
                 continue;
             const float ts = d8T[tok]; // 2^e of the token's normalised staging (pack.hip, prep_scaled_kernel): exact
+            const long crow = MOE ? (long)mats.moe_slot_row[tok] : tok;
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 const long row0 = rt * 32 + 8 * g + 4 * h;
-                float *dst = C + tok * ldc + row0;
+                float *dst = C + crow * ldc + row0;
 #ifdef KR_BOUNDS
                 {
                     bool bad_ = false;
@@ -532,5 +547,18 @@ hipError_t lfamd_kr_go(int Atype, const gemm_mats &mats128, int nb, const void *
     }
     gemm_kr_kernel<LFAMD_TYPE_Q4_K><<<(unsigned)(n_rb * n_ct), 512, 0, s>>>(mats, nb, (const _Float16 *)Xh, (const float *)d8T,
                                                                              (const _Float16 *)Xm, n, n_pad, n_rb, n_ct);
+    return hipGetLastError();
+}
+
+// GGML_OP_MUL_MAT_ID batches on scaled operands: one launch over (token tile, expert, 256-row block); mats as
+// lfamd_launch_gemm_wide_moe fills it.  (512 tokens x top-2 of 8 experts = 128 rows per expert: one 128-token tile each, and a
+// dequantised fragment feeds four MFMAs instead of the loader-wave body's 128-row work-groups.)
+hipError_t lfamd_kr_moe_go(int Atype, const gemm_mats &mats, int nb, const void *Xh, const void *d8T, const void *Xm, long n_pad, int experts,
+                           int ct_max, hipStream_t s) {
+    if (Atype != LFAMD_TYPE_Q4_K || nb < 1 || experts < 1 || ct_max < 1)
+        return hipErrorInvalidValue;
+    const int n_rb = (int)((mats.m[0] + 255) / 256);
+    gemm_kr_kernel<LFAMD_TYPE_Q4_K, true><<<(unsigned)(experts * n_rb * ct_max), 512, 0, s>>>(mats, nb, (const _Float16 *)Xh, (const float *)d8T,
+                                                                                              (const _Float16 *)Xm, n_pad, n_pad, n_rb, ct_max);
     return hipGetLastError();
 }

@@ -22,6 +22,8 @@ bool lfamd_ks_ok(int Atype);
 bool lfamd_kr_ok(int Atype);
 hipError_t lfamd_kr_go(int Atype, const gemm_mats &mats128, int nb, const void *Xh, const void *d8T, const void *Xm, long n, long n_pad,
                        int n_ct, hipStream_t s);
+hipError_t lfamd_kr_moe_go(int Atype, const gemm_mats &mats, int nb, const void *Xh, const void *d8T, const void *Xm, long n_pad, int experts,
+                           int ct_max, hipStream_t s);
 hipError_t lfamd_ks_go(int Atype, const gemm_mats &mats, int nb, const void *Xh, const void *d8T, const void *Xm, long n, long n_pad,
                        int n_rb, int n_ct, hipStream_t s);
 hipError_t lfamd_lw_ksplit_reduce(const float *P, int ks, long n, long n_pad, long ldp, long m, float *C, long ldc,
@@ -301,5 +303,9 @@ extern "C" hipError_t lfamd_launch_gemm_wide_moe(int Atype, const void *W, long 
     const unsigned n_wg = (unsigned)experts * n_rb * ct_max;
     if (Atype != LFAMD_TYPE_Q4_K && Atype != LFAMD_TYPE_Q5_K && Atype != LFAMD_TYPE_Q6_K)
         return hipErrorInvalidValue;
+    // scaled operands, Q4_K experts: the 256 x 128 row-split body (gemm_kr.hip) — LFAMD_MOE_NO_KR: the loader-wave body (A/B runs)
+    static const bool no_kr = getenv("LFAMD_MOE_NO_KR") != nullptr;
+    if ((mode & 2) && lw_allowed(mode) && !no_kr && lfamd_kr_ok(Atype))
+        return lfamd_kr_moe_go(Atype, mats, nb, Xh, d8T, Xm, n_pad, experts, ct_max, s);
     return wide_go(Atype, mode, nullptr, 0, mats, nb, Xh, d8T, Xm, n_pad, n_pad, n_rb, ct_max, 1, nb, n_wg, 1, s);
 }

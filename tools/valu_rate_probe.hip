@@ -29,6 +29,37 @@
 #define I_MULU24(k) "v_mul_u32_u24 %" #k ", %8, %" #k "\n\t"
 #define I_MADI24(k) "v_mad_i32_i24 %" #k ", %8, %" #k ", %" #k "\n\t"
 #define I_PKMAD(k) "v_pk_mad_u16 %" #k ", %8, %" #k ", %" #k "\n\t"
+#define I_PKFMA32(k) "v_pk_fma_f32 %" #k ", %9, %" #k ", %" #k "\n\t"
+#define I_PKMUL32(k) "v_pk_mul_f32 %" #k ", %9, %" #k "\n\t"
+
+#define BODY8_64(INS)                                                                                                         \
+    asm volatile(INS(0) INS(1) INS(2) INS(3) INS(4) INS(5) INS(6) INS(7) INS(0) INS(1) INS(2) INS(3) INS(4) INS(5) INS(6) INS(7) \
+                 INS(0) INS(1) INS(2) INS(3) INS(4) INS(5) INS(6) INS(7) INS(0) INS(1) INS(2) INS(3) INS(4) INS(5) INS(6) INS(7) \
+                 INS(0) INS(1) INS(2) INS(3) INS(4) INS(5) INS(6) INS(7) INS(0) INS(1) INS(2) INS(3) INS(4) INS(5) INS(6) INS(7) \
+                 INS(0) INS(1) INS(2) INS(3) INS(4) INS(5) INS(6) INS(7) INS(0) INS(1) INS(2) INS(3) INS(4) INS(5) INS(6) INS(7) \
+                 : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7])               \
+                 : "v"(s), "v"(s2))
+#define KERNEL64(NAME, INS)                                                                                                   \
+    __global__ void NAME(unsigned long long *out, uint32_t *sink) {                                                           \
+        typedef float f2 __attribute__((ext_vector_type(2)));                                                                \
+        f2 q[8];                                                                                                              \
+        for (int k = 0; k < 8; k++)                                                                                           \
+            q[k] = f2{(float)(threadIdx.x + k), 1.0f};                                                                        \
+        uint32_t s = threadIdx.x | 0x01010101u;                                                                               \
+        f2 s2 = {1.0001f, 0.9999f};                                                                                           \
+        __syncthreads();                                                                                                      \
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();                                                           \
+        for (int i = 0; i < REPS; i++)                                                                                        \
+            BODY8_64(INS);                                                                                                    \
+        asm volatile("s_nop 0" ::: "memory");                                                                                 \
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime();                                                           \
+        if ((threadIdx.x & 63) == 0)                                                                                          \
+            out[blockIdx.x * 16 + (threadIdx.x >> 6)] = t1 - t0;                                                              \
+        float acc = 0;                                                                                                        \
+        for (int k = 0; k < 8; k++)                                                                                           \
+            acc += q[k].x + q[k].y;                                                                                           \
+        sink[blockIdx.x * blockDim.x + threadIdx.x] = __builtin_bit_cast(uint32_t, acc);                                      \
+    }
 
 #define KERNEL(NAME, INS)                                                                                                     \
     __global__ void NAME(unsigned long long *out, uint32_t *sink) {                                                           \
@@ -60,6 +91,8 @@ KERNEL(k_andor, I_ANDOR)
 KERNEL(k_mulu24, I_MULU24)
 KERNEL(k_madi24, I_MADI24)
 KERNEL(k_pkmad, I_PKMAD)
+KERNEL64(k_pkfma32, I_PKFMA32)
+KERNEL64(k_pkmul32, I_PKMUL32)
 
 int main() {
     unsigned long long *out, h[256 * 16];
@@ -72,7 +105,7 @@ int main() {
     } ks[] = {{"v_and_b32", k_and},         {"v_lshrrev_b32", k_lshr},   {"v_and_or_b32", k_andor}, {"v_perm_b32", k_perm},
               {"v_pk_mul_lo_u16", k_pkmul}, {"v_pk_mad_u16", k_pkmad},   {"v_mul_u32_u24", k_mulu24}, {"v_mad_i32_i24", k_madi24},
               {"v_lshl_add_u32", k_lshladd}, {"v_cvt_f32_i32", k_cvt},   {"v_mul_f32", k_mul},      {"v_fma_f32", k_fma},
-              {"v_pk_add_f16", k_pkaddh}};
+              {"v_pk_add_f16", k_pkaddh}, {"v_pk_fma_f32", k_pkfma32}, {"v_pk_mul_f32", k_pkmul32}};
     for (auto &k : ks)
         for (int waves : {4, 8, 16}) {
             hipMemset(out, 0, sizeof(h));
