@@ -45,10 +45,6 @@ def parse():
     p.add_argument("--decode", type=int, default=128)
     p.add_argument("--no-graph", action="store_true")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--ffn-block", action="store_true",
-                   help="decode: ffn_gate + ffn_up + silu*up + ffn_down as ONE lfamd_ffn_block launch (measured SLOWER than the "
-                        "separate launches on MI355X — 53 vs 23 us per block: its grid barrier costs ~26 us under the weight "
-                        "stream against ~2.6 us for the launch boundary it replaces; DESIGN.md section 4 — so off by default)")
     p.add_argument("--force-dist", action="store_true",
                    help="rehearsal: initialise the process group and issue the collectives even at world size 1")
     p.add_argument("--model", default="llama3-8b-q4_k_m", choices=["llama3-8b-q4_k_m", "llama3-8b-q8_0", "llama3-70b-q4_k_m"])
@@ -73,7 +69,6 @@ class Runner:
         self.collectives = collectives
         self.comm = comm  # llamafile_amd.tp.Comm (the C ABI's collectives); None: torch.distributed (LFAMD_COLLECTIVES=torch)
         self.flags = sgemm.host_variant_flags()
-        self.fuse_ffn = False  # batch 1: ffn_gate + ffn_up + swiglu + ffn_down as one launch (lfamd_ffn_block; --ffn-block)
         self.layers = []
         seed = 0x5EED0000
         for layer in layers:
@@ -143,9 +138,7 @@ class Runner:
         return groups
 
     def prepare(self, n):
-        """Pre-build the ctypes argument arrays of every launch of a pass at batch n.  At batch 1 a layer's ffn_gate + ffn_up
-        group followed by its ffn_down becomes ONE lfamd_ffn_block launch (gate / up GEMV, silu * up, Q8_K, down GEMV) when
-        the fused form covers the types and sizes (self.fuse_ffn; --no-ffn-block keeps the separate launches)."""
+        """Pre-build the ctypes argument arrays of every launch of a pass at batch n."""
         b = self.buf[n]
         calls = []
         for ops in self.layers:
@@ -155,21 +148,6 @@ class Runner:
                 g = groups[gi]
                 o0 = g[0]
                 x = b["x"][(o0.spec.input, o0.k)]
-                nxt = groups[gi + 1] if gi + 1 < len(groups) else None
-                if (n == 1 and self.fuse_ffn and len(g) == 2 and nxt is not None and len(nxt) == 1 and
-                        g[0].spec.name.endswith("ffn_gate") and g[1].spec.name.endswith("ffn_up") and
-                        nxt[0].spec.name.endswith("ffn_down") and g[0].spec.type == g[1].spec.type == T.Q4_K and g[0].m == g[1].m and
-                        g[0].k <= 4096 and nxt[0].k == g[0].m and nxt[0].k <= 15360 and nxt[0].spec.type in (T.Q4_K, T.Q6_K)):
-                    od = nxt[0]
-                    key = (od.m, 0)
-                    if key not in b["out"]:
-                        b["out"][key] = torch.empty((n, od.m), dtype=torch.float32, device=self.dev)
-                    out = b["out"][key]
-                    if "ffn_ws" not in b:
-                        b["ffn_ws"] = torch.empty(int(self.L.lfamd_ffn_block_workspace(g[0].m)), dtype=torch.uint8, device=self.dev)
-                    calls.append(("ffn", g + [od], x, [out], None, None, None, None))
-                    gi += 2
-                    continue
                 cnt = len(g)
                 outs = []
                 for j, o in enumerate(g):
@@ -187,8 +165,7 @@ class Runner:
 
     def run_pass(self, n, only_type=None):
         """Launch every GGML_OP_MUL_MAT of the model at batch n on the current stream: f32 activations in
-        (quantisation is fused into the kernels), sibling ops sharing an input fused per layer, the feed-forward block one
-        launch at batch 1.  `only_type`: restrict to the launches all of whose matrices are of one weight type, no collectives
+        (quantisation is fused into the kernels), sibling ops sharing an input fused per layer.  `only_type`: restrict to the launches all of whose matrices are of one weight type, no collectives
         (roofline measurement).  Returns (launches, ops)."""
         L, b = self.L, self.buf[n]
         if "calls" not in b:
@@ -200,29 +177,6 @@ class Runner:
             o0 = g[0]
             types = {o.spec.type for o in g}
             if only_type is not None and types != {only_type}:
-                continue
-            if kind == "ffn":
-                og, ou, od = g
-                fw = b["ffn_ws"]
-                rc = L.lfamd_ffn_block(og.spec.type, C.c_void_p(og.W.data.data_ptr()), C.c_void_p(ou.W.data.data_ptr()), og.m, og.k,
-                                       od.spec.type, C.c_void_p(od.W.data.data_ptr()), od.m, C.c_void_p(x.data_ptr()), None,
-                                       C.c_void_p(outs[0].data_ptr()), C.c_void_p(fw.data_ptr()), fw.numel(), stream)
-                if rc:
-                    _hip.check(rc, "ffn_block " + og.spec.name)
-                launches += 1
-                nops += 3
-                if only_type is None and self.collectives and od.spec.shard == "cols":
-                    if self.comm is not None:
-                        self.comm.allreduce_add(outs[0])
-                    else:
-                        torch.distributed.all_reduce(outs[0])
-                continue
-            if (n == 1 and len(g) == 1 and only_type is None and self.collectives and o0.spec.shard == "cols" and self.comm is not None
-                    and getattr(self.comm, "fused_ok", False) and outs[0].numel() * 4 <= self.comm.oneshot_eff):
-                # decode attn_output: the product and the all-reduce of its partial in ONE launch (lfamd_mul_mat_allreduce)
-                self.comm.mul_mat_allreduce(o0.W, x, T.F32, residual=None, out=outs[0], partial=outs[0], workspace=b["ws"])
-                launches += 1
-                nops += 1
                 continue
             rc = L.lfamd_mul_mat_multi_types(len(g), t_arr, A_arr, m_arr, o0.k, T.F32, C.c_void_p(x.data_ptr()),
                                              x.stride(0) * 4, n, C_arr, m_arr, ws, wsn, self.flags, stream)
@@ -412,46 +366,12 @@ def make_comm(rank, world, same_device=False):
         if abs(float(big[0].item()) - world * (world + 1) / 2) > 1e-3 or abs(float(big[-1].item()) - world * (world + 1) / 2) > 1e-3:
             raise RuntimeError("RCCL all-reduce through the C ABI returned a wrong sum")
     comm.oneshot_eff = oneshot if (oneshot and world > 1 and "self-test failed" not in comm.mode) else 0
-    # the fused form (decode product + exchange in one launch): trusted only if it gives the two-launch form's bits here
-    comm.fused_ok = False
-    comm.fused_test = "not run"
-    # (run only on request — LFAMD_FUSED_EXCHANGE=1 — so that a default scaling run executes nothing round 2 did not)
-    if comm.oneshot_eff and os.environ.get("LFAMD_FUSED_EXCHANGE") and not os.environ.get("LFAMD_NO_FUSED_EXCHANGE"):
-        from llamafile_amd import sgemm, synth
-        m_t, k_t = 4096, 1024
-        Wt = sgemm.upload_weights(T.Q4_K, synth.random_weights(T.Q4_K, m_t, k_t, 900 + rank), m_t, k_t)
-        bad = 0
-        for it in range(8):
-            if it % 4 == 3:
-                time.sleep(1e-3 * rank)
-            xt = torch.from_numpy(synth.random_activations(1, k_t, 950 + 8 * rank + it)).cuda()
-            two = sgemm.mul_mat(Wt, xt.view(torch.uint8).view(1, k_t * 4), T.F32, n=1)
-            comm.allreduce_add(two)
-            one = comm.mul_mat_allreduce(Wt, xt, T.F32)
-            torch.cuda.synchronize()
-            if not torch.equal(one, two):
-                bad += 1
-        good = comm.check() == 0 and bad == 0
-        flag = torch.tensor([1 if good else 0])
-        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
-        comm.fused_ok = bool(int(flag.item()))
-        comm.fused_test = "passed 8/8 on every rank" if comm.fused_ok else f"FAILED ({bad}/8 differ on rank {rank}) -> two launches"
-        # Used only on request: in the one measurement this lease allows (two ranks sharing one GPU) the fused form is SLOWER,
-        # 1.612 against 1.547 ms per decode pass (profiles/r03_fused_exchange_rehearsal.json) — every work-group pays a store
-        # acknowledgement and an atomic before it retires, which costs what the saved launch boundary gives
-        comm.fused_use = comm.fused_ok and bool(os.environ.get("LFAMD_FUSED_EXCHANGE"))
-        comm.fused_ok = comm.fused_use
-        if not good:
-            comm.clear_error()
     rccl_on = use_rccl or "self-test failed" in comm.mode
     comm.describe = lambda: (
         (f"all-reduce <= {comm.oneshot_eff} B: one-shot peer kernel in fine-grained memory (self-test {comm.selftest}); " if comm.oneshot_eff else "")
         + ("larger all-reduces and the logits all-gather: ncclAllReduce / ncclAllGather (RCCL, known-answer check passed)" if rccl_on
            else "no RCCL (ranks share a device): every size on the one-shot kernel")
-        + ", through the C ABI"
-        + (f"; decode attn_output product + exchange in one launch: self-test {comm.fused_test}, "
-           + ("in use" if getattr(comm, "fused_use", False) else "not used") if comm.fused_test != "not run"
-           else "; attn_output product and exchange as two launches (the fused form, LFAMD_FUSED_EXCHANGE=1, measured slower)" if comm.oneshot_eff else ""))
+        + ", through the C ABI")
     comm.has_rccl = use_rccl or "self-test failed" in comm.mode
     comm.oneshot = oneshot if "self-test failed" not in comm.mode else 0
     return comm
@@ -615,7 +535,6 @@ def run():
         layers = {"llama3-8b-q4_k_m": LS.llama3_8b_q4_k_m, "llama3-8b-q8_0": LS.llama3_8b_q8_0,
                   "llama3-70b-q4_k_m": LS.llama3_70b_q4_k_m}[a.model]()
     runner = Runner(layers, rank, world, (a.prefill, 1), dev, collectives=dist_on, comm=comm, tensors=gguf_tensors)
-    runner.fuse_ffn = a.ffn_block
 
     def barrier():
         torch.cuda.synchronize()
@@ -784,16 +703,10 @@ def run():
     avg_us = us / n_launch
     # algorithmic bytes per launch: weights once + f32 activations (once per launch: sibling
     # ops fused into a launch share them) + f32 outputs
-    # (a fused feed-forward launch: its three matrices, the f32 row in, the f32 row out — gate / up / h never leave the chip's
-    # caches as far as the algorithm is concerned)
     dom_calls = [c for c in runner.buf[1]["calls"] if {o.spec.type for o in c[1]} == {dom_type}]
     alg_bytes = 0
     for kind, g, *_ in dom_calls:
-        if kind == "ffn":
-            alg_bytes += sum(o.m * T.row_size(dom_type, o.k) for o in g) + g[0].k * 4 + g[2].m * 4
-        else:
-            alg_bytes += sum(o.m * T.row_size(dom_type, o.k) + o.m * 4 for o in g) + g[0].k * 4
-    n_fused = sum(1 for c in dom_calls if c[0] == "ffn")
+        alg_bytes += sum(o.m * T.row_size(dom_type, o.k) + o.m * 4 for o in g) + g[0].k * 4
     avg_bytes = alg_bytes / launches_per_pass
     achieved = avg_bytes / (avg_us * 1e-6) / 1e9
     # HBM traffic per launch: from the rocprofv3 PMC passes of this same workload (tools/profile_round.sh:
@@ -814,8 +727,7 @@ def run():
         except (KeyError, ValueError, OSError):
             tj = None
     if dom_type == T.Q4_K:
-        kname = ("gemv_kq_kernel<q4k_traits, 1, F32, {16 | 8 waves}, {1,2}>" +
-                 (f" + ffn_block_kernel<q4k, q4k> ({n_fused} fused feed-forward launches)" if n_fused else "") +
+        kname = ("gemv_kq_kernel<q4k_traits, 1, F32, {16 | 8 waves}, {1,2}>"
                  " (all decode launches of a pass whose matrices are all Q4_K)")
     elif dom_type == T.Q8_0:
         kname = "gemv_q80_kernel<1, F32, mode>"
@@ -836,7 +748,10 @@ def run():
         tf = fl / (gus * 1e-6) / 1e12
         roofline_gemm = {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(tf / MFMA_F16_PEAK_TFLOPS, 4),
-                         "kernel": "prep_scaled_kernel + gemm_ks_kernel<Q4_K> (128x64 tile, K-split waves, scaled operands; 128 tiles of 128x128 cannot fill 256 CUs)",
+                         "kernel": ("prep_i8_kernel + gemm_i8_kernel (128x64 tile, int8 matrix cores: exact integer sub-block dots, loader waves + one "
+                                    "computing wave per SIMD; 128 tiles of 128x128 cannot fill 256 CUs)"
+                                    if _hip.lib().lfamd_mul_mat_is_exact(o.W.type, o.m, o.k, a.prefill, runner.flags) else
+                                    "prep_scaled_kernel + gemm_ks_kernel<Q4_K> (128x64 tile, K-split waves, scaled operands)"),
                          "shape": [o.m, o.k, a.prefill], "avg_launch_us": round(gus, 2)}
         # the same measurement on the largest Q4_K shape of the model (256x128 row-split body, gemm_kr.hip)
         big = [q for q in runner.layers[0] if q.W.type == T.Q4_K and q.m >= 8192]
@@ -891,11 +806,12 @@ def run():
         "dtype": "int8",
         "data": "synthetic" if not a.gguf else f"weights of {os.path.basename(a.gguf)} (GGUF v{gguf_file.version}, {len(gguf_tensors)} mat-mul tensors), synthetic activations",
         "config": {
-            "workload": f"{a.model} mat-muls ({sum(len(l) for l in layers)} GGML_OP_MUL_MAT per pass, f32 activations in, quantisation fused, sibling ops fused at decode" + (", feed-forward block (gate, up, silu*up, Q8_K, down) one launch at decode" if a.ffn_block else "") + "), "
+            "workload": f"{a.model} mat-muls ({sum(len(l) for l in layers)} GGML_OP_MUL_MAT per pass, f32 activations in, quantisation fused, sibling ops fused at decode" + "), "
                         f"{a.prefill}-token prefill + {a.decode} decode, matmul-only",
-            "numerics": "decode: exact int8 x int4/int6 block dot products with f32 scales (v_dot4_i32_i8); prefill: f16 MFMA, "
-                        "f32 accumulate, Q4_K and Q6_K on scaled operands f16(d*sc*q) x f16(d8*code) (<= 1e-3 relative, measured "
-                        "~3e-4; exact integer codes with LFAMD_FLAG_PRECISE)",
+            "numerics": "decode: exact int8 x int4/int6 block dot products with f32 scales (v_dot4_i32_i8); prefill: Q4_K on grids of up "
+                        "to 128 tiles of 128x128 (attn_q, attn_output, ffn_down) on the int8 matrix cores, exact integer sub-block dots "
+                        "(2e-6 of the oracle); larger Q4_K grids and Q6_K on f16 MFMA with scaled operands f16(d*sc*q) x f16(d8*code) "
+                        "(<= 1e-3 relative, measured ~3e-4; exact integer codes with LFAMD_FLAG_PRECISE)",
             "model": a.model, "prefill_tokens": a.prefill, "decode_tokens": a.decode,
             "parallelism": "single GPU" if world == 1 else f"tp{world} (all-reduce on attn_output/ffn_down: {comm.describe() if comm is not None else 'torch.distributed ' + os.environ.get('LFAMD_DIST_BACKEND', 'nccl')})",
             "hip_graph": use_graph, "weight_bytes_per_gpu": runner.weight_bytes(),

@@ -109,6 +109,14 @@ int lfamd_pack_weights(int type, long rows, long cols, const void *d_raw, size_t
  * smallest super-blocks (they contribute < 1e-7 of the result). */
 int lfamd_scaled_gemm_ok(int type, long rows, long cols, const void *d_packed, void *stream);
 
+/* Which arithmetic a lfamd_mul_mat call with these arguments runs: 1 = exact integer block dot products with f32 scales (the
+ * reference's CPU arithmetic, iqk_mul_mat.inc:601-643; within 2e-6 of it: only the order of the f32 sums differs) — every call
+ * of up to 32 columns, LFAMD_FLAG_PRECISE, and since round 4 the Q4_K batches that run on the int8 matrix cores
+ * (llamafile_amd/csrc/gemm_i8.hip: grids of at most 128 tiles of 128 x 128 that still fill half the chip — attn_q, attn_output,
+ * ffn_down of an 8B model at 512 tokens); 0 = scaled operands on the f16 matrix cores (one f16 rounding per operand, <= 1e-3,
+ * measured ~3e-4; Q6_K's exact body also rounds sc * (q - 32) above 2048).  No device call is made. */
+int lfamd_mul_mat_is_exact(int Atype, long m, long k, long n, unsigned flags);
+
 /* ---- activations --------------------------------------------------------------------------
  * f32 rows -> the reference's activation block format (vec_dot_type: Q8_0, Q8_1 or Q8_K in
  * llamafile's field order).  Same rounding as the scalar reference quantisers. */
@@ -209,24 +217,6 @@ int lfamd_gemm_strided_batched_f16(long m, long n, long k, float alpha, const vo
 int lfamd_gemm_batched_f16(long m, long n, long k, float alpha, const void *const *d_Aarray, long lda, const void *const *d_Barray,
                            long ldb, float beta, void *const *d_Carray, int Ctype, long ldc, int batch, void *stream);
 
-/* ---- the decode feed-forward block as ONE launch -------------------------------------------
- * d_out[m_out] = W_down x quantize_q8_K( silu(W_gate x q(x)) * (W_up x q(x)) )  (+ d_residual), one activation row x[k] (f32).
- * Replaces five graph nodes of a llama feed-forward at batch 1 — GGML_OP_MUL_MAT (ffn_gate), GGML_OP_MUL_MAT (ffn_up),
- * GGML_OP_SILU * GGML_OP_MUL, the activation quantiser, GGML_OP_MUL_MAT (ffn_down) [+ GGML_OP_ADD]; reference kernels
- * mul_mat_vec_q + quantize_q8_1 (ggml-cuda.cu.patch:14428-14575, 15259-15293), silu_f32 (:16172-16179) — with the arithmetic
- * of the separate calls (lfamd_mul_mat_multi, lfamd_swiglu_quantize, lfamd_mul_mat): exact integer block dots, f32 silu,
- * quantize_row_q8_K bit for bit.  One persistent launch with a grid-wide barrier between the two mat-mul phases; ffn_down's
- * weights are already streaming into registers while the barrier completes (llamafile_amd/csrc/ffn_block.hip).
- * Covers Q4_K gate / up with k <= 4096 and Q4_K / Q6_K down with n_ff <= 15360 (LFAMD_ERR_UNSUPPORTED otherwise: use the
- * separate calls).  Launches on ONE device must not overlap each other (one barrier state per device); the barrier is
- * bounded by wall time (LFAMD_FFN_TIMEOUT_S, default 2 s): lfamd_ffn_block_check() != 0 reports a launch whose grid was not
- * co-resident (results void).  Packed weights as from lfamd_pack_weights; workspace = lfamd_ffn_block_workspace(n_ff) bytes. */
-size_t lfamd_ffn_block_workspace(long n_ff);
-int lfamd_ffn_block(int type_gate_up, const void *d_Wgate_packed, const void *d_Wup_packed, long n_ff, long k, int type_down,
-                    const void *d_Wdown_packed, long m_out, const float *d_x, const float *d_residual, float *d_out,
-                    void *d_workspace, size_t workspace_bytes, void *stream);
-int lfamd_ffn_block_check(void);
-
 /* ---- collectives (tensor parallel, one process per GPU) ---------------------------------------
  * The exchange step of the sharded path: attn_output / ffn_down are split by input columns and
  * the f32 partial sums of the residual stream are all-reduced; output.weight is split by vocabulary rows and the logits
@@ -272,16 +262,7 @@ int lfamd_comm_allreduce_add_f32(lfamd_comm *comm, const float *d_partial, const
                                  void *stream);
 int lfamd_comm_allreduce_sum_f32(lfamd_comm *comm, float *d_inout, long count, void *stream);
 int lfamd_comm_allgather(lfamd_comm *comm, const void *d_send, void *d_recv, size_t bytes_per_rank, void *stream);
-/* The decode step of a column-sharded matrix (attn_output / ffn_down) with its exchange in ONE launch:
- *   d_out = (d_residual ? d_residual : 0) + sum over ranks of (A_rank . b_rank);   d_partial: m floats of scratch
- * b = one activation row (Btype f32, or the vec-dot type of Atype).  Fused — the product's last work-group to finish runs
- * the one-shot exchange — when the one-shot path is attached, m * 4 fits its slot, m % 4 == 0 and Atype is Q4_K / Q5_K /
- * Q6_K; otherwise lfamd_mul_mat + lfamd_comm_allreduce_add_f32.  Bit-identical either way (and on every rank);
- * LFAMD_NO_FUSED_EXCHANGE=1 forces the two launches.  Replaces the peer copies + main-GPU add of
- * ggml-cuda.cu.patch:18077-18121.  hipGraph-capturable like the calls above. */
-int lfamd_mul_mat_allreduce(lfamd_comm *comm, int Atype, const void *d_A_packed, long m, long k, int Btype, const void *d_B,
-                            size_t b_row_bytes, const float *d_residual, float *d_partial, float *d_out, void *d_workspace,
-                            size_t workspace_bytes, unsigned flags, void *stream);
+
 int lfamd_comm_check(lfamd_comm *comm);
 int lfamd_comm_clear_error(lfamd_comm *comm);
 

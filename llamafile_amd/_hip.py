@@ -45,6 +45,7 @@ _SIGS = {
     "lfamd_packed_size": (_sz, [_i, _l, _l]),
     "lfamd_pack_weights": (_i, [_i, _l, _l, _vp, _sz, _vp, _vp]),
     "lfamd_scaled_gemm_ok": (_i, [_i, _l, _l, _vp, _vp]),
+    "lfamd_mul_mat_is_exact": (_i, [_i, _l, _l, _l, _u]),
     "lfamd_quantize_rows": (_i, [_i, _vp, _l, _l, _sz, _vp, _sz, _vp]),
     "lfamd_mul_mat_workspace": (_sz, [_i, _l, _l, _l]),
     "lfamd_mul_mat": (_i, [_i, _vp, _l, _l, _i, _vp, _sz, _l, _vp, _l, _vp, _sz, _u, _vp]),
@@ -59,9 +60,6 @@ _SIGS = {
     "lfamd_gemm_strided_batched_f16": (_i, [_l, _l, _l, C.c_float, _vp, _l, C.c_longlong, _vp, _l, C.c_longlong, C.c_float, _vp, _i, _l,
                                             C.c_longlong, _i, _vp]),
     "lfamd_gemm_batched_f16": (_i, [_l, _l, _l, C.c_float, _vp, _l, _vp, _l, C.c_float, _vp, _i, _l, _i, _vp]),
-    "lfamd_ffn_block_workspace": (_sz, [_l]),
-    "lfamd_ffn_block": (_i, [_i, _vp, _vp, _l, _l, _i, _vp, _l, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "lfamd_ffn_block_check": (_i, []),
     "lfamd_comm_unique_id": (_i, [_vp]),
     "lfamd_comm_init": (_i, [C.POINTER(_vp), _i, _i, _vp]),
     "lfamd_comm_destroy": (_i, [_vp]),
@@ -75,7 +73,6 @@ _SIGS = {
     "lfamd_comm_allreduce_sum_f32": (_i, [_vp, _vp, _l, _vp]),
     "lfamd_comm_allgather": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "lfamd_comm_check": (_i, [_vp]),
-    "lfamd_mul_mat_allreduce": (_i, [_vp, _i, _vp, _l, _l, _i, _vp, _sz, _vp, _vp, _vp, _vp, _sz, _u, _vp]),
     "lfamd_comm_clear_error": (_i, [_vp]),
     "lfamd_time_mul_mat": (_i, [_i, _vp, _l, _l, _i, _vp, _sz, _l, _vp, _l, _vp, _sz, _u, _vp, _i, _i,
                                 C.POINTER(C.c_float)]),

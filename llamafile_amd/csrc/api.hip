@@ -453,6 +453,21 @@ static bool gemv_quantise_separately(int Atype, long m) {
     return false; // persistent GEMV work-groups stage the activations once each: fused is always cheaper
 }
 
+int lfamd_mul_mat_is_exact(int Atype, long m, long k, long n, unsigned flags) {
+    if (!type_known(Atype) || m <= 0 || k <= 0 || n <= 0)
+        return 0;
+    const bool kq = Atype == LFAMD_TYPE_Q4_K || Atype == LFAMD_TYPE_Q5_K || Atype == LFAMD_TYPE_Q6_K;
+    if (n <= 8 || !kq)
+        return Atype != LFAMD_TYPE_Q8_0 || n <= 8 || !lfamd_blaslt_ok() || (flags & (LFAMD_FLAG_PRECISE | LFAMD_FLAG_Q80_EXACT)) ? 1 : 0;
+    if (use_gemm_sb(Atype, n, flags, k, m))
+        return 1;
+    if (Atype == LFAMD_TYPE_Q6_K)
+        return 0; // (both batch bodies round sc * (q - 32) above 2048)
+    if (flags & (LFAMD_FLAG_PRECISE | LFAMD_FLAG_GEMM_NARROW | LFAMD_FLAG_GEMM_PLAIN))
+        return 1;
+    return use_gemm_i8(Atype, n, flags, k, (m + 127) / 128) ? 1 : (lfamd_gemm_wide_scaled_ok(Atype, 0) ? 0 : 1);
+}
+
 static size_t mul_mat_workspace_base(int Atype, long m, long k, long n) {
     if (use_gemv(Atype, n, 0, k) && gemv_quantise_separately(Atype, m))
         return align_up((size_t)n * lfamd_row_size(lfamd_vec_dot_type(Atype), k), 256);

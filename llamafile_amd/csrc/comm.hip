@@ -25,14 +25,6 @@
 
 extern "C" void lfamd_set_error(const char *msg);
 hipError_t lfamd_launch_add_f32(float *y, const float *r, long n, hipStream_t s);
-extern "C" hipError_t lfamd_launch_gemv_fx(int Atype, const void *A, long m, long k, int Btype, const void *B, size_t b_row_bytes,
-                                           float *partial, const void *fx_args, hipStream_t s);
-struct gemv_fx { // (gemv_impl.h)
-    oneshot_args a;
-    const float *residual;
-    float *out;
-};
-
 namespace {
 
 // ---- the few RCCL entry points, by name (rccl.h's types restated as opaque handles; 128-byte unique id)
@@ -444,50 +436,6 @@ int lfamd_comm_allgather(lfamd_comm *c, const void *d_send, void *d_recv, size_t
     }
     int rc = R.AllGather(d_send, d_recv, bytes_per_rank, NCCL_INT8, c->nccl, (hipStream_t)stream);
     return rc ? nccl_fail(rc, "ncclAllGather") : LFAMD_OK;
-}
-
-// One activation row against this rank's column shard of a matrix AND the all-reduce of the f32 partials, residual added:
-//   d_out = (d_residual ? d_residual : 0) + sum over ranks of (A_rank . b_rank)
-// One launch when the one-shot exchange is attached, the message fits its slot and the type has the fused kernel (Q4_K, Q5_K,
-// Q6_K: the decode GEMV whose last work-group runs the exchange); otherwise lfamd_mul_mat followed by
-// lfamd_comm_allreduce_add_f32 — the same bits either way.  d_partial (m floats) is scratch for the two-launch form.
-int lfamd_mul_mat_allreduce(lfamd_comm *c, int Atype, const void *d_A_packed, long m, long k, int Btype, const void *d_B,
-                            size_t b_row_bytes, const float *d_residual, float *d_partial, float *d_out, void *d_ws, size_t ws_bytes,
-                            unsigned flags, void *stream) {
-    if (!c || !d_partial || !d_out || m <= 0) {
-        lfamd_set_error("lfamd_mul_mat_allreduce: bad arguments");
-        return LFAMD_ERR_INVALID;
-    }
-    static const bool no_fuse = getenv("LFAMD_NO_FUSED_EXCHANGE") && atoi(getenv("LFAMD_NO_FUSED_EXCHANGE"));
-    const bool aligned = (m & 3) == 0 && ((((uintptr_t)d_partial) | ((uintptr_t)d_out) | ((uintptr_t)d_residual)) & 15) == 0;
-    if (!no_fuse && c->local && aligned && (size_t)m * 4 <= c->slot_bytes) {
-        comm_device on(c);
-        gemv_fx fx;
-        for (int r = 0; r < ONESHOT_MAX_WORLD; r++)
-            fx.a.peer[r] = c->peer[r < c->world ? r : 0];
-        fx.a.rank = c->rank, fx.a.world = c->world;
-        fx.a.slot_bytes = c->slot_bytes;
-        fx.a.count = m;
-        fx.a.timeout_ticks = c->timeout_ticks;
-        fx.a.state = c->d_state;
-        fx.residual = d_residual, fx.out = d_out;
-        hipError_t e = lfamd_launch_gemv_fx(Atype, d_A_packed, m, k, Btype, d_B, b_row_bytes, d_partial, &fx, (hipStream_t)stream);
-        if (e == hipSuccess)
-            return LFAMD_OK;
-        (void)hipGetLastError();
-        if (e != hipErrorNotSupported) {
-            lfamd_set_error(hipGetErrorString(e));
-            return LFAMD_ERR_HIP;
-        }
-    }
-    int rc;
-    {
-        comm_device on(c);
-        rc = lfamd_mul_mat(Atype, d_A_packed, m, k, Btype, d_B, b_row_bytes, 1, d_partial, m, d_ws, ws_bytes, flags, stream);
-    }
-    if (rc != LFAMD_OK)
-        return rc;
-    return lfamd_comm_allreduce_add_f32(c, d_partial, d_residual, d_out, m, stream);
 }
 
 // One process, several devices (one host thread, hipSetDevice per shard — ncclCommInitAll's shape): comms[i] is rank i of

@@ -14,9 +14,6 @@ hipError_t lfamd_gemv_go_q51(GEMV_GO_ARGS);
 hipError_t lfamd_gemv_ids_go_q4k(int, const gemv_mats &, int, long, const void *, size_t, hipStream_t);
 hipError_t lfamd_gemv_ids_go_q5k(int, const gemv_mats &, int, long, const void *, size_t, hipStream_t);
 hipError_t lfamd_gemv_ids_go_q6k(int, const gemv_mats &, int, long, const void *, size_t, hipStream_t);
-hipError_t lfamd_gemv_fx_go_q4k(int, const gemv_mats &, int, long, const void *, size_t, const gemv_fx &, hipStream_t);
-hipError_t lfamd_gemv_fx_go_q5k(int, const gemv_mats &, int, long, const void *, size_t, const gemv_fx &, hipStream_t);
-hipError_t lfamd_gemv_fx_go_q6k(int, const gemv_mats &, int, long, const void *, size_t, const gemv_fx &, hipStream_t);
 hipError_t lfamd_gemv_ids_pair_go_q4k(int, const gemv_mats &, const gemv_mats &, int, long, const void *, const void *, size_t, hipStream_t);
 hipError_t lfamd_gemv_ids_pair_go_q5k(int, const gemv_mats &, const gemv_mats &, int, long, const void *, const void *, size_t, hipStream_t);
 hipError_t lfamd_gemv_ids_pair_go_q6k(int, const gemv_mats &, const gemv_mats &, int, long, const void *, const void *, size_t, hipStream_t);
@@ -224,29 +221,6 @@ extern "C" hipError_t lfamd_launch_gemv_ids_pair(int Atype, const void *W, long 
     if (Atype == LFAMD_TYPE_Q5_K)
         return lfamd_gemv_ids_pair_go_q5k(f, ma, mb, n_ht, k, Ba, Bb, b_row_bytes, s);
     return lfamd_gemv_ids_pair_go_q6k(f, ma, mb, n_ht, k, Ba, Bb, b_row_bytes, s);
-}
-
-// one activation row against one column-sharded matrix, the all-reduce of the partial (+ residual) in the same launch
-// (gemv_impl.h: gemv_kq_fx_kernel).  hipErrorNotSupported: the caller runs the product and the exchange as two launches.
-extern "C" hipError_t lfamd_launch_gemv_fx(int Atype, const void *A, long m, long k, int Btype, const void *B, size_t b_row_bytes,
-                                           float *partial, const void *fx_args, hipStream_t s) {
-    if ((Atype != LFAMD_TYPE_Q4_K && Atype != LFAMD_TYPE_Q5_K && Atype != LFAMD_TYPE_Q6_K) || m <= 0 || k % 256 ||
-        (Btype != LFAMD_TYPE_F32 && Btype != LFAMD_TYPE_Q8_K) || (size_t)(k / 256) * XBLK > 150 * 1024)
-        return hipErrorNotSupported;
-    gemv_mats mats;
-    const int n_ht = (int)(((m + 31) / 32) * 2);
-    mats.count = 1, mats.ids = nullptr, mats.expert_bytes = 0, mats.experts = 0;
-    for (int i = 0; i < GEMV_MAX_MATS; i++) {
-        mats.A[i] = (const uint8_t *)A, mats.C[i] = partial, mats.m[i] = i == 0 ? m : 0, mats.ldc[i] = i == 0 ? m : 0;
-        mats.ht_end[i] = n_ht, mats.id_idx[i] = 0;
-    }
-    const gemv_fx &fx = *(const gemv_fx *)fx_args;
-    const int f = Btype == LFAMD_TYPE_F32 ? 1 : 0;
-    if (Atype == LFAMD_TYPE_Q4_K)
-        return lfamd_gemv_fx_go_q4k(f, mats, n_ht, k, B, b_row_bytes, fx, s);
-    if (Atype == LFAMD_TYPE_Q5_K)
-        return lfamd_gemv_fx_go_q5k(f, mats, n_ht, k, B, b_row_bytes, fx, s);
-    return lfamd_gemv_fx_go_q6k(f, mats, n_ht, k, B, b_row_bytes, fx, s);
 }
 
 extern "C" hipError_t lfamd_launch_gemv(int Atype, const void *A, long m, long k, int Btype, const void *B,

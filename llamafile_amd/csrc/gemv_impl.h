@@ -21,7 +21,6 @@
 // chunk is always in flight while the current one is consumed.
 #pragma once
 #include "lfamd_device.h"
-#include "oneshot_impl.h"
 #include <stdlib.h>
 
 // LDS image of one Q8_K activation block for the K-quant GEMVs.  A lane = (gsel, h) reads its 64 code
@@ -1159,10 +1158,10 @@ __device__ static inline float kq_sum_rows(float v) {
     return p + q;
 }
 
-template <typename TR, int BT, int NW, int GEMV_CH, bool IDS, bool EARLY = false, bool FX = false, bool PAIR = false>
+template <typename TR, int BT, int NW, int GEMV_CH, bool IDS, bool EARLY = false, bool PAIR = false>
 __device__ __forceinline__ void gemv_kq_body1(const gemv_mats &mats, int nb, const uint8_t *__restrict__ B,
                                               size_t b_row_bytes, long col0, int n_ht, const int bid, int gdim,
-                                              uint8_t *lds, const uint8_t *A0_pre, int cnt_pre, float *fx_row = nullptr) {
+                                              uint8_t *lds, const uint8_t *A0_pre, int cnt_pre) {
     asm volatile("" : "+s"(nb), "+s"(B), "+s"(b_row_bytes), "+s"(col0), "+s"(n_ht), "+s"(gdim)); // (one s_load round)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1212,7 +1211,7 @@ __device__ __forceinline__ void gemv_kq_body1(const gemv_mats &mats, int nb, con
     // out BEFORE the argument table's scalar loads have returned (~0.4 us earlier); both branches issue the same loads
     typename TR::chunk bufA, bufB;
     typename TR::chunk bufA2, bufB2; // (PAIR: the second half-tile of the item; dead otherwise)
-    static_assert(!(PAIR && (EARLY || IDS || FX)), "the paired item is a variant of the plain launch");
+    static_assert(!(PAIR && (EARLY || IDS)), "the paired item is a variant of the plain launch");
     constexpr bool early = EARLY && !IDS; // (a kernel variant, not a run-time branch: hipcc merges its wait counts at a join)
     (void)cnt_pre;
     if constexpr (early) {
@@ -1292,10 +1291,7 @@ __device__ __forceinline__ void gemv_kq_body1(const gemv_mats &mats, int nb, con
                     const int ex = mats.ids[p.idx];                                                                    \
                     ok = ex >= 0 && ex < mats.experts;                                                                 \
                 }                                                                                                      \
-                if constexpr (FX) { /* system-scope store: the work-group that runs the exchange reads it past its caches */ \
-                    if (row < p.m && ok) /* (one matrix, one column: straight into this rank's exchange slot) */       \
-                        st_sys4(fx_row + row, __builtin_bit_cast(uint32_t, t));                                        \
-                } else if (row < p.m && ok)                                                                            \
+                if (row < p.m && ok)                                                                                   \
                     ((__attribute__((address_space(1))) float *)p.C)[col0 * p.ldc + row] = t; /* (not FLAT) */                                                                     \
             }                                                                                                          \
         }                                                                                                              \
@@ -1420,45 +1416,9 @@ __global__ __launch_bounds__(NW * 64) void gemv_kq_kernel(const uint8_t *__restr
     // first weight loads without waiting for the argument table)
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     if constexpr (NC == 1)
-        gemv_kq_body1<TR, BT, NW, GEMV_CH, IDS, EARLY, false, PAIR>(mats, nb, B, b_row_bytes, col0, n_ht, (int)blockIdx.x, gdim, lds, A0, cnt);
+        gemv_kq_body1<TR, BT, NW, GEMV_CH, IDS, EARLY, PAIR>(mats, nb, B, b_row_bytes, col0, n_ht, (int)blockIdx.x, gdim, lds, A0, cnt);
     else
         gemv_kq_body<TR, NC, BT, NW, GEMV_CH, IDS>(mats, nb, B, b_row_bytes, col0, n_ht, (int)blockIdx.x, gdim, lds);
-}
-
-// The decode product of a column-sharded matrix (attn_output / ffn_down under tensor parallelism) and the all-reduce of its
-// f32 partial in ONE launch: the rows are stored with system-scope stores straight into this rank's exchange slot, every work-group counts itself in when its stores
-// have retired, and the last one to arrive runs the rest of the one-shot exchange (oneshot_impl.h) — flag the peers, wait
-// for theirs, sum in rank order, add the residual.  Same arithmetic, same order as the two launches
-// (tests/test_gpu_tp_rehearsal.py asserts bit-identity).  Replaces the main-GPU gather of ggml-cuda.cu.patch:18077-18121.
-struct gemv_fx {
-    oneshot_args a;
-    const float *residual;
-    float *out;
-};
-template <typename TR, int BT, int NW, int GEMV_CH>
-__global__ __launch_bounds__(NW * 64) void gemv_kq_fx_kernel(const uint8_t *__restrict__ B, size_t b_row_bytes, long col0, int nb,
-                                                             int n_ht, int gdim, const uint8_t *__restrict__ A0, int cnt,
-                                                             const gemv_mats mats, const gemv_fx fx) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    // the slot this call publishes in: the parity of the sequence number the exchange is about to take (it is advanced by
-    // the LAST work-group of this launch, after every work-group has read it here)
-    const int seq_next = fx.a.state[1] + 1;
-    float *slot = (float *)(fx.a.peer[fx.a.rank] + ONESHOT_FLAGS_BYTES + (size_t)(seq_next & 1) * fx.a.slot_bytes);
-    gemv_kq_body1<TR, BT, NW, GEMV_CH, false, true, true>(mats, nb, B, b_row_bytes, col0, n_ht, (int)blockIdx.x, gdim, lds, A0, cnt, slot);
-    __shared__ int s_fx[3];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's result stores have reached memory
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned *arrive = (unsigned *)(fx.a.state + 1 + ONESHOT_WGS);
-        const unsigned old = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_fx[2] = old == gridDim.x - 1;
-        if (s_fx[2])
-            __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (the next launch counts from zero)
-    }
-    __syncthreads();
-    if (!s_fx[2])
-        return;
-    oneshot_whole<NW * 64>(fx.a, nullptr, fx.residual, fx.out, s_fx); // (already published: the rows were stored into the slot)
 }
 
 // Two expert GEMVs on DIFFERENT activation rows in ONE decode launch (GGML_OP_MUL_MAT_ID ffn_down_exps: every chosen expert
@@ -1851,32 +1811,6 @@ static hipError_t launch_kq(const gemv_mats &mats, int n_ht, long k, const void 
     return go(gemv_kq_kernel<TR, NC, BT, NW, CH>);
 }
 
-template <typename TR, int BT, int NW, int CH>
-static hipError_t launch_kq_fx(const gemv_mats &mats, int n_ht, long k, const void *B, size_t brb, const gemv_fx &fx, hipStream_t s) {
-    int nb = (int)(k / 256);
-    size_t smem = (size_t)nb * XBLK + 2 * NW * 16 * sizeof(float) + (size_t)NW * XBLK;
-    const int max_wg = (16 / NW) * num_cus(); // (the grid launch_kq gives the same product)
-    const int per_wg = (n_ht + max_wg - 1) / max_wg;
-    const int grid = (n_ht + per_wg - 1) / per_wg;
-    auto kernel = gemv_kq_fx_kernel<TR, BT, NW, CH>;
-    if (smem > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess)
-            return e;
-    }
-    kernel<<<grid, NW * 64, smem, s>>>((const uint8_t *)B, brb, 0, nb, n_ht, grid, mats.A[0], mats.count, mats, fx);
-    return hipGetLastError();
-}
-template <typename TR, int BT>
-static hipError_t launch_kq_fx_pick(const gemv_mats &mats, int n_ht, long k, const void *B, size_t brb, const gemv_fx &fx, hipStream_t s) {
-    const long nb = k / 256; // (launch_kq_pick's choice for one column)
-    if (n_ht <= num_cus() && nb <= 32)
-        return launch_kq_fx<TR, BT, 8, 2>(mats, n_ht, k, B, brb, fx, s);
-    if (nb <= 16)
-        return launch_kq_fx<TR, BT, 16, 1>(mats, n_ht, k, B, brb, fx, s);
-    return launch_kq_fx<TR, BT, 16, 2>(mats, n_ht, k, B, brb, fx, s);
-}
-
 template <typename TRA, typename TRB, int BT, int NW, int CH>
 static hipError_t launch_kq_dual_nw(const gemv_mats &ma, int n_ht_a, const gemv_mats &mb, int n_ht_b, int nb, const void *B,
                                     size_t brb, hipStream_t s) {
@@ -2143,12 +2077,6 @@ static hipError_t launch_q80(const q80_mats &mats, long n_total, long k, const v
                                              const void *Bb, size_t brb, hipStream_t s) {                                \
         return f32in ? launch_kq_ids_pair<TRAITS, LFAMD_TYPE_F32>(ma, mb, n_ht, k, Ba, Bb, brb, s)                       \
                      : launch_kq_ids_pair<TRAITS, LFAMD_TYPE_Q8_K>(ma, mb, n_ht, k, Ba, Bb, brb, s);                     \
-    }
-#define GEMV_INSTANTIATE_FX(NAME, TRAITS)                                                                              \
-    hipError_t lfamd_gemv_fx_go_##NAME(int f32in, const gemv_mats &mats, int n_ht, long k, const void *B, size_t brb,   \
-                                       const gemv_fx &fx, hipStream_t s) {                                             \
-        return f32in ? launch_kq_fx_pick<TRAITS, LFAMD_TYPE_F32>(mats, n_ht, k, B, brb, fx, s)                         \
-                     : launch_kq_fx_pick<TRAITS, LFAMD_TYPE_Q8_K>(mats, n_ht, k, B, brb, fx, s);                       \
     }
 #define GEMV_INSTANTIATE_IDS(NAME, TRAITS)                                                                             \
     hipError_t lfamd_gemv_ids_go_##NAME(int f32in, const gemv_mats &mats, int n_ht, long k, const void *B, size_t brb,  \

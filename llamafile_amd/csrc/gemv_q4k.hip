@@ -4,4 +4,3 @@
 GEMV_INSTANTIATE(q4k, q4k_traits, LFAMD_TYPE_Q8_K)
 GEMV_INSTANTIATE_IDS(q4k, q4k_traits)
 GEMV_INSTANTIATE_IDS_PAIR(q4k, q4k_traits)
-GEMV_INSTANTIATE_FX(q4k, q4k_traits)

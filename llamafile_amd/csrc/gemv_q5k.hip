@@ -4,4 +4,3 @@
 GEMV_INSTANTIATE(q5k, q5k_traits, LFAMD_TYPE_Q8_K)
 GEMV_INSTANTIATE_IDS(q5k, q5k_traits)
 GEMV_INSTANTIATE_IDS_PAIR(q5k, q5k_traits)
-GEMV_INSTANTIATE_FX(q5k, q5k_traits)

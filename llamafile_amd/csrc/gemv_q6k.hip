@@ -4,4 +4,3 @@
 GEMV_INSTANTIATE(q6k, q6k_traits, LFAMD_TYPE_Q8_K)
 GEMV_INSTANTIATE_IDS(q6k, q6k_traits)
 GEMV_INSTANTIATE_IDS_PAIR(q6k, q6k_traits)
-GEMV_INSTANTIATE_FX(q6k, q6k_traits)

@@ -228,24 +228,6 @@ def mul_mat_id(Ws: torch.Tensor, wtype: int, rows: int, cols: int, experts: int,
     return res
 
 
-def ffn_block(Wg: PackedWeights, Wu: PackedWeights, Wd: PackedWeights, x: torch.Tensor, residual: torch.Tensor | None = None,
-              out: torch.Tensor | None = None, ws: torch.Tensor | None = None) -> torch.Tensor:
-    """out[m] = Wd x q8k(silu(Wg x) * (Wu x)) (+ residual) for ONE f32 activation row x[k], one launch (lfamd_ffn_block).
-    Raises _hip.LfamdError(LFAMD_ERR_UNSUPPORTED) for shapes / types the fused launch does not cover."""
-    L = _hip.lib()
-    assert Wg.type == Wu.type and Wg.rows == Wu.rows and Wg.cols == Wu.cols and Wd.cols == Wg.rows
-    n_ff, k, m = Wg.rows, Wg.cols, Wd.rows
-    if out is None:
-        out = torch.empty((1, m), dtype=torch.float32, device=x.device)
-    need = int(L.lfamd_ffn_block_workspace(n_ff))
-    if ws is None:
-        ws = torch.empty(need, dtype=torch.uint8, device=x.device)
-    rc = L.lfamd_ffn_block(Wg.type, _ptr(Wg.data), _ptr(Wu.data), n_ff, k, Wd.type, _ptr(Wd.data), m, _ptr(x),
-                           _ptr(residual) if residual is not None else None, _ptr(out), _ptr(ws), ws.numel(), _stream())
-    _hip.check(rc, "lfamd_ffn_block")
-    return out
-
-
 def time_mul_mat(W: PackedWeights, B: torch.Tensor, Btype: int, n: int, warmup: int = 5, iters: int = 50,
                  flags: int | None = None) -> float:
     """Average device microseconds per lfamd_mul_mat launch (HIP events on the current stream)."""

@@ -111,30 +111,6 @@ class Comm:
         _hip.check(rc, "lfamd_comm_allreduce_add_f32")
         return out
 
-    def mul_mat_allreduce(self, W, B, Btype, residual=None, out=None, partial=None, workspace=None):
-        """out = residual + sum over ranks of (W_rank . b_rank) for ONE activation row: the decode step of a column-sharded
-        matrix and its exchange in one launch where the module can (lfamd_mul_mat_allreduce), else two."""
-        import ctypes as C
-
-        import torch
-
-        from . import _hip, sgemm
-        m = W.rows
-        partial = torch.empty((1, m), dtype=torch.float32, device=B.device) if partial is None else partial
-        out = torch.empty((1, m), dtype=torch.float32, device=B.device) if out is None else out
-        need = self.L.lfamd_mul_mat_workspace(W.type, W.rows, W.cols, 1)
-        if need and (workspace is None or workspace.numel() < need):
-            workspace = torch.empty(need, dtype=torch.uint8, device=B.device)
-        flags = sgemm.host_variant_flags() | (_hip.FLAG_PRECISE if getattr(W, "exact_only", False) else 0)
-        rc = self.L.lfamd_mul_mat_allreduce(self.h, W.type, C.c_void_p(W.data.data_ptr()), W.rows, W.cols, Btype, C.c_void_p(B.data_ptr()),
-                                            B.stride(0) * B.element_size(), C.c_void_p(residual.data_ptr()) if residual is not None else None,
-                                            C.c_void_p(partial.data_ptr()), C.c_void_p(out.data_ptr()),
-                                            C.c_void_p(workspace.data_ptr()) if workspace is not None else None,
-                                            workspace.numel() if workspace is not None else 0, flags,
-                                            C.c_void_p(torch.cuda.current_stream().cuda_stream))
-        _hip.check(rc, "lfamd_mul_mat_allreduce")
-        return out
-
     def allgather(self, send, recv):
         import ctypes as C
 

@@ -173,11 +173,8 @@ def test_qkv_two_types_one_gemm_launch(gpu, ta):
         if W.type == T.Q4_K:
             # (a separate 4096 x 4096 call takes the int8 body since round 4 — exact integer dots — while the fused launch runs the
             # scaled-operand f16 body: one f16 rounding per operand apart)
-            import ctypes as C
             from llamafile_amd import _hip
-            ok_fn = _hip.lib().lfamd_gemm_i8_ok
-            ok_fn.argtypes, ok_fn.restype = (C.c_int, C.c_long, C.c_long), C.c_int
-            tol = 1e-3 if ok_fn(W.type, (W.rows + 127) // 128, PREFILL) else 4e-6
+            tol = 1e-3 if _hip.lib().lfamd_mul_mat_is_exact(W.type, W.rows, k, PREFILL, gpu.host_variant_flags()) else 4e-6
             assert float((f - sep).abs().max()) / float(sep.abs().max()) <= tol, (T.NAMES[W.type], W.rows)
         else:
             assert torch.equal(_bits(f), _bits(sep)), (T.NAMES[W.type], W.rows)

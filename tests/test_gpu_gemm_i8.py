@@ -33,9 +33,7 @@ def test_int8_body_vs_oracle(gpu, oracle, shape, f32in):
     A = synth.random_weights(T.Q4_K, m, k, 41)
     x = synth.random_activations(n, k, 42)
     B = synth.quantize_activations(T.Q8_K, x)
-    ok_fn = _hip.lib().lfamd_gemm_i8_ok
-    ok_fn.argtypes, ok_fn.restype = (C.c_int, C.c_long, C.c_long), C.c_int
-    assert ok_fn(T.Q4_K, (m + 127) // 128, n) == 1
+    assert _hip.lib().lfamd_mul_mat_is_exact(T.Q4_K, m, k, n, gpu.host_variant_flags()) == 1  # (the default route: the int8 body)
     W = gpu.upload_weights(T.Q4_K, A, m, k)
     Bd = torch.from_numpy(x).cuda().view(torch.uint8).view(n, k * 4) if f32in else torch.from_numpy(B).cuda()
     Cd = gpu.mul_mat(W, Bd, T.F32 if f32in else T.Q8_K, n=n)

@@ -50,15 +50,6 @@ def _worker(rank, world, port, q):
                 out = torch.empty_like(part)
                 comm.allreduce_add(part, rd, out)
                 outs.append(out)
-            # the same step as ONE launch (the product's last work-group runs the exchange), alternating with the two-launch
-            # form: same protocol state, same bits
-            xb = torch.from_numpy(xl).cuda().view(torch.uint8).view(1, kl * 4)
-            part2 = torch.zeros_like(part)
-            for rep in range(3):
-                outs.append(comm.mul_mat_allreduce(W, xb, T.F32, residual=rd, partial=part2))
-                out = torch.empty_like(part)
-                comm.allreduce_add(part, rd, out)
-                outs.append(out)
             torch.cuda.synchronize()
             assert comm.check() == 0
             assert all(torch.equal(outs[0], o) for o in outs[1:])
@@ -155,47 +146,3 @@ def test_single_process_communicators_over_one_device(gpu):
     finally:
         for r in range(world):
             lib.lfamd_comm_destroy(comms[r])
-
-
-@pytest.mark.parametrize("attached", [False, True])
-def test_mul_mat_allreduce_with_one_rank(gpu, oracle, attached):
-    """lfamd_mul_mat_allreduce at world 1: without an exchange block it is lfamd_mul_mat + the residual add (two launches);
-    with one (lfamd_comm_init_all over a single device) the fused kernel runs and its last work-group sums a world of one.
-    Same bits, and the oracle's product."""
-    import ctypes as C
-    import torch
-    from llamafile_amd import _hip, ggml_types as T, sgemm, synth
-    lib = _hip.lib()
-    sgemm.init(0)
-    t, m, k = T.Q4_K, 4096, 2048
-    A = synth.random_weights(t, m, k, 11)
-    x = synth.random_activations(1, k, 12)
-    W = sgemm.upload_weights(t, A, m, k)
-    xb = torch.from_numpy(x).cuda()
-    resid = torch.from_numpy(synth.random_activations(1, m, 13)).cuda()
-    comm = C.c_void_p()
-    if attached:
-        comms = (C.c_void_p * 1)()
-        assert lib.lfamd_comm_init_all(comms, 1, (C.c_int * 1)(0), 64 * 1024) == 0, lib.lfamd_last_error()
-        comm = C.c_void_p(comms[0])
-    else:
-        assert lib.lfamd_comm_init(C.byref(comm), 0, 1, None) == 0
-    try:
-        part = torch.zeros((1, m), device="cuda")
-        out = torch.zeros((1, m), device="cuda")
-        ws = torch.empty(max(16, lib.lfamd_mul_mat_workspace(t, m, k, 1)), dtype=torch.uint8, device="cuda")
-        for rep in range(3):
-            rc = lib.lfamd_mul_mat_allreduce(comm, t, C.c_void_p(W.data.data_ptr()), m, k, T.F32, C.c_void_p(xb.data_ptr()), k * 4,
-                                             C.c_void_p(resid.data_ptr()), C.c_void_p(part.data_ptr()), C.c_void_p(out.data_ptr()),
-                                             C.c_void_p(ws.data_ptr()), ws.numel(), sgemm.host_variant_flags(), None)
-            assert rc == 0, lib.lfamd_last_error()
-            torch.cuda.synchronize()
-            assert lib.lfamd_comm_check(comm) == 0
-            two = sgemm.mul_mat(W, xb.view(torch.uint8).view(1, k * 4), T.F32, n=1)
-            assert torch.equal(out, resid + two)
-        ok, G = oracle.sgemm(t, A, T.Q8_K, synth.quantize_activations(T.Q8_K, x), m, 1, k)
-        assert ok == 1
-        got = (out - resid).cpu().numpy()
-        assert np.abs(got - G).max() <= 1e-5 * np.abs(G).max() + 1e-6  # (out - resid re-rounds; the product itself is checked above)
-    finally:
-        lib.lfamd_comm_destroy(comm)
