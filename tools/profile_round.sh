@@ -14,7 +14,7 @@ with open(sys.argv[2], "w") as o:
     w = csv.writer(o)
     w.writerow(rows[0])
     for r in rows[1:]:
-        if any(k in r[0] for k in ("gemv", "gemm", "prep", "quantize", "pack", "moe")):
+        if any(k in r[0] for k in ("gemv", "gemm", "prep", "quantize", "pack", "moe")):  # (gemm_i8_kernel / prep_i8_kernel included)
             r[0] = r[0][:110]
             w.writerow(r)
 PY
@@ -41,6 +41,8 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             agg["gemm_q4k_lw_" + ("128x64" if "Li2E" in k else "128x128")].append(float(r["Counter_Value"]))
         elif "gemm_ks_kernel" in k:
             agg["gemm_q4k_ks_128x64"].append(float(r["Counter_Value"]))
+        elif "gemm_i8_kernel" in k:
+            agg["gemm_q4k_i8_128x64"].append(float(r["Counter_Value"]))
         elif "gemm_kr_kernel" in k:
             agg["gemm_q4k_kr_256x128"].append(float(r["Counter_Value"]))
     for k, v in agg.items():
