@@ -68,7 +68,7 @@ def test_default_prefill_body_vs_oracle_deep_k(gpu, oracle, t, m, k, dscale):
       * Q4_K on grids the int8 body takes (4096-row matrices at 512 tokens; lfamd_mul_mat_is_exact): exact integer dots — 2e-6
         normwise AND no element beyond 1e-5 * (|G| + rms);
       * the scaled-operand f16 bodies (Q4_K on large grids: gemm_kr; Q5_K, Q6_K: gemm_lw): normwise <= 1e-3 (north star) AND no
-        element beyond 2e-3 * (|G| + rms) (measured worst element 0.9-1.1e-3: profiles/r04_scaled_body_error.json).
+        element beyond 1.5e-3 * (|G| + rms) (measured worst element 8.7-9.4e-4: profiles/r04_scaled_body_error.json).
     The measured numbers are printed for that record."""
     from llamafile_amd import _hip, synth
     n = 512
@@ -87,7 +87,7 @@ def test_default_prefill_body_vs_oracle_deep_k(gpu, oracle, t, m, k, dscale):
     err = rel_err(got, G)
     exact = bool(_hip.lib().lfamd_mul_mat_is_exact(t, m, k, n, gpu.host_variant_flags() | (_hip.FLAG_PRECISE if W.exact_only else 0)))
     frac3, worst = elem_err(got, G, rtol=1e-3)
-    frac, _ = elem_err(got, G, rtol=1e-5 if exact else 2e-3)
+    frac, _ = elem_err(got, G, rtol=1e-5 if exact else 1.5e-3)
     print(f"DEFAULT_BODY_ERROR {T.NAMES[t]} m={m} k={k} d={dscale} body={'exact' if exact else 'scaled'}: normwise={err:.3e} "
           f"frac_over_1e-3={frac3:.4f} worst_elem={worst:.3e}")
     assert err <= (2e-6 if exact else 1e-3), err
