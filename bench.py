@@ -385,9 +385,10 @@ def config3_q8_0(a, dev):
     resident = sum(o.W.resident_bytes for ops in r.layers for o in ops)
     res = {"model": "llama3-8b-q8_0", "weight_bytes": resident,  # what the tensors occupy in HBM (the images the kernels read)
            "gguf_bytes": r.weight_bytes(),  # the tensors' size in the file: what the decode roofline below counts
-           "resident_images": "P80 (bit-exact vecdot) + the byte image of the MFMA batch body" +
-                              (" replaced by f16(d*q) rows for hipBLASLt (LFAMD_USE_BLASLT=1)" if _hip.lib().lfamd_vendor_gemm_available() else ""),
-           "batch_gemm": "hipBLASLt (opt-in)" if _hip.lib().lfamd_vendor_gemm_available() else "module's MFMA body (gemm_wide Q8_0 branch)"}
+           "resident_images": "P80 only: the bit-exact vecdot GEMV and the f16 MFMA batch body read the same image (the file's 1.0625 B per weight)" +
+                              (" + f16(d*q) rows for hipBLASLt (LFAMD_USE_BLASLT=1)" if _hip.lib().lfamd_vendor_gemm_available() else ""),
+           "batch_gemm": "hipBLASLt (opt-in)" if _hip.lib().lfamd_vendor_gemm_available() else
+                         "prep_lf_kernel + gemm_lf_q80_kernel (csrc/gemm_lf.hip: f16(d*q) built in registers from P80, loader waves, <= 1e-3)"}
     for n, reps, key in ((1, 20, "decode"), (a.prefill, 2, "prefill")):
         r.run_pass(n)
         torch.cuda.synchronize()

@@ -79,6 +79,9 @@ hipError_t lfamd_launch_moe(int, const void *, long, long, int, size_t, int, con
 size_t lfamd_moe_workspace(int, long, long, int, long, int);
 int lfamd_gemm_i8_ok(int Atype, long row_blocks128, long n);
 size_t lfamd_gemm_i8_workspace(long k, long n);
+hipError_t lfamd_launch_gemm_lf_q80(int count, const void *const *A, const long *m, long k, int Btype, const void *B, size_t b_row_bytes, long n,
+                                    float *const *C, const long *ldc, void *ws, hipStream_t s);
+size_t lfamd_gemm_lf_workspace(long k, long n);
 hipError_t lfamd_launch_gemm_i8(int count, const void *const *A, const long *m, long k, int Btype, const void *B, size_t b_row_bytes, long n,
                                 float *const *C, const long *ldc, void *ws, const int32_t *src_idx, hipStream_t s);
 }
@@ -224,12 +227,12 @@ size_t lfamd_packed_size(int type, long rows, long cols) {
         return (size_t)((rows + 31) / 32) * (size_t)(cols / 256) * P5K_TILE;
     case LFAMD_TYPE_Q6_K:
         return (size_t)((rows + 31) / 32) * (size_t)(cols / 256) * P6K_TILE;
-    case LFAMD_TYPE_Q8_0: // P80 (the bit-exact vecdot / exact batch kernels), then the image batches read: f16(d * q) rows for the
-                          // vendor GEMM (3.1 bytes per weight resident), or — hipBLASLt not loadable, rows of whole 256-weight
-                          // groups — the PC8-form byte image of the MFMA body (2.1 bytes per weight)
-        if (lfamd_blaslt_ok()) // plain f16 image f16(d * q), row-major: batches are a library GEMM (blaslt.hip)
+    case LFAMD_TYPE_Q8_0: // P80, the ONE resident image (1.0625 bytes per weight, the file's): the bit-exact vecdot GEMV, the exact
+                          // batch kernel and the f16 MFMA batch body (gemm_lf.hip) all read it.  A host that opted into the vendor GEMM
+                          // (LFAMD_USE_BLASLT=1) also keeps the plain f16(d * q) rows that library needs (3.1 bytes per weight)
+        if (lfamd_blaslt_ok())
             return q80_p80_bytes(rows, cols) + (size_t)rows * (size_t)cols * 2;
-        return q80_p80_bytes(rows, cols) + (cols % 256 == 0 ? lfamd_wprep8_bytes(rows, cols) : 0);
+        return q80_p80_bytes(rows, cols);
     case LFAMD_TYPE_Q2_K:
     case LFAMD_TYPE_Q3_K: // PK2 / PK3: compact images (84 / 116 bytes per 256 weights) the decode GEMV reads; batches expand them
         return lfamd_pk_bytes(type, rows, cols); // into the canonical PCK image in the workspace, per call
@@ -278,8 +281,6 @@ int lfamd_pack_weights(int type, long rows, long cols, const void *d_raw, size_t
         HIPCHK(lfamd_launch_pack_q80(d_raw, raw_row_bytes, rows, cols, d_packed, s), "pack_q80");
         if (lfamd_blaslt_ok())
             HIPCHK(lfamd_launch_q80_image(d_raw, raw_row_bytes, rows, cols, (uint8_t *)d_packed + q80_p80_bytes(rows, cols), s), "pack_f16 (Q8_0)");
-        else if (cols % 256 == 0)
-            HIPCHK(lfamd_launch_wprep8(type, d_packed, 0, rows, cols, (uint8_t *)d_packed + q80_p80_bytes(rows, cols), s), "pack_pc8 (Q8_0)");
         break;
     case LFAMD_TYPE_Q2_K:
     case LFAMD_TYPE_Q3_K:
@@ -375,31 +376,26 @@ static bool use_gemm_float(int Atype, long n, unsigned flags, long k) {
     return !(flags & LFAMD_FLAG_FORCE_GENERIC) && n > 8 && k % 256 == 0 && (Atype == LFAMD_TYPE_F16 || Atype == LFAMD_TYPE_BF16);
 }
 
-// Q8_0 batches.  Default: the vendor's f16 GEMM on the resident f16(d * q) image (blaslt.hip; <= 1e-3, the north star's tolerance
-// for f16 MFMA paths); where hipBLASLt does not load (rows of whole 256-weight groups): this module's MFMA body on the resident
-// byte image — exact integer block dots, f32 block scales, <= 2e-6.  The north star asks for bit-exactness of the Q8_0 VECDOT
-// (n <= 8: the GEMV), not for replaying tinyBLAS's 8-lane chains at n = 512; LFAMD_FLAG_PRECISE / LFAMD_FLAG_Q80_EXACT (or other
-// row lengths without the library): the register-tiled BIT-EXACT kernel (gemm_q80.hip), an order of magnitude slower.
-// (with hipBLASLt loadable the default is the library GEMM on the resident f16 image: use_gemm_q80_lt)
+// Q8_0 batches.  Default (rows of whole 128-weight quads): this module's f16 MFMA body on the resident P80 image (gemm_lf.hip) —
+// f16(d * q) x f16(d8 * q8), what the reference's GPU path computes for such a batch, <= 1e-3 (the north star's tolerance for
+// f16 MFMA paths).  The north star asks for bit-exactness of the Q8_0 VECDOT (n <= 8: the GEMV), not for replaying tinyBLAS's
+// 8-lane chains at n = 512; LFAMD_FLAG_PRECISE / LFAMD_FLAG_Q80_EXACT (or other row lengths): the register-tiled BIT-EXACT kernel
+// (gemm_q80.hip), an order of magnitude slower.  A host that opted into the vendor library (LFAMD_USE_BLASLT=1) gets its f16 GEMM
+// on a second resident image instead (use_gemm_q80_lt).
 static bool use_gemm_q80_lt(int Atype, long n, unsigned flags, long k) {
     return !(flags & (LFAMD_FLAG_FORCE_GENERIC | LFAMD_FLAG_PRECISE | LFAMD_FLAG_Q80_EXACT)) && n > 8 && Atype == LFAMD_TYPE_Q8_0 && k % 32 == 0 &&
            lfamd_blaslt_ok();
 }
-static bool use_gemm_q80_mfma(int Atype, long n, unsigned flags, long k) {
-    return !(flags & (LFAMD_FLAG_FORCE_GENERIC | LFAMD_FLAG_PRECISE | LFAMD_FLAG_Q80_EXACT)) && n > 8 && Atype == LFAMD_TYPE_Q8_0 && k % 256 == 0 &&
+static bool use_gemm_q80_lf(int Atype, long n, unsigned flags, long k) {
+    return !(flags & (LFAMD_FLAG_FORCE_GENERIC | LFAMD_FLAG_PRECISE | LFAMD_FLAG_Q80_EXACT)) && n > 8 && Atype == LFAMD_TYPE_Q8_0 && k % 128 == 0 &&
            !lfamd_blaslt_ok();
 }
 static size_t gemm_lt_ws(long k, long n) { // the 16-bit activation rows, then the library's workspace
     return align_up((size_t)n * (size_t)k * 2, 256) + lfamd_blaslt_workspace();
 }
 static bool use_gemm_q80(int Atype, long n, unsigned flags, long k) {
-    return !(flags & LFAMD_FLAG_FORCE_GENERIC) && n > 8 && Atype == LFAMD_TYPE_Q8_0 && !use_gemm_q80_mfma(Atype, n, flags, k) &&
+    return !(flags & LFAMD_FLAG_FORCE_GENERIC) && n > 8 && Atype == LFAMD_TYPE_Q8_0 && !use_gemm_q80_lf(Atype, n, flags, k) &&
            !use_gemm_q80_lt(Atype, n, flags, k);
-}
-static size_t gemm_q80_mfma_ws(long m, long k, long n) { // Xh, d8T [nb*8][n_pad]  (the weight image is resident: lfamd_packed_size)
-    (void)m;
-    size_t n_pad = align_up((size_t)n, 128), nb = (size_t)(k / 256);
-    return align_up(n_pad * (size_t)k * 2, 256) + align_up(nb * 8 * n_pad * 4, 256);
 }
 
 // Small batches of Q4_K / Q5_K / Q6_K (up to 32 tokens) on gemm_sb.hip, where it is the fastest route (MI355X; old -> new, us).
@@ -458,7 +454,7 @@ int lfamd_mul_mat_is_exact(int Atype, long m, long k, long n, unsigned flags) {
         return 0;
     const bool kq = Atype == LFAMD_TYPE_Q4_K || Atype == LFAMD_TYPE_Q5_K || Atype == LFAMD_TYPE_Q6_K;
     if (n <= 8 || !kq)
-        return Atype != LFAMD_TYPE_Q8_0 || n <= 8 || !lfamd_blaslt_ok() || (flags & (LFAMD_FLAG_PRECISE | LFAMD_FLAG_Q80_EXACT)) ? 1 : 0;
+        return Atype != LFAMD_TYPE_Q8_0 || n <= 8 || !(use_gemm_q80_lt(Atype, n, flags, k) || use_gemm_q80_lf(Atype, n, flags, k)) ? 1 : 0;
     if (use_gemm_sb(Atype, n, flags, k, m))
         return 1;
     if (Atype == LFAMD_TYPE_Q6_K)
@@ -478,7 +474,7 @@ static size_t mul_mat_workspace_base(int Atype, long m, long k, long n) {
     }
     if (Atype == LFAMD_TYPE_Q8_0 && n > 8) { // (either body may be asked for through the flags: the largest)
         const size_t exact = align_up(lfamd_gemm_q80_workspace(k, n), 256);
-        const size_t mfma = use_gemm_q80_lt(Atype, n, 0, k) ? gemm_lt_ws(k, n) : k % 256 == 0 ? gemm_q80_mfma_ws(m, k, n) : 0;
+        const size_t mfma = use_gemm_q80_lt(Atype, n, 0, k) ? gemm_lt_ws(k, n) : k % 128 == 0 ? align_up(lfamd_gemm_lf_workspace(k, n), 256) : 0;
         return exact > mfma ? exact : mfma;
     }
     if (use_gemm_float(Atype, n, 0, k)) {
@@ -665,16 +661,11 @@ int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const v
         HIPCHK(lfamd_launch_gemm_q80(d_A, m, k, Btype, d_B, b_row_bytes, n, d_C, ldc, d_ws, vregs32, precise, s), "gemm_q80 (library declined)");
         return LFAMD_OK;
     }
-    if (use_gemm_q80_mfma(Atype, n, flags, k)) {
-        if (ws_bytes < gemm_q80_mfma_ws(m, k, n) || !d_ws)
+    if (use_gemm_q80_lf(Atype, n, flags, k) && (Btype == LFAMD_TYPE_F32 || Btype == LFAMD_TYPE_Q8_0)) {
+        if (ws_bytes < lfamd_gemm_lf_workspace(k, n) || !d_ws)
             return fail(LFAMD_ERR_WORKSPACE, "mul_mat: workspace too small%s", "");
-        size_t n_pad = align_up((size_t)n, 128);
-        uint8_t *ws = (uint8_t *)d_ws;
-        void *Xh = ws;
-        void *d8T = ws + align_up(n_pad * (size_t)k * 2, 256);
-        const void *img = (const uint8_t *)d_A + q80_p80_bytes(m, k); // built once by lfamd_pack_weights
-        HIPCHK(lfamd_launch_prep80(Btype, d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, nullptr, s), "prep80");
-        HIPCHK(lfamd_launch_gemm_wide(Atype, img, m, k, Xh, d8T, nullptr, n, (long)n_pad, d_C, ldc, plain, nullptr, 0, s), "gemm_wide (Q8_0)");
+        const void *A1 = d_A;
+        HIPCHK(lfamd_launch_gemm_lf_q80(1, &A1, &m, k, Btype, d_B, b_row_bytes, n, &d_C, &ldc, d_ws, s), "gemm_lf (Q8_0)");
         return LFAMD_OK;
     }
     if (use_gemm_q80(Atype, n, flags, k)) {
@@ -907,6 +898,19 @@ int lfamd_mul_mat_multi(int Atype, int count, const void *const *d_A, const long
                 HIPCHK(lfamd_launch_prep_q8k(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, scaled ? 2 : 0, nullptr, s), "prep_q8k");
             HIPCHK(lfamd_launch_gemm_wide_multi(Atype, count, d_A, m, k, Xh, d8T, Xm, n, (long)n_pad, d_C, ldc, plain | (scaled << 1), nullptr, 0, s),
                    "gemm_wide_multi");
+            return LFAMD_OK;
+        }
+    }
+    // Q8_0 batches on sibling matrices: one staging of the activations, one launch over the concatenated row blocks
+    if (count > 1 && count <= 4 && use_gemm_q80_lf(Atype, n, flags, k) && (Btype == LFAMD_TYPE_F32 || Btype == LFAMD_TYPE_Q8_0) && k > 0 &&
+        b_row_bytes >= lfamd_row_size(Btype, k)) {
+        bool ok = true;
+        for (int j = 0; j < count && ok; j++)
+            ok = m[j] >= 0 && ldc[j] >= m[j];
+        if (ok) {
+            if (ws_bytes < lfamd_gemm_lf_workspace(k, n) || !d_ws)
+                return fail(LFAMD_ERR_WORKSPACE, "mul_mat_multi: workspace too small%s", "");
+            HIPCHK(lfamd_launch_gemm_lf_q80(count, d_A, m, k, Btype, d_B, b_row_bytes, n, d_C, ldc, d_ws, (hipStream_t)stream), "gemm_lf (Q8_0, multi)");
             return LFAMD_OK;
         }
     }

@@ -1,0 +1,382 @@
+// gemm_lf.hip — Q8_0 batches (n > 8) on the f16 matrix cores, straight from the RESIDENT P80 image (the one the bit-exact
+// vecdot GEMV reads: no second copy of the weights), scaled operands: f16(d * q) x f16(d8 * q8), f32 accumulate.  That is what
+// the reference's GPU path computes for a Q8_0 batch (dequantise to f16, f16 GEMM: llamafile/tinyblas.cu:142-226, 475-560;
+// ggml-cuda.cu.patch ggml_cuda_op_mul_mat_cublas) and the north star's tolerance for f16 MFMA paths, <= 1e-3 against the oracle
+// (tinyblas_cpu.h:934-971 restated); LFAMD_FLAG_PRECISE / LFAMD_FLAG_Q80_EXACT ask for the bit-exact kernel (gemm_q80.hip).
+//
+// Shape of the work (the skeleton of gemm_i8.hip): work-group = 128 weight rows x 32 NT tokens, 8 waves.  Waves 4..7 only LOAD —
+// everything arrives by LDS-DMA, R - 1 stages ahead in a ring of R, one barrier per stage; waves 0..3 compute, one per SIMD,
+// 32 rows x 32 NT tokens each over the whole K.  A stage is ONE quad of Q8_0 blocks (128 weights per row):
+//   weights     : 4 row tiles x 4 P80 tiles (8 rows x 4 blocks: 1024 B of codes + 64 B of f16 scales) — a P80 tile's codes are one
+//                 DMA piece; lane (r, j) of a tile holds bytes 4 j .. 4 j + 3 of the quad's FOUR blocks, so a 16-byte LDS read
+//                 gives lane (row, K half h) the operands of two K-steps: K-step s = 2 jj + e of the stage multiplies
+//                 {block 2 e, block 2 e + 1} x {bytes 4 j .. 4 j + 3}, j = 4 h + jj — a permutation of the stage's 128 weights
+//                 that the activation image is written in as well (prep_lf_kernel).  The piece's chunks are placed in LDS at
+//                 position r * 8 + (j ^ (4 (T & 1) + (r >> 1))) of tile T (chosen on the SOURCE address): every 16-lane group
+//                 of a ds_read_b128 then covers all 64 banks.
+//   dequantise  : q ^ 0x80 = q + 128 as a byte; v_perm builds the f16 pair 1024 + u, a packed add of -1152 gives q exactly, a
+//                 packed multiply d * q rounded once: 14 VALU per K-step and wave, feeding NT MFMAs.
+//   activations : f16(d8 * q8) (quantize_row_q8_0 arithmetic, or the caller's Q8_0 blocks), [quad][token][256 B] in the K order
+//                 above, 16-byte chunks XOR-swizzled by token on the source address.
+#include "gemm_wide_impl.h"
+
+#include <stdlib.h>
+
+typedef _Float16 lf_half4 __attribute__((ext_vector_type(4)));
+
+#define LF_W 0        // 16 P80 tiles x 1024 B of codes
+#define LF_WD 16384   // 16 x 64 B of block scales
+#define LF_X 17408    // 32 NT tokens x 256 B
+
+// LDS-DMA pieces: 64 lanes x 16 B (x 4 B) from base + voff to LDS at lds_dst + 16 (4) * lane.  SGPR base kept by scalar adds; M0
+// written and not restored (nothing else in this kernel reads it).
+__device__ static inline void lf_dma16(const void *base, uint32_t lds_dst, uint32_t voff) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(lds_dst) : "memory");
+}
+__device__ static inline void lf_dma4(const void *base, uint32_t lds_dst, uint32_t voff) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(base), "s"(lds_dst) : "memory");
+}
+template <int IMM>
+__device__ static inline void lf_dsr16(u32x4 &dst, uint32_t addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(IMM));
+}
+__device__ static inline void lf_dsr8(uint2 &dst, uint32_t addr) {
+    asm volatile("ds_read_b64 %0, %1" : "=v"(dst) : "v"(addr));
+}
+
+template <int NT>
+__global__ __launch_bounds__(512) void gemm_lf_q80_kernel(const gemm_mats mats, int nq, const _Float16 *__restrict__ Xh, long n, long n_pad,
+                                                           int n_rb, int n_ct) {
+#ifdef LF_CHECK_NQ // tools/isa_hazards.py: a fixed trip count
+    nq = LF_CHECK_NQ;
+#endif
+    constexpr int SLOT = LF_X + NT * 8192;
+    constexpr int RING = NT == 2 ? 4 : 3;
+    constexpr int COLS = 32 * NT;
+    constexpr int PIECES = 5 + 2 * NT; // of a loader and stage
+    __shared__ __attribute__((aligned(16))) uint8_t lds[RING * SLOT];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = lane & 31, h = lane >> 5;
+
+    // ---- tile of this work-group (the order of gemm_ks: XCD-aware super-tiles)
+    int rb, ct;
+    {
+        const int n_wg = n_rb * n_ct;
+        const int id = (int)blockIdx.x, q8 = n_wg >> 3, r8 = n_wg & 7, xcd = id & 7;
+        const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3);
+        tile_of(L, n_rb, n_ct, rb, ct);
+    }
+    int mj = 0;
+#pragma unroll
+    for (int jj = 1; jj < GEMM_MAX_MATS; jj++)
+        if (jj < mats.count && rb >= mats.rb_end[jj - 1])
+            mj = jj;
+    if (mj > 0)
+        rb -= mats.rb_end[mj - 1];
+    const uint8_t *__restrict__ A = mats.A[mj];
+    float *__restrict__ C = mats.C[mj];
+    const long m = mats.m[mj], ldc = mats.ldc[mj];
+    const long n0 = (long)ct * COLS;
+    const int n_tiles8 = (int)((m + 7) / 8);
+    const uint32_t lds0 = lds_addr(lds);
+
+    if (wave >= 4) {
+        // ================= loader waves: PIECES pieces per stage each, RING - 1 stages ahead, counted waits =================
+        // (eight loader waves with half the pieces each measured 1-5 % slower: the loaders do not set the pace)
+        const int lw = wave - 4;
+        // 0..3: the codes of P80 tiles 4 (4 rb + lw) + T (tiles past the matrix: its last one); lane = position p of the tile in LDS
+        uint32_t voffW[4];
+#pragma unroll
+        for (int T = 0; T < 4; T++) {
+            const int t8 = (rb * 4 + lw) * 4 + T;
+            const int r = lane >> 3, j = (lane & 7) ^ ((T & 1) * 4 + (r >> 1));
+            voffW[T] = (uint32_t)(t8 < n_tiles8 ? t8 : n_tiles8 - 1) * (uint32_t)nq * (uint32_t)P80_TILE + (uint32_t)((r * 8 + j) * 16);
+        }
+        const uint32_t dstW = (uint32_t)(LF_W + lw * 4096);
+        // 4: the block scales of those four tiles: 4 x 64 B, one dword per lane
+        uint32_t voffD;
+        {
+            const int t8 = (rb * 4 + lw) * 4 + (lane >> 4);
+            voffD = (uint32_t)(t8 < n_tiles8 ? t8 : n_tiles8 - 1) * (uint32_t)nq * (uint32_t)P80_TILE + (uint32_t)(P80_D + (lane & 15) * 4);
+        }
+        const uint32_t dstD = (uint32_t)(LF_WD + lw * 256);
+        // 5..: activation pieces 2 NT lw + e: tokens 4 p .. 4 p + 3, lane = (token 4 p + (lane >> 4), slot lane & 15) <- chunk slot ^ (token & 15)
+        uint32_t voffX[2 * NT];
+#pragma unroll
+        for (int e = 0; e < 2 * NT; e++) {
+            const int tk = 4 * (2 * NT * lw + e) + (lane >> 4);
+            voffX[e] = (uint32_t)(tk * 256 + (((lane & 15) ^ (tk & 15)) << 4));
+        }
+        const uint32_t dstX = (uint32_t)(LF_X + 2 * NT * lw * 1024);
+        const size_t xstride = (size_t)n_pad * 256;
+        const uint8_t *wt_n = uniform_ptr(A);
+        const uint8_t *xh_n = uniform_ptr((const uint8_t *)Xh + (size_t)n0 * 256);
+        // five wait states between the VALU writes of those SGPRs (v_readfirstlane) and the first vector-memory instruction that
+        // reads them: hipcc pads such hazards itself, but not in front of an asm statement (tools/isa_hazards.py checks the ISA)
+        asm volatile("s_nop 4" ::"s"(wt_n), "s"(xh_n));
+        auto dma_stage = [&](uint32_t slot_base) {
+#pragma unroll
+            for (int T = 0; T < 4; T++)
+                lf_dma16(wt_n, slot_base + dstW + (uint32_t)(T * 1024), voffW[T]);
+            lf_dma4(wt_n, slot_base + dstD, voffD);
+#pragma unroll
+            for (int e = 0; e < 2 * NT; e++)
+                lf_dma16(xh_n, slot_base + dstX + (uint32_t)(e * 1024), voffX[e]);
+            wt_n += P80_TILE, xh_n += xstride; // (past the last quad nothing more is issued)
+        };
+#pragma unroll
+        for (int st = 0; st < RING - 1; st++)
+            if (st < nq) // (uniform)
+                dma_stage(lds0 + (uint32_t)(st * SLOT));
+        // stage 0 has landed when only the stages issued behind it are in flight
+        {
+            const int behind = (nq < RING - 1 ? nq : RING - 1) - 1;
+            if (behind >= 2)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");
+            else if (behind == 1)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_barrier" ::: "memory"); // stage 0 has landed for everybody
+        int slot_i = RING - 1; // slot of stage b + RING - 1
+        for (int b = 0; b < nq; b++) {
+            // this wave's pieces of stage b + 1 (all but those of the stages issued behind it); past the barrier everybody's have
+            // landed and everybody is done with stage b - 1, whose slot takes stage b + RING - 1
+            int behind = nq - 2 - b; // stages issued behind stage b + 1
+            behind = behind < 0 ? 0 : behind > RING - 3 ? RING - 3 : behind;
+            if (RING == 4 && behind >= 1)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_barrier" ::: "memory");
+            if (b + RING - 1 < nq)
+                dma_stage(lds0 + (uint32_t)(slot_i * SLOT));
+            slot_i = slot_i + 1 == RING ? 0 : slot_i + 1;
+        }
+        return;
+    }
+
+    // ================= compute waves: row tile rw, NT token tiles =================
+    const int rw = wave;
+    const int rt = rb * 4 + rw;
+    const int T = i >> 3, r = i & 7;
+    // ---- this lane's LDS read addresses in slot 0: the weight chunk of K-step pair jj, its scales, the code chunk of K-step s
+    uint32_t adW[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; jj++)
+        adW[jj] = lds0 + (uint32_t)(LF_W + (rw * 4 + T) * 1024 + (r * 8 + ((4 * h + jj) ^ ((T & 1) * 4 + (r >> 1)))) * 16);
+    const uint32_t adD = lds0 + (uint32_t)(LF_WD + (rw * 4 + T) * 64 + r * 8);
+    uint32_t adX[8];
+#pragma unroll
+    for (int s = 0; s < 8; s++)
+        adX[s] = lds0 + (uint32_t)(LF_X + i * 256 + (((2 * s + h) ^ (i & 15)) << 4));
+
+    float16_t_ acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int e = 0; e < 16; e++)
+            acc[t][e] = 0.0f;
+
+    asm volatile("s_barrier" ::: "memory"); // stage 0 has landed for everybody
+
+    // Registers of the LDS pipeline (all reads are asm, every wait is counted: LDS reads of a wave return in issue order): XF[2][NT]
+    // the code fragments ONE K-step ahead (two ahead measured the same), WQ[2] the weight chunks (one serves two K-steps) one pair
+    // ahead, SC the stage's scales.  In K-step s the wave issues X(s + 1) [NT reads], at odd s the weight chunk of pair (s + 1) / 2,
+    // at s = 7 the next stage's scales — from the NEXT slot once s + 1 = 8: that stage has landed, the barrier at the top of this one
+    // said so — then waits for what step s needs: younger than it are exactly this step's own reads.
+    u32x4 XF[2][NT], WQ[2];
+    uint2 SC;
+#define LF_WAIT(N) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N))
+#define LF_XREAD(S, BASE)                                                                                                     \
+    do {                                                                                                                      \
+        lf_dsr16<0>(XF[(S)&1][0], adX[(S)&7] + (BASE));                                                                        \
+        lf_dsr16<8192>(XF[(S)&1][1], adX[(S)&7] + (BASE));                                                                     \
+        if (NT == 4) {                                                                                                        \
+            lf_dsr16<16384>(XF[(S)&1][NT - 2], adX[(S)&7] + (BASE));                                                           \
+            lf_dsr16<24576>(XF[(S)&1][NT - 1], adX[(S)&7] + (BASE));                                                           \
+        }                                                                                                                     \
+    } while (0)
+#define LF_XTIE(S)                                                                                                            \
+    do {                                                                                                                      \
+        asm volatile("" : "+v"(XF[(S)&1][0]), "+v"(XF[(S)&1][1]));                                                              \
+        if (NT == 4)                                                                                                          \
+            asm volatile("" : "+v"(XF[(S)&1][NT - 2]), "+v"(XF[(S)&1][NT - 1]));                                                \
+    } while (0)
+    LF_XREAD(0, 0u);
+    lf_dsr16<0>(WQ[0], adW[0]);
+    lf_dsr8(SC, adD);
+
+    half2_t Dk[4]; // per block of the quad: (d, d)
+    int slot_c = 0;
+    for (int b = 0; b < nq; b++) {
+        const uint32_t so = (uint32_t)(slot_c * SLOT);
+        slot_c = slot_c + 1 == RING ? 0 : slot_c + 1;
+        const uint32_t so_n = (uint32_t)(slot_c * SLOT);
+        asm volatile("s_barrier" ::: "memory"); // stage b + 1 has landed for everybody (the loaders waited for their pieces)
+#define LF_STEP(S)                                                                                                            \
+    do {                                                                                                                      \
+        LF_XREAD((S) + 1, (S) == 7 ? so_n : so);                                                                              \
+        if ((S)&1)                                                                                                            \
+            lf_dsr16<0>(WQ[(((S) + 1) >> 1) & 1], adW[(((S) + 1) >> 1) & 3] + ((S) == 7 ? so_n : so));                           \
+        if ((S) == 7)                                                                                                         \
+            lf_dsr8(SC, adD + so_n);                                                                                          \
+        LF_WAIT(NT + ((S)&1) + ((S) == 7));                                                                                   \
+        LF_XTIE(S);                                                                                                           \
+        asm volatile("" : "+v"(WQ[((S) >> 1) & 1]));                                                                           \
+        if ((S) == 0) { /* (d, d) of the quad's four blocks */                                                                \
+            asm volatile("" : "+v"(SC));                                                                                      \
+            Dk[0] = as_half2(__builtin_amdgcn_perm(SC.x, SC.x, 0x01000100u)), Dk[1] = as_half2(__builtin_amdgcn_perm(SC.x, SC.x, 0x03020302u)); \
+            Dk[2] = as_half2(__builtin_amdgcn_perm(SC.y, SC.y, 0x01000100u)), Dk[3] = as_half2(__builtin_amdgcn_perm(SC.y, SC.y, 0x03020302u)); \
+        }                                                                                                                     \
+        const u32x4 &wq_ = WQ[((S) >> 1) & 1];                                                                                 \
+        const uint32_t u0_ = (((S)&1) ? wq_.z : wq_.x) ^ 0x80808080u, u1_ = (((S)&1) ? wq_.w : wq_.y) ^ 0x80808080u;            \
+        const half2_t m1152_ = {(_Float16)-1152.0f, (_Float16)-1152.0f};                                                      \
+        frag_u f_; /* (1024 + u) - 1152 = q exactly, then ONE rounding in d * q (a fused -1152 d would be a rounded constant) */ \
+        f_.p[0] = (as_half2(__builtin_amdgcn_perm(0x64646464u, u0_, 0x04010400u)) + m1152_) * Dk[2 * ((S)&1)];                  \
+        f_.p[1] = (as_half2(__builtin_amdgcn_perm(0x64646464u, u0_, 0x04030402u)) + m1152_) * Dk[2 * ((S)&1)];                  \
+        f_.p[2] = (as_half2(__builtin_amdgcn_perm(0x64646464u, u1_, 0x04010400u)) + m1152_) * Dk[2 * ((S)&1) + 1];              \
+        f_.p[3] = (as_half2(__builtin_amdgcn_perm(0x64646464u, u1_, 0x04030402u)) + m1152_) * Dk[2 * ((S)&1) + 1];              \
+        _Pragma("unroll") for (int t = 0; t < NT; t++)                                                                         \
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, XF[(S)&1][t]), f_.v, acc[t], 0, 0, 0);  \
+        __builtin_amdgcn_sched_barrier(0); /* (left alone hipcc gathers the reads of all eight steps at the top of the stage) */ \
+    } while (0)
+        LF_STEP(0);
+        LF_STEP(1);
+        LF_STEP(2);
+        LF_STEP(3);
+        LF_STEP(4);
+        LF_STEP(5);
+        LF_STEP(6);
+        LF_STEP(7);
+#undef LF_STEP
+    }
+    LF_WAIT(0); // (the reads of a stage that does not exist: slot contents never used)
+    LF_XTIE(0);
+    asm volatile("" : "+v"(WQ[0]), "+v"(SC));
+#undef LF_WAIT
+#undef LF_XREAD
+#undef LF_XTIE
+
+    // ---- store: lane (i, h) holds weight row 32 rt + i, register e = token n0 + 32 t + 8 (e >> 2) + 4 h + (e & 3)
+    if ((long)rt * 32 + i < m) {
+        const long row = (long)rt * 32 + i;
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const long tk = n0 + 32 * t + 8 * (e >> 2) + 4 * h + (e & 3);
+                if (tk < n)
+                    C[tk * ldc + row] = acc[t][e];
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Activation staging: f16(d8 * q8) of Q8_0-quantised rows (quantize_row_q8_0: d = amax / 127 kept as f16, code = roundf(x / d);
+// or the caller's Q8_0 blocks), written as Xh [quad][n_pad][256 B]: 16-byte chunk 2 s + h of a token and quad = K-step s = 2 jj + e,
+// K half h = {block 2 e, block 2 e + 1} x {elements 4 j .. 4 j + 3}, j = 4 h + jj.  One thread per eight consecutive elements
+// (two groups j = 2 o, 2 o + 1 of block bq of the quad); the block maximum over the four threads of a block by DPP.
+template <bool F32IN>
+__global__ __launch_bounds__(256) void prep_lf_kernel(const uint8_t *__restrict__ X, size_t x_row_bytes, long n, long n_pad, int nq,
+                                                       _Float16 *__restrict__ Xh) {
+    const long tok = (long)blockIdx.x;
+    const int c8 = (int)blockIdx.y * 256 + (int)threadIdx.x; // eight elements 8 c8 .. 8 c8 + 7 of the row
+    const bool live = c8 < nq * 16;
+    const int cc = live ? c8 : 0;
+    float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float d = 0.0f;
+    if (tok < n) {
+        if constexpr (F32IN) {
+            const float4 *p = (const float4 *)((const float *)(X + (size_t)tok * x_row_bytes) + (size_t)cc * 8);
+            const float4 f0 = p[0], f1 = p[1];
+            v[0] = f0.x, v[1] = f0.y, v[2] = f0.z, v[3] = f0.w, v[4] = f1.x, v[5] = f1.y, v[6] = f1.z, v[7] = f1.w;
+            float am = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 8; e++)
+                am = fmaxf(am, fabsf(v[e]));
+            am = fmaxf(am, dpp_f32<DPP_XOR1>(am)); // the block's four threads are one quad of lanes
+            am = fmaxf(am, dpp_f32<DPP_XOR2>(am));
+            const float dd = am / 127.0f;
+            const float id = dd != 0.0f ? 1.0f / dd : 0.0f;
+            d = (float)(_Float16)dd; // the scale as the block stores it
+#pragma unroll
+            for (int e = 0; e < 8; e++)
+                v[e] = roundf(v[e] * id);
+        } else {
+            const lfamd_block_q8_0 *bq = (const lfamd_block_q8_0 *)(X + (size_t)tok * x_row_bytes) + (cc >> 2);
+            d = h2f(bq->d);
+#pragma unroll
+            for (int e = 0; e < 8; e++)
+                v[e] = (float)bq->qs[(cc & 3) * 8 + e];
+        }
+    }
+    if (!live)
+        return;
+    const int quad = cc >> 4, blk = (cc >> 2) & 3, o = cc & 3;
+    uint8_t *dst = (uint8_t *)Xh + ((size_t)quad * n_pad + tok) * 256;
+#pragma unroll
+    for (int g = 0; g < 2; g++) { // group j = 2 o + g: K half j >> 2, pair jj = j & 3; K-step 2 jj + (blk >> 1), second half of the chunk for odd blocks
+        const int j = 2 * o + g, hh = j >> 2, jj = j & 3, s = 2 * jj + (blk >> 1);
+        lf_half4 w;
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+            w[e] = (_Float16)(d * v[4 * g + e]);
+        *(lf_half4 *)(dst + (2 * s + hh) * 16 + (blk & 1) * 8) = w;
+    }
+}
+
+// Which launches take this body: Q8_0, rows of whole quads.  NT = 4 (128 x 128 tiles) where those fill the chip, else 128 x 64.
+static int lf_nt(long row_blocks128, long n) {
+    static const int force = getenv("LFAMD_LF_NT") ? atoi(getenv("LFAMD_LF_NT")) : 0; // A/B runs
+    if (force == 2 || force == 4)
+        return force;
+    return row_blocks128 * ((n + 127) / 128) >= 160 ? 4 : 2; // (6144 x 4096 x 512: 192 tiles of 128 x 128 44 us, 384 of 128 x 64 54)
+}
+
+extern "C" size_t lfamd_gemm_lf_workspace(long k, long n) { // Xh
+    const size_t n_pad = ((size_t)n + 127) / 128 * 128;
+    return n_pad * (size_t)k * 2;
+}
+
+// B: f32 rows or Q8_0 blocks; ws: lfamd_gemm_lf_workspace(k, n) bytes; A[j]: P80 images of m[j] x k.
+extern "C" hipError_t lfamd_launch_gemm_lf_q80(int count, const void *const *A, const long *m, long k, int Btype, const void *B,
+                                               size_t b_row_bytes, long n, float *const *C, const long *ldc, void *ws, hipStream_t s) {
+    if (n <= 0 || count <= 0)
+        return hipSuccess;
+    if (count > GEMM_MAX_MATS || k % 128 || (Btype != LFAMD_TYPE_F32 && Btype != LFAMD_TYPE_Q8_0))
+        return hipErrorInvalidValue;
+    const int nq = (int)(k / 128);
+    const long n_pad = (n + 127) / 128 * 128;
+    _Float16 *Xh = (_Float16 *)ws;
+    const dim3 pg((unsigned)n_pad, (unsigned)((nq * 16 + 255) / 256));
+    if (Btype == LFAMD_TYPE_F32)
+        prep_lf_kernel<true><<<pg, 256, 0, s>>>((const uint8_t *)B, b_row_bytes, n, n_pad, nq, Xh);
+    else
+        prep_lf_kernel<false><<<pg, 256, 0, s>>>((const uint8_t *)B, b_row_bytes, n, n_pad, nq, Xh);
+    gemm_mats mats;
+    int n_rb = 0;
+    mats.count = 0;
+    mats.moe_cnt = mats.moe_poff = mats.moe_slot_row = nullptr, mats.expert_bytes = 0, mats.moe_ct_max = 0;
+    for (int j = 0; j < count; j++) {
+        if (m[j] <= 0)
+            continue;
+        const int q = mats.count++;
+        mats.A[q] = (const uint8_t *)A[j], mats.C[q] = C[j], mats.m[q] = m[j], mats.ldc[q] = ldc[j];
+        n_rb += (int)((m[j] + 127) / 128);
+        mats.rb_end[q] = n_rb;
+    }
+    if (mats.count == 0)
+        return hipGetLastError();
+    for (int q = mats.count; q < GEMM_MAX_MATS; q++)
+        mats.A[q] = mats.A[0], mats.C[q] = mats.C[0], mats.m[q] = 0, mats.ldc[q] = 0, mats.rb_end[q] = n_rb;
+    if (lf_nt(n_rb, n) == 4) {
+        const int n_ct = (int)((n + 127) / 128);
+        gemm_lf_q80_kernel<4><<<(unsigned)(n_rb * n_ct), 512, 0, s>>>(mats, nq, Xh, n, n_pad, n_rb, n_ct);
+    } else {
+        const int n_ct = (int)((n + 63) / 64);
+        gemm_lf_q80_kernel<2><<<(unsigned)(n_rb * n_ct), 512, 0, s>>>(mats, nq, Xh, n, n_pad, n_rb, n_ct);
+    }
+    return hipGetLastError();
+}

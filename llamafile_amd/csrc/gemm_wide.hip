@@ -14,7 +14,6 @@ hipError_t lfamd_wide_go_q3k(WIDE_ARGS);
 hipError_t lfamd_wide_go_iq4xs(WIDE_ARGS);
 hipError_t lfamd_wide_go_f16(WIDE_ARGS);
 hipError_t lfamd_wide_go_bf16(WIDE_ARGS);
-hipError_t lfamd_wide_go_q80(WIDE_ARGS);
 
 hipError_t lfamd_lw_go(int Atype, const gemm_mats &mats, int nb, const void *Xh, const void *d8T, const void *Xm, long n, long n_pad,
                        int n_rb, int n_ct, unsigned n_wg, int moe, int fast, int nt, int ks, float *P, hipStream_t s);
@@ -156,8 +155,6 @@ static hipError_t wide_go(int Atype, int mode, float *P, size_t P_bytes, WIDE_AR
         return lfamd_wide_go_q2k(mats, nb, Xh, d8T, Xm, n, n_pad, n_rb, n_ct, ks, nbs, n_wg, moe, s);
     case LFAMD_TYPE_Q3_K:
         return lfamd_wide_go_q3k(mats, nb, Xh, d8T, Xm, n, n_pad, n_rb, n_ct, ks, nbs, n_wg, moe, s);
-    case LFAMD_TYPE_Q8_0: // (per-call byte image, generic.hip wprep8)
-        return lfamd_wide_go_q80(mats, nb, Xh, d8T, Xm, n, n_pad, n_rb, n_ct, ks, nbs, n_wg, moe, s);
     case LFAMD_TYPE_IQ4_XS:
         return lfamd_wide_go_iq4xs(mats, nb, Xh, d8T, Xm, n, n_pad, n_rb, n_ct, ks, nbs, n_wg, moe, s);
     case LFAMD_TYPE_F16:

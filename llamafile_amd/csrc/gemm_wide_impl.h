@@ -146,19 +146,13 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const gemm_mats mats, in
     constexpr bool CANON16 = TYPE == LFAMD_TYPE_Q2_K || TYPE == LFAMD_TYPE_Q3_K;
     constexpr bool MINS16 = TYPE == LFAMD_TYPE_Q2_K;
     constexpr bool BYTES8 = TYPE == LFAMD_TYPE_IQ4_XS; // PC8 byte image built per call (generic.hip, wprep8)
-    // Q8_0 batches (tolerance path; the bit-exact kernel is gemm_q80.hip): a PC8-form byte image (q + 128) built per call
-    // from the resident P80 layout with the row's EIGHT f16 block scales as header; q is exact in f16, the activations
-    // are Q8_0-quantised codes (exact in f16), a 32-block's dot is exact in the f32 accumulator, then
-    // acc += (tmp * d8[token][block]) * d[row][block] per block like the legacy types (tinyblas_cpu.h:934-971's
-    // arithmetic without its 8-lane summation order: <= 2e-6 of the reference, not bit-exact)
-    constexpr bool Q80B = TYPE == LFAMD_TYPE_Q8_0;
-    constexpr bool BLK8 = LEGACY || Q80B; // eight 32-blocks per super-block: d8 per block
+    constexpr bool BLK8 = LEGACY; // eight 32-blocks per super-block: d8 per block
     // float tinyBLAS types (tinyblas_cpu.h:419-613): no dequantisation, no scales — the lane's 8 consecutive halves of a
     // K-step are 16 contiguous bytes of the RAW row; f32 accumulate on the matrix cores like the reference's fmaf chains
     constexpr bool FLT = TYPE == LFAMD_TYPE_F16 || TYPE == LFAMD_TYPE_BF16;
     __shared__ __attribute__((aligned(16))) float d8s[2][(BLK8 ? 8 : 1) * WD_COLS]; // d8 of the 128 tokens
     __shared__ __attribute__((aligned(16))) uint8_t xms[2][WD_COLS * 32]; // Q4_K mins operand rows; L1: the 8 x 128 f32 s values
-    constexpr int TILE = (TYPE == LFAMD_TYPE_Q4_K || TYPE == LFAMD_TYPE_Q4_0) ? P4K_TILE : LEGACY ? PCL_TILE : TYPE == LFAMD_TYPE_Q5_K ? P5K_TILE : CANON16 ? PCK_TILE : (BYTES8 || Q80B) ? PC8_TILE : P6K_TILE;
+    constexpr int TILE = (TYPE == LFAMD_TYPE_Q4_K || TYPE == LFAMD_TYPE_Q4_0) ? P4K_TILE : LEGACY ? PCL_TILE : TYPE == LFAMD_TYPE_Q5_K ? P5K_TILE : CANON16 ? PCK_TILE : BYTES8 ? PC8_TILE : P6K_TILE;
     constexpr bool MINS = TYPE == LFAMD_TYPE_Q4_K || TYPE == LFAMD_TYPE_Q5_K; // Q4_K family: {d, dmin, 6-bit scales/mins}
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 31, h = lane >> 5;
@@ -274,7 +268,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const gemm_mats mats, in
             gload16<128>(w.f[4], tile, fo), gload16<160>(w.f[5], tile, fo), gload16<192>(w.f[6], tile, fo), gload16<224>(w.f[7], tile, fo);
             gload16<256>(w.f[8], tile, fo), gload16<288>(w.f[9], tile, fo), gload16<320>(w.f[10], tile, fo), gload16<352>(w.f[11], tile, fo);
             gload16<384>(w.f[12], tile, fo), gload16<416>(w.f[13], tile, fo), gload16<448>(w.f[14], tile, fo), gload16<480>(w.f[15], tile, fo);
-        } else if constexpr (BYTES8 || Q80B) {
+        } else if constexpr (BYTES8) {
             gload16<0>(w.q8[0], tile_h, wo);
             gload16<1024>(w.q8[1], tile_h, wo);
             gload16<2048>(w.q8[2], tile_h, wo);
@@ -320,7 +314,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const gemm_mats mats, in
                 gload16<128>(w.f[4], tile, fo), gload16<160>(w.f[5], tile, fo), gload16<192>(w.f[6], tile, fo), gload16<224>(w.f[7], tile, fo);
                 gload16<256>(w.f[8], tile, fo), gload16<288>(w.f[9], tile, fo), gload16<320>(w.f[10], tile, fo), gload16<352>(w.f[11], tile, fo);
                 gload16<384>(w.f[12], tile, fo), gload16<416>(w.f[13], tile, fo), gload16<448>(w.f[14], tile, fo), gload16<480>(w.f[15], tile, fo);
-            } else if constexpr (BYTES8 || Q80B) {
+            } else if constexpr (BYTES8) {
                 gload16<0>(w.q8[0], tile_h, wo);
                 gload16<1024>(w.q8[1], tile_h, wo);
                 gload16<2048>(w.q8[2], tile_h, wo);
@@ -386,7 +380,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const gemm_mats mats, in
                          : "+v"(w.qs[0]), "+v"(w.qs[1]), "+v"(w.qs[2]), "+v"(w.qs[3]), "+v"(w.hd)
                          :
                          : "memory");
-        else if constexpr (BYTES8 || Q80B)
+        else if constexpr (BYTES8)
             asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier"
                          : "+v"(w.qs[0]), "+v"(w.qs[1]), "+v"(w.qs[2]), "+v"(w.qs[3]), "+v"(w.hd), "+v"(w.q8[0]), "+v"(w.q8[1]),
                            "+v"(w.q8[2]), "+v"(w.q8[3])
@@ -569,51 +563,6 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const gemm_mats mats, in
                         acc[nt][r] = fmaf(d * tmp[nt][r], d8[e], acc[nt][r]);
                     }
                 }
-        } else if constexpr (Q80B) {
-            const uint32_t bw[32] = {w.qs[0].x, w.qs[0].y, w.qs[0].z, w.qs[0].w, w.qs[1].x, w.qs[1].y, w.qs[1].z, w.qs[1].w,
-                                     w.qs[2].x, w.qs[2].y, w.qs[2].z, w.qs[2].w, w.qs[3].x, w.qs[3].y, w.qs[3].z, w.qs[3].w,
-                                     w.q8[0].x, w.q8[0].y, w.q8[0].z, w.q8[0].w, w.q8[1].x, w.q8[1].y, w.q8[1].z, w.q8[1].w,
-                                     w.q8[2].x, w.q8[2].y, w.q8[2].z, w.q8[2].w, w.q8[3].x, w.q8[3].y, w.q8[3].z, w.q8[3].w};
-            const uint32_t hdw[4] = {w.hd.x, w.hd.y, w.hd.z, w.hd.w}; // eight f16 block scales of this lane's row
-            const uint32_t d8base = d8_lane;
-            const half2_t S1 = bcast_h2(1.0f), O1 = bcast_h2(-1152.0f); // (1024 + byte) - 1152 = q
-            half8_t F[2][2];
-            read_frags(F[0], 0);
-#pragma unroll
-            for (int bl = 0; bl < 8; bl++) {
-#pragma unroll
-                for (int e = 0; e < 2; e++) {
-                    const int t = 2 * bl + e;
-                    const half8_t wf = dequant_bytes(bw[2 * t], bw[2 * t + 1], S1, O1);
-                    if (t + 1 < 16) {
-                        read_frags(F[(t + 1) & 1], t + 1);
-                        ds_wait<2>(F[t & 1][0], F[t & 1][1]);
-                    } else {
-                        ds_wait<0>(F[t & 1][0], F[t & 1][1]);
-                    }
-#pragma unroll
-                    for (int nt = 0; nt < 2; nt++)
-                        tmp[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F[t & 1][nt], wf, e == 0 ? zero16 : tmp[nt], 0, 0, 0);
-                    prefetch_step(t, bn, st ^ 1, wn);
-                }
-                const float dbl = h2f((uint16_t)((bl & 1) ? (hdw[bl >> 1] >> 16) : (hdw[bl >> 1] & 0xffff)));
-#pragma unroll
-                for (int nt = 0; nt < 2; nt++) {
-                    float4_t_ d8[4]; // (asm reads with immediate offsets: see the legacy branch below)
-                    asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%5+32\n\t"
-                                 "ds_read_b128 %2, %4 offset:%5+64\n\tds_read_b128 %3, %4 offset:%5+96\n\ts_waitcnt lgkmcnt(0)"
-                                 : "=&v"(d8[0]), "=&v"(d8[1]), "=&v"(d8[2]), "=&v"(d8[3])
-                                 : "v"(d8base), "n"(st * 8 * WD_COLS * 4 + bl * WD_COLS * 4 + nt * 128));
-#pragma unroll
-                    for (int r4 = 0; r4 < 4; r4++)
-#pragma unroll
-                        for (int e = 0; e < 4; e++) {
-                            const int r = 4 * r4 + e;
-                            acc[nt][r] = fmaf(tmp[nt][r] * d8[r4][e], dbl, acc[nt][r]);
-                        }
-                }
-                asm volatile("" : "+v"(acc[0]), "+v"(acc[1])); // (pins the scaling here: see the legacy branch)
-            }
         } else if constexpr (CANON16) {
             // w = d * sc_t * q - dmin * mn_t per 16-wide sub-block t (one K-step); operand sc_t * (code - OFF), exact in f16
             constexpr float OFF = TYPE == LFAMD_TYPE_Q3_K ? 4.0f : 0.0f;

@@ -4,4 +4,3 @@
 WIDE_INSTANTIATE(iq4xs, LFAMD_TYPE_IQ4_XS)
 WIDE_INSTANTIATE(f16, LFAMD_TYPE_F16)
 WIDE_INSTANTIATE(bf16, LFAMD_TYPE_BF16)
-WIDE_INSTANTIATE(q80, LFAMD_TYPE_Q8_0)

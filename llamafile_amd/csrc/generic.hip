@@ -385,50 +385,8 @@ extern "C" size_t lfamd_wprep8_bytes(long rows, long cols) {
     return (size_t)((rows + 31) / 32) * (size_t)(cols / 256) * PC8_TILE;
 }
 
-// Q8_0 (resident P80 tiles: 8 rows x 4 blocks, lfamd_device.h) -> PC8-form tiles: q + 128 per byte in the MFMA K-step order,
-// header = the row's eight f16 block scales.  Every image dword is ONE dword of a source block (4 consecutive k).
-__global__ void wprep8_q80_kernel(const uint8_t *__restrict__ p80, long rows, int nb, uint8_t *__restrict__ out, long n_tiles) {
-    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long tile = tid / 2176; // 2048 code dwords + 128 header dwords
-    const int w = (int)(tid % 2176);
-    if (tile >= n_tiles)
-        return;
-    const long rt = tile / nb;
-    const int b = (int)(tile % nb);
-    const int nquads = 2 * nb; // 8 blocks per super-block, 4 per P80 tile
-    uint32_t *dst = (uint32_t *)(out + tile * PC8_TILE);
-    uint32_t v = w < 2048 ? 0x80808080u : 0u; // (rows past the matrix: q = 0)
-    if (w < 2048) {
-        const int g2 = w >> 8, lane = (w >> 2) & 63, e = w & 3;
-        const int i = lane & 31, h = lane >> 5;
-        const long row = rt * 32 + i;
-        if (row < rows) {
-            const int t = 2 * g2 + (e >> 1);
-            const int k = 16 * t + 8 * h + 4 * (e & 1), ib = 8 * b + (k >> 5), j = (k & 31) >> 2;
-            const uint8_t *src = p80 + ((size_t)(row >> 3) * nquads + (ib >> 2)) * P80_TILE;
-            v = *(const uint32_t *)(src + ((row & 7) * 8 + j) * 16 + (ib & 3) * 4) ^ 0x80808080u;
-        }
-    } else {
-        const int sidx = w - 2048, i = sidx >> 2, q = sidx & 3; // header dword q of row i: block scales 2q, 2q + 1
-        const long row = rt * 32 + i;
-        if (row < rows) {
-            const int ib = 8 * b + 2 * q;
-            const uint8_t *src = p80 + ((size_t)(row >> 3) * nquads + (ib >> 2)) * P80_TILE + P80_D;
-            v = *(const uint32_t *)(src + ((row & 7) * 4 + (ib & 3)) * 2); // two consecutive f16 (ib even: same tile)
-        }
-    }
-    dst[w] = v;
-}
-
 extern "C" hipError_t lfamd_launch_wprep8(int type, const void *raw, size_t raw_row_bytes, long rows, long cols, void *out,
                                           hipStream_t s) {
-    if (type == LFAMD_TYPE_Q8_0) { // `raw` is the P80-packed matrix here
-        const int nb = (int)(cols / 256);
-        const long n_tiles = ((rows + 31) / 32) * nb;
-        const long threads = n_tiles * 2176;
-        wprep8_q80_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>((const uint8_t *)raw, rows, nb, (uint8_t *)out, n_tiles);
-        return hipGetLastError();
-    }
     if (type != LFAMD_TYPE_IQ4_XS)
         return hipErrorInvalidValue;
     const int nb = (int)(cols / 256);

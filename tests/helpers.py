@@ -31,9 +31,10 @@ def elem_err(C, G, rtol=1e-3):
     return float(np.mean(d > rtol * np.abs(G) + rtol * rms)), float((d / (np.abs(G) + rms)).max())
 
 
-def q80_batch_tol():
-    """Q8_0 batches (n > 8), default flags: the module's MFMA body on exact integer codes with per-block f32 scaling (2e-6).  Only a
-    process that opted into the vendor GEMM (LFAMD_USE_BLASLT=1: f16(d * q) x f16(d8 * code), one f16 rounding per operand) gets the
-    scaled-operand tolerance of the north star (1e-3, measured 2-4e-4).  The bit-exact kernel is LFAMD_FLAG_Q80_EXACT either way."""
-    import os
-    return 1e-3 if os.environ.get("LFAMD_USE_BLASLT", "0") not in ("", "0") else 2e-6
+def q80_batch_tol(m=128, k=128, n=16, flags=0):
+    """Q8_0 batches (n > 8): what the call runs is asked of the module (lfamd_mul_mat_is_exact).  Default flags, rows of whole
+    128-weight quads: the f16 MFMA body on the resident P80 image (gemm_lf.hip: f16(d * q) x f16(d8 * code), one f16 rounding per
+    operand) — the north star's tolerance for f16 MFMA paths, 1e-3 (measured 2-4e-4); the same for a process that opted into the
+    vendor GEMM (LFAMD_USE_BLASLT=1).  Other row lengths, LFAMD_FLAG_PRECISE / LFAMD_FLAG_Q80_EXACT: the bit-exact kernel."""
+    from llamafile_amd import _hip, ggml_types as T
+    return 2e-6 if _hip.lib().lfamd_mul_mat_is_exact(T.Q8_0, m, k, n, flags) else 1e-3

@@ -100,21 +100,3 @@ def pack_q80(raw, rows, cols):
     out[:, :, :1024] = qs.transpose(0, 2, 1, 4, 3, 5).reshape(nrg, nq, 1024)  # [rg, L, r, j, dd, byte]
     out[:, :, 1024:] = b[..., :2].transpose(0, 2, 1, 3, 4).reshape(nrg, nq, 64)  # [rg, L, r, dd, 2]
     return out.reshape(-1)
-
-
-def pack_q80_pc8(raw, rows, cols):
-    """The second Q8_0 image (rows of whole 256-weight groups): PC8-form tiles of 32 rows x 256 weights, q + 128 per byte in
-    the MFMA K-step order — dword (g2, lane = (i, h), e) of a tile holds weights k = 16 (2 g2 + (e >> 1)) + 8 h + 4 (e & 1) .. + 3
-    of row i — then the row's eight f16 block scales (lfamd_device.h: PC8; generic.hip: wprep8_q80_kernel)."""
-    nblk, nb = cols // 32, cols // 256
-    blk = _pad_rows(raw[:, : nblk * 34].reshape(rows, nblk, 34), 32)
-    nrt = blk.shape[0] // 32
-    q = (blk[..., 2:] ^ 0x80).reshape(nrt, 32, nb, 256)  # [rt, i, b, k]  (a padded row: q = 0 -> 0x80)
-    d = blk[..., :2].reshape(nrt, 32, nb, 16)  # [rt, i, b, 8 scales x 2 bytes]
-    out = np.zeros((nrt, nb, 8704), dtype=np.uint8)
-    # k = 32 g2 + 16 e1 + 8 h + 4 e0 + byte  ->  [g2, e1, h, e0, byte]; image order [g2, h, i, e1, e0, byte]
-    qk = q.reshape(nrt, 32, nb, 8, 2, 2, 2, 4)  # [rt, i, b, g2, e1, h, e0, byte]
-    out[:, :, :8192] = qk.transpose(0, 2, 3, 5, 1, 4, 6, 7).reshape(nrt, nb, 8192)
-    out[:, :, 8192:] = d.transpose(0, 2, 1, 3).reshape(nrt, nb, 512)
-    return out.reshape(-1)
-

@@ -44,11 +44,11 @@ def test_packed_size_is_exactly_gguf_size_for_aligned_shapes():
     lib = _hip.lib()
     for t in (T.Q4_K, T.Q6_K):
         assert lib.lfamd_packed_size(t, 4096, 4096) == 4096 * T.row_size(t, 4096)
-    # Q8_0: the GGUF-sized P80 image, then (rows of whole 256-weight groups) the MFMA batch body's byte image: 8704 B per 32 x 256
-    # (or, where hipBLASLt loads and a GPU gives it a handle, plain f16 rows for the vendor GEMM: 2 bytes per weight)
-    second = 4096 * 4096 * 2 if lib.lfamd_vendor_gemm_available() else 128 * 16 * 8704
-    assert lib.lfamd_packed_size(T.Q8_0, 4096, 4096) == 4096 * T.row_size(T.Q8_0, 4096) + second
-    assert lib.lfamd_packed_size(T.Q8_0, 64, 96) == 64 // 8 * 1088 + (64 * 96 * 2 if lib.lfamd_vendor_gemm_available() else 0)  # 3 blocks -> one P80 tile of four
+    # Q8_0: the GGUF-sized P80 image and nothing else — the vecdot GEMV, the bit-exact batch kernel and the f16 MFMA batch body all
+    # read it (a process that opted into the vendor GEMM, LFAMD_USE_BLASLT=1, also keeps plain f16 rows: 2 more bytes per weight)
+    lt = lib.lfamd_vendor_gemm_available()
+    assert lib.lfamd_packed_size(T.Q8_0, 4096, 4096) == 4096 * T.row_size(T.Q8_0, 4096) + (4096 * 4096 * 2 if lt else 0)
+    assert lib.lfamd_packed_size(T.Q8_0, 64, 96) == 64 // 8 * 1088 + (64 * 96 * 2 if lt else 0)  # 3 blocks -> one P80 tile of four
     assert lib.lfamd_packed_size(T.Q4_K, 33, 256) == 2 * 4608  # rows round up to 32
     # Q2_K / Q3_K: compact resident images (84 / 116 bytes per 256 weights; the canonical image is rebuilt per batch call);
     assert lib.lfamd_packed_size(T.Q2_K, 4096, 4096) == 128 * 16 * 2688 == 4096 * T.row_size(T.Q2_K, 4096)

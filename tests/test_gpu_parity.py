@@ -79,10 +79,10 @@ def test_q8_0_bit_exact(gpu, oracle, variant, precise, shape):
 @pytest.mark.parametrize("shape", [(128, 64, 512), (96, 100, 1024), (33, 9, 256), (256, 512, 2048), (64, 130, 768), (300, 40, 4096)], ids=str)
 @pytest.mark.parametrize("f32in", [False, True], ids=["q80", "f32"])
 def test_q8_0_batches_default(gpu, oracle, shape, f32in):
-    """Q8_0, n > 8, default flags: the module's MFMA body on exact integer codes with per-block f32 scaling, 2e-6 normwise AND
-    element-wise.  A process that opted into the vendor GEMM (LFAMD_USE_BLASLT=1: the subprocess test below) runs hipBLASLt on the
-    resident f16(d * q) image against f16(d8 * code) activations, <= 1e-3 like the scaled K-quant batches.  Neither is bit-exact:
-    LFAMD_FLAG_Q80_EXACT gives the bit-exact kernel (test_q8_0_bit_exact)."""
+    """Q8_0, n > 8, default flags: the module's f16 MFMA body on the resident P80 image (gemm_lf.hip): f16(d * q) x f16(d8 * code),
+    <= 1e-3 normwise like the scaled K-quant batches and no element beyond 3e-3 (|G| + rms); rows that are not whole 128-weight
+    quads run the bit-exact kernel.  A process that opted into the vendor GEMM (LFAMD_USE_BLASLT=1: the subprocess test below) runs
+    hipBLASLt on a second, f16 image — the same arithmetic.  LFAMD_FLAG_Q80_EXACT gives the bit-exact kernel (test_q8_0_bit_exact)."""
     from llamafile_amd import synth
     from helpers import q80_batch_tol
     m, n, k = shape
@@ -94,7 +94,7 @@ def test_q8_0_batches_default(gpu, oracle, shape, f32in):
     W = gpu.upload_weights(T.Q8_0, A, m, k)
     Bd = torch.from_numpy(x).cuda().view(torch.uint8).view(n, k * 4) if f32in else torch.from_numpy(B).cuda()
     C = gpu.mul_mat(W, Bd, T.F32 if f32in else T.Q8_0).cpu().numpy()
-    tol = q80_batch_tol()
+    tol = q80_batch_tol(m, k, n)
     assert rel_err(C, G) <= tol, rel_err(C, G)
     from helpers import elem_err
     frac, worst = elem_err(C, G, rtol=1e-5 if tol < 1e-5 else 3e-3)
@@ -103,7 +103,7 @@ def test_q8_0_batches_default(gpu, oracle, shape, f32in):
 
 def test_q8_0_batches_with_the_vendor_library(gpu):
     """The same cases in a process that opted into hipBLASLt (LFAMD_USE_BLASLT=1): the library GEMM on the f16(d * q) image, <= 1e-3.
-    The default (this process) is the module's own MFMA body on the PC8-form byte image (2e-6)."""
+    The default (this process) is the module's own MFMA body on the resident P80 image (the same arithmetic)."""
     import os
     import subprocess
     import sys
@@ -527,9 +527,9 @@ def test_tuned_types_random_shapes(gpu, oracle, t):
             if t == T.Q8_0:
                 if n <= 8:  # the vecdot
                     assert np.array_equal(C.view(np.uint32), G.view(np.uint32)), (m, n, k)
-                else:  # batches: library GEMM / MFMA body by default (helpers.q80_batch_tol), the bit-exact kernel on request
+                else:  # batches: the f16 MFMA body by default (helpers.q80_batch_tol), the bit-exact kernel on request
                     from helpers import q80_batch_tol
-                    assert rel_err(C, G) <= q80_batch_tol(), (m, n, k)
+                    assert rel_err(C, G) <= q80_batch_tol(m, k, n), (m, n, k)
                     Cx = run_gpu(gpu, t, A, B, bt, m, n, k, flags=gpu.host_variant_flags() | _hip.FLAG_Q80_EXACT)
                     assert np.array_equal(Cx.view(np.uint32), G.view(np.uint32)), (m, n, k)
             else:
@@ -654,7 +654,7 @@ def test_mul_mat_id_other_expert_types(gpu, oracle, t, tokens):
             assert ok == 1
             if t == T.Q8_0:
                 from helpers import q80_batch_tol
-                assert rel_err(res[tok, th], G[0]) <= (q80_batch_tol() if tokens > 1 else 2e-6)
+                assert rel_err(res[tok, th], G[0]) <= (1e-3 if tokens > 1 else 2e-6)
             else:  # (an expert with more than 8 rows runs the MFMA body: IQ4_XS rounds |sc * v| above 2048 to f16 there)
                 tol = 1e-3 if t == T.IQ4_XS and tokens > 1 else TOL.get(t, DEFAULT_TOL)
                 assert rel_err(res[tok, th], G[0]) <= tol, (T.NAMES[t], tok, th)

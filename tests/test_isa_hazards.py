@@ -24,17 +24,18 @@ def test_no_register_is_touched_before_its_load_is_waited_for():
             assert not bad, (f, kernel, bad[:3])
 
 
-KS_TUS = [("gemm_ks.hip", nb) for nb in (1, 5, 8)] + [("gemm_kr.hip", nb) for nb in (1, 3, 4)] + [("gemm_i8.hip", nb) for nb in (1, 2, 4)]
+KS_TUS = [("gemm_ks.hip", nb) for nb in (1, 5, 8)] + [("gemm_kr.hip", nb) for nb in (1, 3, 4)] + [("gemm_i8.hip", nb) for nb in (1, 2, 4)] + \
+         [("gemm_lf.hip", nb) for nb in (1, 3, 4)]
 
 
 @pytest.mark.skipif(not os.path.exists(isa_hazards.HIPCC), reason="needs hipcc")
 def test_k_split_and_row_split_bodies():
-    """gemm_ks / gemm_kr / gemm_i8 keep loads in flight across several periods of a rolled loop whose blocks hipcc lays out out of
+    """gemm_ks / gemm_kr / gemm_i8 / gemm_lf keep loads in flight across several periods of a rolled loop whose blocks hipcc lays out out of
     execution order; the linear walk needs straight-line code, which a fixed trip count (-DKS_CHECK_NB) gives.  The
     VALU-written-SGPR rule is position-local and runs on the shipped (rolled) build as well."""
     def one(arg):
         f, nb = arg
-        return isa_hazards.check_file(os.path.join(ROOT, "llamafile_amd", "csrc", f), (f"-DKS_CHECK_NB={nb}", f"-DI8_CHECK_NB={nb}"))
+        return isa_hazards.check_file(os.path.join(ROOT, "llamafile_amd", "csrc", f), (f"-DKS_CHECK_NB={nb}", f"-DI8_CHECK_NB={nb}", f"-DLF_CHECK_NQ={nb}"))
     with ThreadPoolExecutor(max_workers=3) as ex:
         results = list(ex.map(one, KS_TUS))
     for (f, nb), res in zip(KS_TUS, results):
@@ -43,7 +44,7 @@ def test_k_split_and_row_split_bodies():
             assert not bad, (f, nb, kernel, bad[:3])
     import subprocess
     import tempfile
-    for f in ("gemm_ks.hip", "gemm_kr.hip", "gemm_i8.hip"):
+    for f in ("gemm_ks.hip", "gemm_kr.hip", "gemm_i8.hip", "gemm_lf.hip"):
         with tempfile.NamedTemporaryFile(suffix=".s") as t:
             subprocess.run([isa_hazards.HIPCC, *isa_hazards.FLAGS, os.path.join(ROOT, "llamafile_amd", "csrc", f), "-o", t.name],
                            check=True, stderr=subprocess.DEVNULL)
