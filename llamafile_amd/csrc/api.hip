@@ -82,6 +82,8 @@ size_t lfamd_gemm_i8_workspace(long k, long n);
 hipError_t lfamd_launch_gemm_lf_q80(int count, const void *const *A, const long *m, long k, int Btype, const void *B, size_t b_row_bytes, long n,
                                     float *const *C, const long *ldc, void *ws, hipStream_t s);
 size_t lfamd_gemm_lf_workspace(long k, long n);
+hipError_t lfamd_launch_gemm_lf_float(int Atype, const void *A, size_t a_row_bytes, long m, long k, const void *Xh, long n, long n_pad, float *C,
+                                      long ldc, hipStream_t s);
 hipError_t lfamd_launch_gemm_i8(int count, const void *const *A, const long *m, long k, int Btype, const void *B, size_t b_row_bytes, long n,
                                 float *const *C, const long *ldc, void *ws, const int32_t *src_idx, hipStream_t s);
 }
@@ -599,6 +601,14 @@ int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const v
     own_float_body:
         size_t n_pad = align_up((size_t)n, 128);
         HIPCHK(lfamd_launch_prep_float(Atype, Btype, d_B, b_row_bytes, n, (long)n_pad, k, d_ws, s), "prep_float");
+        // default: the loader-wave body on the RAW rows (gemm_lf.hip); the 128 x 128 wide body on request (testing flags), for
+        // unaligned tensors and for matrices beyond a 32-bit byte offset
+        const size_t a_row = lfamd_row_size(Atype, k);
+        if (!(flags & (LFAMD_FLAG_GEMM_WIDE | LFAMD_FLAG_GEMM_NARROW | LFAMD_FLAG_GEMM_PLAIN)) && ((uintptr_t)d_A & 15) == 0 &&
+            (size_t)m * a_row < ((size_t)1 << 32)) {
+            HIPCHK(lfamd_launch_gemm_lf_float(Atype, d_A, a_row, m, k, d_ws, n, (long)n_pad, d_C, ldc, s), "gemm_lf (float)");
+            return LFAMD_OK;
+        }
         HIPCHK(lfamd_launch_gemm_wide(Atype, d_A, m, k, d_ws, d_ws, d_ws, n, (long)n_pad, d_C, ldc, plain, nullptr, 0, s), "gemm_wide");
         return LFAMD_OK;
     }

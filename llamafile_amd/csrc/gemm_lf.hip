@@ -327,6 +327,187 @@ __global__ __launch_bounds__(256) void prep_lf_kernel(const uint8_t *__restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// F16 / BF16 weights (the float tinyBLAS types, tinyblas_cpu.h:419-613): the same skeleton without a dequantisation — the RAW rows
+// are the MFMA operand as they lie.  Work-group = 128 rows x 64 tokens; a stage = 128 weights per row: 32 KB of weight rows
+// ([row][256 B], 16-byte chunks XOR-swizzled by row on the source address) + 16 KB of activations (the image of
+// lfamd_launch_prep_float: [super-block][token][512 B] in the weight's type), ring of 3; four loader waves (eight with half the
+// pieces each measured 3-9 % slower), four computing waves, fragments one K-step ahead.  f32 accumulate on the matrix cores like the reference's fmaf chains.
+#define LFF_X 32768
+#define LFF_SLOT (32768 + 16384)
+template <bool BF>
+__global__ __launch_bounds__(512) void gemm_lf_float_kernel(const gemm_mats mats, int nq, size_t a_row_bytes, const uint16_t *__restrict__ Xh,
+                                                                      long n, long n_pad, int n_rb, int n_ct) {
+#ifdef LF_CHECK_NQ
+    nq = LF_CHECK_NQ;
+#endif
+    constexpr int NT = 2, RING = 3;
+    constexpr int WP = 8, XP = 4, PIECES = WP + XP; // of a loader and stage
+    __shared__ __attribute__((aligned(16))) uint8_t lds[RING * LFF_SLOT];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    int rb, ct;
+    {
+        const int n_wg = n_rb * n_ct;
+        const int id = (int)blockIdx.x, q8 = n_wg >> 3, r8 = n_wg & 7, xcd = id & 7;
+        const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3);
+        tile_of(L, n_rb, n_ct, rb, ct);
+    }
+    int mj = 0;
+#pragma unroll
+    for (int jj = 1; jj < GEMM_MAX_MATS; jj++)
+        if (jj < mats.count && rb >= mats.rb_end[jj - 1])
+            mj = jj;
+    if (mj > 0)
+        rb -= mats.rb_end[mj - 1];
+    const uint8_t *__restrict__ A = mats.A[mj];
+    float *__restrict__ C = mats.C[mj];
+    const long m = mats.m[mj], ldc = mats.ldc[mj];
+    const long n0 = (long)ct * 64;
+    const uint32_t lds0 = lds_addr(lds);
+
+    if (wave >= 4) {
+        const int lw = wave - 4;
+        // weight pieces WP lw + e: rows 4 p .. 4 p + 3 of the block (rows past the matrix: its last one), lane = (row, slot) <- chunk slot ^ (row & 15)
+        uint32_t voffW[WP], voffX[XP];
+#pragma unroll
+        for (int e = 0; e < WP; e++) {
+            const int rl = 4 * (WP * lw + e) + (lane >> 4);
+            const long row = (long)rb * 128 + rl;
+            voffW[e] = (uint32_t)((size_t)(row < m ? row : m - 1) * a_row_bytes) + (uint32_t)(((lane & 15) ^ (rl & 15)) << 4);
+        }
+#pragma unroll
+        for (int e = 0; e < XP; e++) {
+            const int tk = 4 * (XP * lw + e) + (lane >> 4);
+            voffX[e] = (uint32_t)(tk * 512 + (((lane & 15) ^ (tk & 15)) << 4));
+        }
+        const uint32_t dstW = (uint32_t)(WP * lw * 1024), dstX = (uint32_t)(LFF_X + XP * lw * 1024);
+        const size_t xstride = (size_t)n_pad * 512;
+        const uint8_t *wt_n = uniform_ptr(A);
+        const uint8_t *xh_n = uniform_ptr((const uint8_t *)Xh + (size_t)n0 * 512);
+        asm volatile("s_nop 4" ::"s"(wt_n), "s"(xh_n)); // (VALU-written SGPRs in front of asm loads: tools/isa_hazards.py)
+        int q_n = 0;
+        auto dma_stage = [&](uint32_t slot_base) {
+#pragma unroll
+            for (int e = 0; e < WP; e++)
+                lf_dma16(wt_n, slot_base + dstW + (uint32_t)(e * 1024), voffW[e]);
+#pragma unroll
+            for (int e = 0; e < XP; e++)
+                lf_dma16(xh_n, slot_base + dstX + (uint32_t)(e * 1024), voffX[e]);
+            wt_n += 256;
+            xh_n += (q_n & 1) ? xstride - 256 : 256; // the other half of the token rows / the next super-block
+            q_n++;
+        };
+#pragma unroll
+        for (int st = 0; st < RING - 1; st++)
+            if (st < nq) // (uniform)
+                dma_stage(lds0 + (uint32_t)(st * LFF_SLOT));
+        if (nq >= 2)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory"); // stage 0 has landed for everybody
+        int slot_i = RING - 1;
+        for (int b = 0; b < nq; b++) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // stage b + 1
+            asm volatile("s_barrier" ::: "memory");
+            if (b + RING - 1 < nq)
+                dma_stage(lds0 + (uint32_t)(slot_i * LFF_SLOT));
+            slot_i = slot_i + 1 == RING ? 0 : slot_i + 1;
+        }
+        return;
+    }
+
+    const int rw = wave;
+    const int rt = rb * 4 + rw;
+    uint32_t adW[8], adX[8];
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+        adW[s] = lds0 + (uint32_t)((rw * 32 + i) * 256 + (((2 * s + h) ^ (i & 15)) << 4));
+        adX[s] = lds0 + (uint32_t)(LFF_X + i * 256 + (((2 * s + h) ^ (i & 15)) << 4));
+    }
+    float16_t_ acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int e = 0; e < 16; e++)
+            acc[t][e] = 0.0f;
+    asm volatile("s_barrier" ::: "memory"); // stage 0 has landed for everybody
+    // fragments ONE K-step ahead: in step s the wave issues W(s + 1), X(s + 1) [from the NEXT slot once s = 7: landed, the barrier at
+    // the top of this stage said so] and waits for step s's: younger are exactly this step's three reads
+    u32x4 WF[2], XF[2][NT];
+    lf_dsr16<0>(WF[0], adW[0]);
+    lf_dsr16<0>(XF[0][0], adX[0]);
+    lf_dsr16<8192>(XF[0][1], adX[0]);
+    typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+    int slot_c = 0;
+    for (int b = 0; b < nq; b++) {
+        const uint32_t so = (uint32_t)(slot_c * LFF_SLOT);
+        slot_c = slot_c + 1 == RING ? 0 : slot_c + 1;
+        const uint32_t so_n = (uint32_t)(slot_c * LFF_SLOT);
+        asm volatile("s_barrier" ::: "memory"); // stage b + 1 has landed for everybody
+#define LFF_STEP(S)                                                                                                           \
+    do {                                                                                                                      \
+        lf_dsr16<0>(WF[((S) + 1) & 1], adW[((S) + 1) & 7] + ((S) == 7 ? so_n : so));                                            \
+        lf_dsr16<0>(XF[((S) + 1) & 1][0], adX[((S) + 1) & 7] + ((S) == 7 ? so_n : so));                                         \
+        lf_dsr16<8192>(XF[((S) + 1) & 1][1], adX[((S) + 1) & 7] + ((S) == 7 ? so_n : so));                                      \
+        asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(WF[(S)&1]), "+v"(XF[(S)&1][0]), "+v"(XF[(S)&1][1]));                          \
+        _Pragma("unroll") for (int t = 0; t < NT; t++) {                                                                       \
+            if constexpr (BF)                                                                                                 \
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, XF[(S)&1][t]),                    \
+                                                                 __builtin_bit_cast(bf16x8_t, WF[(S)&1]), acc[t], 0, 0, 0);     \
+            else                                                                                                              \
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, XF[(S)&1][t]),                      \
+                                                                __builtin_bit_cast(half8_t, WF[(S)&1]), acc[t], 0, 0, 0);       \
+        }                                                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                                    \
+    } while (0)
+        LFF_STEP(0);
+        LFF_STEP(1);
+        LFF_STEP(2);
+        LFF_STEP(3);
+        LFF_STEP(4);
+        LFF_STEP(5);
+        LFF_STEP(6);
+        LFF_STEP(7);
+#undef LFF_STEP
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(WF[0]), "+v"(XF[0][0]), "+v"(XF[0][1])); // (reads of a stage that does not exist)
+    if ((long)rt * 32 + i < m) {
+        const long row = (long)rt * 32 + i;
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const long tk = n0 + 32 * t + 8 * (e >> 2) + 4 * h + (e & 3);
+                if (tk < n)
+                    C[tk * ldc + row] = acc[t][e];
+            }
+    }
+}
+
+// A: RAW rows of m x k 16-bit values (row stride a_row_bytes, 16-byte aligned); Xh: the image lfamd_launch_prep_float wrote.
+extern "C" hipError_t lfamd_launch_gemm_lf_float(int Atype, const void *A, size_t a_row_bytes, long m, long k, const void *Xh, long n, long n_pad,
+                                                 float *C, long ldc, hipStream_t s) {
+    if (n <= 0 || m <= 0)
+        return hipSuccess;
+    if (k % 256 || (a_row_bytes & 15) || ((uintptr_t)A & 15) || (Atype != LFAMD_TYPE_F16 && Atype != LFAMD_TYPE_BF16))
+        return hipErrorInvalidValue;
+    gemm_mats mats;
+    const int n_rb = (int)((m + 127) / 128), n_ct = (int)((n + 63) / 64);
+    mats.count = 1;
+    mats.moe_cnt = mats.moe_poff = mats.moe_slot_row = nullptr, mats.expert_bytes = 0, mats.moe_ct_max = 0;
+    for (int q = 0; q < GEMM_MAX_MATS; q++)
+        mats.A[q] = (const uint8_t *)A, mats.C[q] = C, mats.m[q] = q ? 0 : m, mats.ldc[q] = q ? 0 : ldc, mats.rb_end[q] = n_rb;
+    const int nq = (int)(k / 128);
+    const unsigned grid = (unsigned)(n_rb * n_ct);
+    if (Atype == LFAMD_TYPE_BF16)
+        gemm_lf_float_kernel<true><<<grid, 512, 0, s>>>(mats, nq, a_row_bytes, (const uint16_t *)Xh, n, n_pad, n_rb, n_ct);
+    else
+        gemm_lf_float_kernel<false><<<grid, 512, 0, s>>>(mats, nq, a_row_bytes, (const uint16_t *)Xh, n, n_pad, n_rb, n_ct);
+    return hipGetLastError();
+}
+
 // Which launches take this body: Q8_0, rows of whole quads.  NT = 4 (128 x 128 tiles) where those fill the chip, else 128 x 64.
 static int lf_nt(long row_blocks128, long n) {
     static const int force = getenv("LFAMD_LF_NT") ? atoi(getenv("LFAMD_LF_NT")) : 0; // A/B runs
@@ -362,6 +543,8 @@ extern "C" hipError_t lfamd_launch_gemm_lf_q80(int count, const void *const *A, 
     for (int j = 0; j < count; j++) {
         if (m[j] <= 0)
             continue;
+        if ((size_t)((m[j] + 7) / 8) * (size_t)nq * P80_TILE >= ((size_t)1 << 32)) // (the loaders address a tile by a 32-bit byte offset)
+            return hipErrorInvalidValue;
         const int q = mats.count++;
         mats.A[q] = (const uint8_t *)A[j], mats.C[q] = C[j], mats.m[q] = m[j], mats.ldc[q] = ldc[j];
         n_rb += (int)((m[j] + 127) / 128);
