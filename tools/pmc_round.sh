@@ -1,10 +1,10 @@
 #!/bin/bash
 # Round evidence: PMC counters of the north-star kernels (rocprofv3, counters only, one set per run), summarised as JSON:
-#   prefill GEMM 4096x4096x512 and 14336x4096x512 (MFMA utilisation, VALU / LDS activity), decode GEMV 4096x4096 and 4096x14336
+#   prefill GEMM 4096x4096x512 (int8 body) and 14336x4096x512, the Q8_0 batch body, decode GEMV 4096x4096 and 4096x14336 (Q4_K, Q6_K)
 # usage (through gpurun): bash tools/pmc_round.sh  ->  gpurun_out/pmc_round.json
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/pmc_round; rm -rf $OUT; mkdir -p $OUT
-CASES="Q4_K,4096,4096,512;Q4_K,14336,4096,512;Q4_K,4096,4096,1;Q4_K,4096,14336,1"
+CASES="Q4_K,4096,4096,512;Q4_K,14336,4096,512;Q4_K,4096,4096,1;Q4_K,4096,14336,1;Q6_K,4096,14336,1;Q8_0,4096,4096,512"
 n=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_MFMA" "SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU" "GRBM_GUI_ACTIVE FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "SQ_VALU_MFMA_COEXEC_CYCLES SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_SCA"; do
   n=$((n+1))
@@ -23,10 +23,20 @@ for f in glob.glob(f"{out}/s*/**/*counter_collection.csv", recursive=True):
             key = "gemm_ks 128x64 (4096x4096x512)"
         elif "gemm_kr_kernel" in k:
             key = "gemm_kr 256x128 (14336x4096x512)"
+        elif "gemm_i8_kernel" in k:
+            key = "gemm_i8 128x64 (4096x4096x512)"
+        elif "gemm_lf_q80_kernel" in k:
+            key = "gemm_lf_q80 128x64 (Q8_0 4096x4096x512)"
         elif "gemv_kq_kernel" in k and "q4k" in k:
             key = "gemv_q4k " + ("k<=4096" if ", 16, 1," in k or "Li16ELi1E" in k else "deep-k")
+        elif "gemv_kq_kernel" in k and "q6k" in k:
+            key = "gemv_q6k deep-k (4096x14336)"
         elif "prep_scaled" in k:
             key = "prep_scaled"
+        elif "prep_i8" in k:
+            key = "prep_i8"
+        elif "prep_lf" in k:
+            key = "prep_lf"
         else:
             continue
         agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
