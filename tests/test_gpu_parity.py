@@ -76,7 +76,8 @@ def test_q8_0_bit_exact(gpu, oracle, variant, precise, shape):
     assert not np.isnan(C).any()
 
 
-@pytest.mark.parametrize("shape", [(128, 64, 512), (96, 100, 1024), (33, 9, 256), (256, 512, 2048), (64, 130, 768), (300, 40, 4096)], ids=str)
+@pytest.mark.parametrize("shape", [(128, 64, 512), (96, 100, 1024), (33, 9, 256), (256, 512, 2048), (64, 130, 768), (300, 40, 4096), (64, 20, 128),
+                                   (40, 33, 384), (1100, 200, 640), (72, 12, 160)], ids=str)
 @pytest.mark.parametrize("f32in", [False, True], ids=["q80", "f32"])
 def test_q8_0_batches_default(gpu, oracle, shape, f32in):
     """Q8_0, n > 8, default flags: the module's f16 MFMA body on the resident P80 image (gemm_lf.hip): f16(d * q) x f16(d8 * code),
@@ -441,7 +442,7 @@ def test_float_types_vs_oracle(gpu, oracle, ta, tb, shape):
 
 
 @pytest.mark.parametrize("ta,tb", [(T.F16, T.F16), (T.F16, T.F32), (T.BF16, T.BF16), (T.BF16, T.F32)], ids=lambda t: T.NAMES[t])
-@pytest.mark.parametrize("shape", [(128, 64, 512), (45, 100, 1024), (200, 130, 768), (33, 9, 256)], ids=str)
+@pytest.mark.parametrize("shape", [(128, 64, 512), (45, 100, 1024), (200, 130, 768), (33, 9, 256), (300, 70, 2048), (130, 20, 256)], ids=str)
 def test_float_types_mfma_gemm(gpu, oracle, ta, tb, shape):
     """F16 / BF16 weights, batches: MFMA (f16 / bf16 inputs, f32 accumulate) straight on the RAW rows; f32 activations
     are converted like ggml does before it calls sgemm (f16 RNE; bf16 nearest-even with NaN quieting).  Criterion as
