@@ -502,6 +502,25 @@ size_t lfamd_mul_mat_workspace(int Atype, long m, long k, long n) {
     return base > sb ? base : sb;
 }
 
+// The largest workspace any batch of 1 .. n rows can ask for (which body serves a batch depends on n, so the size is not monotonic
+// in n: a K-split launch of few tiles keeps partial tiles a larger batch does not need).  For callers that size ONE buffer for
+// per-group calls of varying n (csrc/moe.hip).  Evaluated at n and at every point where a body's choice or tile count can change.
+size_t lfamd_mul_mat_workspace_upto(int Atype, long m, long k, long n) {
+    size_t best = 0;
+    auto take = [&](long v) {
+        if (v >= 1 && v <= n) {
+            const size_t w = lfamd_mul_mat_workspace(Atype, m, k, v);
+            best = w > best ? w : best;
+        }
+    };
+    take(n);
+    for (long v : {1L, 2L, 3L, 4L, 5L, 6L, 7L, 8L, 9L, 16L, 17L, 32L, 33L})
+        take(v);
+    for (long v = 64; v <= n + 63; v += 64) // token tiles of 64 and 128: the last batch of a tile count and the first of the next
+        take(v), take(v + 1);
+    return best;
+}
+
 int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const void *d_B, size_t b_row_bytes, long n,
                   float *d_C, long ldc, void *d_ws, size_t ws_bytes, unsigned flags, void *stream) {
     (void)hipGetLastError(); // a stale error of an earlier call (e.g. an invalidated stream capture) must not fail this one
@@ -975,8 +994,13 @@ int lfamd_mul_mat_id_multi(int type, int count, const void *const *d_W, long row
     (void)hipGetLastError();
     if (count <= 0)
         return LFAMD_OK;
-    if (!d_W || !d_result)
+    if (!d_W || !d_result || !d_plan || !d_thought)
         return fail(LFAMD_ERR_INVALID, "mul_mat_id_multi: null argument%s", "");
+    for (int j = 0; j < count; j++) // (the fused launch below goes straight into the kernel: a null stack or result would be a device fault)
+        if (!d_W[j] || !d_result[j])
+            return fail(LFAMD_ERR_INVALID, "mul_mat_id_multi: null expert stack or result%s", "");
+    if (tasks <= 0 || tasks > thinkers || !type_known(Btype))
+        return fail(LFAMD_ERR_INVALID, "mul_mat_id_multi: bad shape or activation type%s", "");
     if (count <= 4 && type_known(type) && rows > 0 && cols > 0 && experts > 0 && thinkers > 0 && thinkers <= experts && tokens > 0 &&
         b_row_bytes >= lfamd_row_size(Btype, cols) && lfamd_moe_decode_multi_ok(type, cols, Btype, tasks, tokens, flags)) {
         HIPCHK(lfamd_launch_moe_decode_multi(type, count, d_W, rows, cols, experts, lfamd_packed_size(type, rows, cols), Btype, d_thought,

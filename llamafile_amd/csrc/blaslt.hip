@@ -14,6 +14,7 @@
 #include <hipblaslt/hipblaslt.h>
 
 #include <map>
+#include <set>
 #include <mutex>
 #include <tuple>
 
@@ -185,16 +186,19 @@ size_t lfamd_blaslt_workspace() {
     return LFAMD_BLASLT_WS;
 }
 
-// dtype: LFAMD_TYPE_F16 or LFAMD_TYPE_BF16 (both operands); C f32.  ws may be null (then only algorithms without workspace).
-hipError_t lfamd_blaslt_gemm(int dtype, const void *W, long ldw, const void *X, long ldx, long m, long n, long k, float *C, long ldc,
-                             void *ws, size_t ws_bytes, hipStream_t s) {
-    if (!lfamd_blaslt_ok())
-        return hipErrorNotSupported;
+// One product under the lock: hipErrorNotSupported = the library has nothing for this shape on this device.
+static void destroy_plan(lt_api &a, plan &q) {
+    if (q.desc)
+        a.DescDestroy(q.desc);
+    for (hipblasLtMatrixLayout_t l : {q.a, q.b, q.c})
+        if (l)
+            a.LayoutDestroy(l);
+    q = plan();
+}
+
+static hipError_t blaslt_gemm_one(int dtype, const void *W, long ldw, const void *X, long ldx, long m, long n, long k, float *C, long ldc,
+                                  void *ws, size_t ws_bytes, hipStream_t s) {
     lt_api &a = g_lt;
-    if (ws_bytes > LFAMD_BLASLT_WS)
-        ws_bytes = LFAMD_BLASLT_WS;
-    if (!ws)
-        ws_bytes = 0;
     std::lock_guard<std::mutex> lk(g_mu);
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32)
@@ -204,17 +208,16 @@ hipError_t lfamd_blaslt_gemm(int dtype, const void *W, long ldw, const void *X, 
         return hipErrorNotSupported;
     }
     const hipblasLtHandle_t handle = a.per_device[dev];
-    const auto key = std::make_tuple(dtype, m, n, k, ldw, ldx, ldc * 2 + (ws_bytes ? 1 : 0));
-    if (g_plans.size() >= 1024 && !g_plans.count(key)) { // (a KV cache as the A operand grows by a row per token: bound the cache)
-        for (auto &kv : g_plans) {
-            plan &q = kv.second;
-            if (q.desc)
-                a.DescDestroy(q.desc);
-            for (hipblasLtMatrixLayout_t l : {q.a, q.b, q.c})
-                if (l)
-                    a.LayoutDestroy(l);
-        }
+    // (the device is part of the key: an algorithm is chosen by, and replayed on, one device's handle)
+    const auto key = std::make_tuple(dtype * 32 + dev, m, n, k, ldw, ldx, ldc * 2 + (ws_bytes ? 1 : 0));
+    static std::set<std::tuple<int, long, long, long, long, long, long>> refused; // shapes the heuristic had nothing for (no objects kept)
+    if (refused.count(key))
+        return hipErrorNotSupported;
+    if (g_plans.size() + refused.size() >= 1024 && !g_plans.count(key)) { // (a KV cache as the A operand grows by a row per token: bound the cache)
+        for (auto &kv : g_plans)
+            destroy_plan(a, kv.second);
         g_plans.clear();
+        refused.clear();
     }
     plan &p = g_plans[key];
     if (!p.desc) { // first use of this shape: descriptors + the heuristic's first choice
@@ -243,23 +246,37 @@ hipError_t lfamd_blaslt_gemm(int dtype, const void *W, long ldw, const void *X, 
         }
         if (pref)
             a.PrefDestroy(pref);
-    }
-    if (!p.ok) {
-        if (m <= 8192)
+        if (!p.ok) { // nothing usable: no half-built plan stays behind (its layouts would leak and the shape would stay refused for good)
+            destroy_plan(a, p);
+            g_plans.erase(key);
+            refused.insert(key);
             return hipErrorNotSupported;
-        // a very tall matrix (output.weight) the heuristic has nothing for: the same product in row blocks
-        g_mu.unlock();
-        hipError_t e = hipSuccess;
-        for (long r0 = 0; r0 < m && e == hipSuccess; r0 += 8192) {
-            const long mr = m - r0 < 8192 ? m - r0 : 8192;
-            e = lfamd_blaslt_gemm(dtype, (const uint8_t *)W + (size_t)r0 * ldw * 2, ldw, X, ldx, mr, n, k, C + r0, ldc, ws, ws_bytes, s);
         }
-        g_mu.lock(); // (the guard below releases it)
-        return e;
     }
     const float one = 1.0f, zero = 0.0f;
     const hipblasStatus_t st = a.Matmul(handle, p.desc, &one, W, p.a, X, p.b, &zero, C, p.c, C, p.c, &p.algo, ws, p.ws, s);
     return st == HIPBLAS_STATUS_SUCCESS ? hipSuccess : hipErrorUnknown;
+}
+
+// dtype: LFAMD_TYPE_F16 or LFAMD_TYPE_BF16 (both operands); C f32.  ws may be null (then only algorithms without workspace).
+hipError_t lfamd_blaslt_gemm(int dtype, const void *W, long ldw, const void *X, long ldx, long m, long n, long k, float *C, long ldc,
+                             void *ws, size_t ws_bytes, hipStream_t s) {
+    if (!lfamd_blaslt_ok())
+        return hipErrorNotSupported;
+    if (ws_bytes > LFAMD_BLASLT_WS)
+        ws_bytes = LFAMD_BLASLT_WS;
+    if (!ws)
+        ws_bytes = 0;
+    hipError_t e = blaslt_gemm_one(dtype, W, ldw, X, ldx, m, n, k, C, ldc, ws, ws_bytes, s);
+    if (e != hipErrorNotSupported || m <= 8192)
+        return e;
+    // a very tall matrix (output.weight) the heuristic has nothing for: the same product in row blocks (the lock is taken per block)
+    e = hipSuccess;
+    for (long r0 = 0; r0 < m && e == hipSuccess; r0 += 8192) {
+        const long mr = m - r0 < 8192 ? m - r0 : 8192;
+        e = blaslt_gemm_one(dtype, (const uint8_t *)W + (size_t)r0 * ldw * 2, ldw, X, ldx, mr, n, k, C + r0, ldc, ws, ws_bytes, s);
+    }
+    return e;
 }
 
 hipError_t lfamd_launch_rows_to_16(int dtype, const void *X, size_t x_row_bytes, long n, long k, void *out, hipStream_t s) {

@@ -492,8 +492,13 @@ int lfamd_comm_init_all(lfamd_comm **comms, int ndev, const int *devices, size_t
                 if (hipDeviceCanAccessPeer(&can, devices[i], devices[j]) != hipSuccess || !can) {
                     lfamd_set_error("lfamd_comm_init_all: the devices cannot access each other's memory");
                     e = hipErrorPeerAccessUnsupported;
-                } else if (hipDeviceEnablePeerAccess(devices[j], 0) != hipSuccess) {
-                    (void)hipGetLastError(); // (already enabled)
+                } else {
+                    const hipError_t pe = hipDeviceEnablePeerAccess(devices[j], 0);
+                    (void)hipGetLastError();
+                    if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) { // (anything else would fault later, inside the kernel)
+                        lfamd_set_error("lfamd_comm_init_all: hipDeviceEnablePeerAccess failed");
+                        e = pe;
+                    }
                 }
             }
         c->slot_bytes = (max_message_bytes + 255) / 256 * 256;
@@ -532,6 +537,7 @@ int lfamd_comm_init_all(lfamd_comm **comms, int ndev, const int *devices, size_t
 int lfamd_comm_clear_error(lfamd_comm *c) {
     if (!c || !c->d_state)
         return LFAMD_OK;
+    comm_device on(c); // (a single-process communicator lives on its own device)
     return hipMemset(c->d_state, 0, sizeof(int)) == hipSuccess ? LFAMD_OK : LFAMD_ERR_HIP;
 }
 
@@ -539,6 +545,7 @@ int lfamd_comm_clear_error(lfamd_comm *c) {
 int lfamd_comm_check(lfamd_comm *c) {
     if (!c || !c->d_state)
         return 0;
+    comm_device on(c);
     int v = 0;
     if (hipMemcpy(&v, c->d_state, sizeof v, hipMemcpyDeviceToHost) != hipSuccess)
         return -1;

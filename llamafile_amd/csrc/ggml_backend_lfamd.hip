@@ -917,8 +917,11 @@ GGML_CALL bool ggml_cuda_link(const struct ggml_backend_api *backend_api) {
         for (int j = 0; j < g_ndev; j++)
             if (g_phys[j] != g_phys[i]) {
                 int can = 0;
-                if (hipDeviceCanAccessPeer(&can, g_phys[i], g_phys[j]) == hipSuccess && can)
-                    (void)hipDeviceEnablePeerAccess(g_phys[j], 0);
+                if (hipDeviceCanAccessPeer(&can, g_phys[i], g_phys[j]) == hipSuccess && can) {
+                    const hipError_t pe = hipDeviceEnablePeerAccess(g_phys[j], 0);
+                    if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) // (copies between these two then go through the host)
+                        fprintf(stderr, "ggml_backend_lfamd: peer access %d -> %d not enabled (%s)\n", g_phys[i], g_phys[j], hipGetErrorString(pe));
+                }
                 (void)hipGetLastError(); // (already enabled is not an error worth keeping)
             }
     }

@@ -18,6 +18,7 @@
 extern "C" int lfamd_mul_mat(int, const void *, long, long, int, const void *, size_t, long, float *, long, void *, size_t,
                              unsigned, void *);
 extern "C" size_t lfamd_mul_mat_workspace(int, long, long, long);
+extern "C" size_t lfamd_mul_mat_workspace_upto(int, long, long, long);
 extern "C" hipError_t lfamd_launch_gemv_ids_pair(int, const void *, long, int, const int32_t *, int, int, long, long, int, const void *,
                                                  const void *, size_t, float *, float *, hipStream_t);
 extern "C" hipError_t lfamd_launch_gemv_ids(int, int, const void *const *, long, int, const int32_t *, const int *, long, long, int,
@@ -146,7 +147,7 @@ extern "C" size_t lfamd_moe_workspace(int type, long rows, long cols, int expert
     (void)experts;
     const size_t nr = (size_t)tokens * thinkers;
     const size_t brb = lfamd_row_size(lfamd_vec_dot_type(type), cols);
-    const size_t inner = lfamd_mul_mat_workspace(type, rows, cols, (long)nr); // monotonic in n
+    const size_t inner = lfamd_mul_mat_workspace_upto(type, rows, cols, (long)nr); // (an expert's batch is any n <= nr)
     size_t host_path = align_up_(nr * brb, 256) + align_up_(nr * (size_t)rows * 4, 256) + align_up_(nr * 4, 256) * 2 +
                        align_up_(inner, 256);
     if (moe_grouped_ok(type, tokens, thinkers, experts) && cols % 256 == 0) {

@@ -96,3 +96,23 @@ def test_single_process_communicators_decline_cleanly():
     if not torch.cuda.is_available():
         assert lib.lfamd_comm_init_all(comms, 2, devs, 65536) != 0
         assert all(c is None for c in comms[:2])
+
+
+def test_moe_inner_workspace_covers_every_smaller_batch():
+    """The MUL_MAT_ID host path sizes ONE inner workspace for per-expert calls of any n up to tokens x thinkers (csrc/moe.hip).
+    lfamd_mul_mat_workspace is NOT monotonic in n (a K-split launch of few tiles keeps partial tiles a larger batch does not need),
+    so the bound used there must cover every smaller batch."""
+    import ctypes as C
+    lib = _hip.lib()
+    upto = lib.lfamd_mul_mat_workspace_upto
+    upto.restype, upto.argtypes = C.c_size_t, [C.c_int, C.c_long, C.c_long, C.c_long]
+    for t in (T.Q4_K, T.Q5_K, T.Q6_K, T.Q8_0, T.Q4_0, T.Q5_1, T.Q2_K, T.Q3_K, T.IQ4_XS, T.F16, T.BF16):
+        for m, k in ((4096, 4096), (14336, 4096), (4096, 14336), (1024, 512)):
+            prev = 0
+            for n in list(range(1, 70)) + list(range(70, 1200, 37)):
+                bound = upto(t, m, k, n)
+                assert bound >= prev and bound >= lib.lfamd_mul_mat_workspace(t, m, k, n), (T.NAMES[t], m, k, n)
+                prev = bound
+            for n in (100, 144, 300, 1100):  # every smaller batch, exhaustively, at a few sizes
+                bound = upto(t, m, k, n)
+                assert all(lib.lfamd_mul_mat_workspace(t, m, k, v) <= bound for v in range(1, n + 1)), (T.NAMES[t], m, k, n)
