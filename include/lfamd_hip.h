@@ -50,8 +50,9 @@ enum lfamd_status {
 #define LFAMD_FLAG_GEMM_WIDE 16u    /* testing: force the 128x128 MFMA body */
 #define LFAMD_FLAG_GEMM_PLAIN 32u   /* testing: the 128x128 body without loader waves (Q4_K / Q5_K default to them) */
 #define LFAMD_FLAG_Q80_EXACT 64u    /* Q8_0 batches (n > 8): the BIT-EXACT restatement of tinyBLAS_Q0's 8-lane chains (VALU, ~12x
-                                       slower) instead of the default: the vendor f16 GEMM on the resident f16(d * q) image (<= 1e-3),
-                                       or, where lfamd_vendor_gemm_available() is 0, the MFMA body on exact integer codes (2e-6).  n <= 8 — the Q8_0 vecdot of the north star — is always bit-exact;
+                                       slower) instead of the default: this module's f16 MFMA body on the resident image, f16(d * q) x
+                                       f16(d8 * code), <= 1e-3 (csrc/gemm_lf.hip; rows that are not whole 128-weight groups run the exact
+                                       kernel anyway).  n <= 8 — the Q8_0 vecdot of the north star — is always bit-exact;
                                        LFAMD_FLAG_PRECISE implies this flag. */
 
 int lfamd_abi_version(void);
@@ -82,17 +83,17 @@ int lfamd_stream_sync(void *stream);
  * blocks (include/lfamd_blocks.h).  Packing is a device kernel: raw and packed are device
  * pointers.  lfamd_packed_size is the ONLY source of the packed byte count: Q4_K / Q5_K / Q6_K / Q4_0 images are
  * the GGUF size (+ tile round-up); Q2_K / Q3_K / IQ4_XS are compact images of 84 / 116 / 144 bytes per 256 weights (1.00x /
- * 1.055x / 1.06x the file: DESIGN.md section 10.10; batches expand them per call into the canonical image in the workspace); Q8_0 keeps TWO images —
- * the GGUF-sized one the bit-exact vecdot and exact batch kernels read, and behind it what batches read: f16(d * q) rows for
- * the vendor GEMM (3.1 bytes per weight resident in all) or, where lfamd_vendor_gemm_available() is 0, the MFMA body's byte
- * image (2.1); Q4_1 / Q5_0 / Q5_1 are kept as the canonical image their MFMA and decode kernels read (192 bytes per 256
+ * 1.055x / 1.06x the file: DESIGN.md section 10.10; batches expand them per call into the canonical image in the workspace); Q8_0 is
+ * ONE image of the file's size (1.0625 bytes per weight) that the bit-exact vecdot, the exact batch kernel and the f16 MFMA batch
+ * body all read — only a process that opted into the vendor GEMM (LFAMD_USE_BLASLT=1) keeps f16(d * q) rows behind it (3.1 bytes
+ * per weight in all); Q4_1 / Q5_0 / Q5_1 are kept as the canonical image their MFMA and decode kernels read (192 bytes per 256
  * weights: 1.2 - 1.5x the file); legacy 32-block rows that are not whole
  * 256-weight groups and float tensors stay as GGUF rows. */
 size_t lfamd_packed_size(int type, long rows, long cols);
-/* 1 when batches on PLAIN 16-bit float matrices — F16 / BF16 weight tensors and the resident f16(d * q) image of Q8_0 weights — go
- * through the vendor's GEMM (hipBLASLt, dlopen()ed on first use; LFAMD_NO_BLASLT=1 in the environment keeps it out), 0 when they
- * run on this module's own MFMA bodies.  Decides the second Q8_0 image (f16 rows, 3.1 bytes per weight resident, <= 1e-3 — or
- * the byte image of the exact-code body, 2.1 bytes per weight, 2e-6); constant for the life of the process. */
+/* 1 when the process opted into the vendor's GEMM (LFAMD_USE_BLASLT=1 in the environment before the first call, and hipBLASLt
+ * loads): batches on PLAIN 16-bit float matrices — F16 / BF16 weight tensors and a second, f16(d * q) image of Q8_0 weights — then
+ * go through it (a shape or device it declines falls back to this module's kernels).  0 (the default): every batch runs on this
+ * module's own MFMA bodies and nothing depends on the library.  Constant for the life of the process. */
 int lfamd_vendor_gemm_available(void);
 int lfamd_pack_weights(int type, long rows, long cols, const void *d_raw, size_t raw_row_bytes,
                        void *d_packed, void *stream);
@@ -134,8 +135,8 @@ int lfamd_quantize_rows(int vec_dot_type, const float *d_x, long nrows, long col
  *      with hardware float atomics, which fine-grained or host-mapped memory does not honour
  * Policy (cf. ggml_cuda_mul_mat): one token -> wave-reduction GEMV kernels; 2 .. 8 tokens -> multi-column GEMVs or, where
  * faster, the small-batch MFMA kernel (also 9 .. 32 tokens on deep rows and matrices of at most 8192 rows: csrc/gemm_sb.hip);
- * larger batches -> dequant-to-MFMA GEMM on 128-token tiles; plain F16 / BF16 weights and the f16 image of Q8_0 weights ->
- * the vendor GEMM when lfamd_vendor_gemm_available().  `workspace` must hold lfamd_mul_mat_workspace() bytes (may be NULL
+ * larger batches -> dequant-to-MFMA GEMM on 64- / 128-token tiles (plain F16 / BF16 weights and Q8_0: the vendor GEMM instead when
+ * lfamd_vendor_gemm_available()).  `workspace` must hold lfamd_mul_mat_workspace() bytes (may be NULL
  * if that is 0). */
 size_t lfamd_mul_mat_workspace(int Atype, long m, long k, long n);
 int lfamd_mul_mat(int Atype, const void *d_A_packed, long m, long k, int Btype, const void *d_B,

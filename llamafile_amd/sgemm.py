@@ -63,7 +63,7 @@ class PackedWeights:
     @property
     def nbytes(self) -> int:
         """ALGORITHMIC bytes: the tensor's size in the GGUF file (what one pass over the weights has to read at least).  The
-        resident image may be larger (Q8_0 keeps a second, MFMA-ordered byte image for batches): `resident_bytes`."""
+        resident image may be larger (Q3_K, IQ4_XS, Q4_1 / Q5_0 / Q5_1; Q8_0 only in a process that opted into the vendor GEMM): `resident_bytes`."""
         return self.rows * T.row_size(self.type, self.cols)
 
     @property
