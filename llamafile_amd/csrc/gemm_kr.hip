@@ -109,6 +109,7 @@ __global__ __launch_bounds__(512) void gemm_kr_kernel(const gemm_mats mats, int 
     const long n_row_tiles = (m + 31) / 32;
     const long rt = (long)rb * 8 + wave;
     const bool active = rt < n_row_tiles;
+    const int ntl = MOE ? __builtin_amdgcn_readfirstlane(moe_left >= KR_COLS ? 4 : (moe_left + 31) >> 5) : 4; // live 32-token quarters
     const uint32_t lds0 = lds_addr(lds);
 
     float16_t_ acc[4];
@@ -285,10 +286,17 @@ __global__ __launch_bounds__(512) void gemm_kr_kernel(const gemm_mats mats, int 
             const half2_t S16 = {cp.S16[hs], cp.S16[hs]}, O16 = {cp.O16[hs], cp.O16[hs]};
             return dequant_q4(qw[t8], S, O, S16, O16, magic);
         };
+        // MOE: an expert's LAST token tile usually holds a handful of slots (an expert of a 512-token top-2 batch over 8 experts has
+        // 128 +- 11): its dead 32-token quarters skip their MFMAs (wave-uniform branches; the fragments are still fetched, so every
+        // counted wait stays as it is).  Such a work-group still streams and dequantises its 256 rows, but retires in about half the time.
         auto mfma4 = [&](const half8_t &wf, half8_t(&f)[4]) {
-#pragma unroll
-            for (int nt = 0; nt < 4; nt++)
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, f[nt], acc[nt], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, f[0], acc[0], 0, 0, 0);
+            if (!MOE || ntl > 1)
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, f[1], acc[1], 0, 0, 0);
+            if (!MOE || ntl > 2)
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, f[2], acc[2], 0, 0, 0);
+            if (!MOE || ntl > 3)
+                acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, f[3], acc[3], 0, 0, 0);
         };
         // All four mins MFMAs of a super-block sit between K-steps 3 and 4 of its SECOND stage — the same place in every token
         // tile's sum, so a token's result does not depend on where in the tile it stands (tests permute the tokens and compare
@@ -299,12 +307,15 @@ __global__ __launch_bounds__(512) void gemm_kr_kernel(const gemm_mats mats, int 
             static_assert((set & 1) == 1, "second stage of the super-block");
             asm volatile("" : "+v"(fxm[0]), "+v"(fxm[1]));
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wm[hsel].v, fxm[0], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wm[hsel].v, fxm[1], acc[1], 0, 0, 0);
+            if (!MOE || ntl > 1)
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wm[hsel].v, fxm[1], acc[1], 0, 0, 0);
             asm volatile("" : "+v"(acc[0]), "+v"(acc[1])); // (the operand registers are free again)
             read_mins(setc, std::integral_constant<int, 1>{});
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fxm[0]), "+v"(fxm[1]));
-            acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wm[hsel].v, fxm[0], acc[2], 0, 0, 0);
-            acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wm[hsel].v, fxm[1], acc[3], 0, 0, 0);
+            if (!MOE || ntl > 2)
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wm[hsel].v, fxm[0], acc[2], 0, 0, 0);
+            if (!MOE || ntl > 3)
+                acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wm[hsel].v, fxm[1], acc[3], 0, 0, 0);
         };
         auto wait_frags = [&](half8_t(&f)[4], auto youngerc) {
             asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]) : "n"(decltype(youngerc)::value));
