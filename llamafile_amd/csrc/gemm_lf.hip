@@ -51,11 +51,7 @@ __global__ __launch_bounds__(512) void gemm_lf_q80_kernel(const gemm_mats mats, 
     nq = LF_CHECK_NQ;
 #endif
     constexpr int SLOT = LF_X + NT * 8192;
-#ifdef LF_FORCE_RING3
-    constexpr int RING = 3;
-#else
-    constexpr int RING = NT == 2 ? 4 : 3;
-#endif
+    constexpr int RING = NT == 2 ? 4 : 3; // (a ring of three at 128 x 64 measured 3-11 % slower: profiles/r04_q80_batch_body.txt)
     constexpr int COLS = 32 * NT;
     constexpr int PIECES = 5 + 2 * NT; // of a loader and stage
     __shared__ __attribute__((aligned(16))) uint8_t lds[RING * SLOT];
