@@ -754,6 +754,21 @@ def run():
                                     if _hip.lib().lfamd_mul_mat_is_exact(o.W.type, o.m, o.k, a.prefill, runner.flags) else
                                     "prep_scaled_kernel + gemm_ks_kernel<Q4_K> (128x64 tile, K-split waves, scaled operands)"),
                          "shape": [o.m, o.k, a.prefill], "avg_launch_us": round(gus, 2)}
+        # the same mat-mul when a fused producer (lfamd_rms_norm_quantize / lfamd_swiglu_quantize with LFAMD_TYPE_STAGED_Q8K) has
+        # written the body's staged image: no staging launch in front of it (same bits; tests/test_gpu_norm_quant.py)
+        L_ = _hip.lib()
+        if L_.lfamd_mul_mat_takes_staged(o.W.type, o.m, o.k, a.prefill, runner.flags):
+            image = torch.empty(L_.lfamd_staged_q8k_size(o.k, a.prefill), dtype=torch.uint8, device=dev)
+            _hip.check(L_.lfamd_rms_norm_quantize(C.c_void_p(xin.data_ptr()), xin.stride(0) * 4, C.c_void_p(0), C.c_float(1e-5), a.prefill, o.k,
+                                                  _hip.TYPE_STAGED_Q8K, C.c_void_p(image.data_ptr()), 0, C.c_void_p(0), 0,
+                                                  C.c_void_p(torch.cuda.current_stream().cuda_stream)), "rms_norm_quantize (staged)")
+            sus = sgemm.time_mul_mat(o.W, image, _hip.TYPE_STAGED_Q8K, a.prefill, warmup=5, iters=50)
+            stf = fl / (sus * 1e-6) / 1e12
+            roofline_gemm["from_producer_staged_image"] = {
+                "avg_launch_us": round(sus, 2), "achieved": round(stf, 1), "frac": round(stf / MFMA_F16_PEAK_TFLOPS, 4),
+                "what": "gemm_i8_kernel alone: the activations arrive as the staged image a fused producer wrote "
+                        "(Btype = LFAMD_TYPE_STAGED_Q8K); the headline figure above is the GGML_OP_MUL_MAT boundary (f32 rows in, "
+                        "staging launch included)"}
         # the same measurement on the largest Q4_K shape of the model (256x128 row-split body, gemm_kr.hip)
         big = [q for q in runner.layers[0] if q.W.type == T.Q4_K and q.m >= 8192]
         if big:

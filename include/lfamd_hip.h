@@ -191,6 +191,19 @@ int lfamd_mul_mat_id_multi(int type, int count, const void *const *d_W_packed, l
                            const void *d_thought, size_t b_row_bytes, int tasks, long tokens, const int32_t *d_plan, int thinkers,
                            float *const *d_result, void *d_ws, size_t ws_bytes, unsigned flags, void *stream);
 
+/* The staged activation image of the int8 batch body as an OUTPUT format of the two fused producers below (vec_dot_type =
+ * LFAMD_TYPE_STAGED_Q8K, d_yq = a 16-byte aligned buffer of lfamd_staged_q8k_size(k, nrows) bytes, yq_row_bytes ignored) and as an
+ * INPUT format of lfamd_mul_mat / lfamd_mul_mat_multi (Btype = LFAMD_TYPE_STAGED_Q8K, d_B = that buffer, b_row_bytes ignored):
+ * the Q8_K codes, scales and block sums of quantize_row_q8_K, laid out the way the Q4_K batch body on the int8 matrix cores reads
+ * them — a graph that owns the producer runs NO staging launch in front of the mat-mul (reference: quantize_q8_1 fused in front
+ * of MMQ, ggml-cuda.cu.patch:15259-15292, 17896).  The result has the bits of the same call on the producer's f32 output.
+ * lfamd_mul_mat_takes_staged() says whether a call accepts the image (Q4_K batches that run the int8 body: every matrix of at most
+ * 128 tiles of 128 x 128 whose 128 x 64 tiles fill half the chip — attn_output / ffn_down of the Llama shapes at 512 tokens);
+ * other calls answer LFAMD_ERR_UNSUPPORTED for it and want Q8_K blocks or f32 rows. */
+#define LFAMD_TYPE_STAGED_Q8K 0x1000
+size_t lfamd_staged_q8k_size(long k, long nrows);
+int lfamd_mul_mat_takes_staged(int Atype, long m, long k, long n, unsigned flags);
+
 /* ---- the step in front of the path, fused: RMS-norm x weight -> Q8_K -----------------------------
  * y[i] = (x[i] * 1/sqrtf(mean(x^2) + eps)) * weight[i] per row (ggml_compute_forward_rms_norm_f32 + the MUL node; GPU
  * reference rms_norm_f32, ggml-cuda.cu.patch:14926-14960), written as the reference's Q8_K activation blocks

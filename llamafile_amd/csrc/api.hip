@@ -84,6 +84,8 @@ hipError_t lfamd_launch_gemm_lf_q80(int count, const void *const *A, const long 
 size_t lfamd_gemm_lf_workspace(long k, long n);
 hipError_t lfamd_launch_gemm_lf_float(int Atype, const void *A, size_t a_row_bytes, long m, long k, const void *Xh, long n, long n_pad, float *C,
                                       long ldc, hipStream_t s);
+hipError_t lfamd_launch_gemm_i8_staged(int count, const void *const *A, const long *m, long k, const void *image, long n, float *const *C,
+                                       const long *ldc, hipStream_t s);
 hipError_t lfamd_launch_gemm_i8(int count, const void *const *A, const long *m, long k, int Btype, const void *B, size_t b_row_bytes, long n,
                                 float *const *C, const long *ldc, void *ws, const int32_t *src_idx, hipStream_t s);
 }
@@ -466,6 +468,13 @@ int lfamd_mul_mat_is_exact(int Atype, long m, long k, long n, unsigned flags) {
     return use_gemm_i8(Atype, n, flags, k, (m + 127) / 128) ? 1 : (lfamd_gemm_wide_scaled_ok(Atype, 0) ? 0 : 1);
 }
 
+// Does a call accept the staged image a fused producer wrote (LFAMD_TYPE_STAGED_Q8K)?  Exactly the calls that run the int8 body.
+int lfamd_mul_mat_takes_staged(int Atype, long m, long k, long n, unsigned flags) {
+    if (!type_known(Atype) || m <= 0 || k <= 0 || n <= 0)
+        return 0;
+    return !use_gemm_sb(Atype, n, flags, k, m) && use_gemm(Atype, n, flags, k) && use_gemm_i8(Atype, n, flags, k, (m + 127) / 128) ? 1 : 0;
+}
+
 static size_t mul_mat_workspace_base(int Atype, long m, long k, long n) {
     if (use_gemv(Atype, n, 0, k) && gemv_quantise_separately(Atype, m))
         return align_up((size_t)n * lfamd_row_size(lfamd_vec_dot_type(Atype), k), 256);
@@ -529,6 +538,15 @@ int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const v
         return fail(LFAMD_ERR_UNSUPPORTED, "mul_mat: unsupported weight type%s", "");
     if (m < 0 || n < 0 || k < 0 || ldc < m || k % lfamd_blck_size(Atype))
         return fail(LFAMD_ERR_INVALID, "mul_mat: bad shape%s", "");
+    if (Btype == LFAMD_TYPE_STAGED_Q8K) { // a fused producer wrote the int8 body's staged image: the GEMM alone, no staging launch
+        if (m == 0 || n == 0)
+            return LFAMD_OK;
+        if (!lfamd_mul_mat_takes_staged(Atype, m, k, n, flags))
+            return fail(LFAMD_ERR_UNSUPPORTED, "mul_mat: this call does not run the int8 batch body (lfamd_mul_mat_takes_staged)%s", "");
+        const void *A1 = d_A;
+        HIPCHK(lfamd_launch_gemm_i8_staged(1, &A1, &m, k, d_B, n, &d_C, &ldc, (hipStream_t)stream), "gemm_i8 (staged input)");
+        return LFAMD_OK;
+    }
     const int vdt = lfamd_vec_dot_type(Atype);
     const bool float_a = Atype == LFAMD_TYPE_F32 || Atype == LFAMD_TYPE_F16 || Atype == LFAMD_TYPE_BF16;
     if (float_a) {
@@ -862,6 +880,18 @@ int lfamd_mul_mat_multi(int Atype, int count, const void *const *d_A, const long
     const int plain = (flags & LFAMD_FLAG_GEMM_PLAIN) ? 1 : 0;
     if (count <= 0)
         return LFAMD_OK;
+    if (Btype == LFAMD_TYPE_STAGED_Q8K) { // sibling matrices on one staged image: every one of them must take it
+        if (n == 0)
+            return LFAMD_OK;
+        for (int j = 0; j < count; j++)
+            if (m[j] > 0 && (ldc[j] < m[j] || !lfamd_mul_mat_takes_staged(Atype, m[j], k, n, flags)))
+                return fail(LFAMD_ERR_UNSUPPORTED, "mul_mat_multi: a matrix of this call does not run the int8 batch body%s", "");
+        for (int j0 = 0; j0 < count; j0 += 4) {
+            const int c = count - j0 < 4 ? count - j0 : 4;
+            HIPCHK(lfamd_launch_gemm_i8_staged(c, d_A + j0, m + j0, k, d_B, n, d_C + j0, ldc + j0, (hipStream_t)stream), "gemm_i8 (staged input, multi)");
+        }
+        return LFAMD_OK;
+    }
     if (count == 1 && use_gemm_sb(Atype, n, flags, k, m[0])) // a handful of tokens on one matrix (attn_output, ffn_down): gemm_sb.hip
         return lfamd_mul_mat(Atype, d_A[0], m[0], k, Btype, d_B, b_row_bytes, n, d_C[0], ldc[0], d_ws, ws_bytes, flags, stream);
     // several tokens (6 and more) on sibling matrices that all take the small-batch MFMA kernel (ffn_gate + ffn_up): the activations

@@ -478,23 +478,16 @@ extern "C" size_t lfamd_gemm_i8_workspace(long k, long n) { // Xq, d8T, Xs
     return n_pad * nb * 256 + n_pad * nb * 4 + n_pad * nb * 32;
 }
 
-// B: f32 rows or Q8_K blocks; ws: lfamd_gemm_i8_workspace(k, n) bytes.
-extern "C" hipError_t lfamd_launch_gemm_i8(int count, const void *const *A, const long *m, long k, int Btype, const void *B, size_t b_row_bytes,
-                                           long n, float *const *C, const long *ldc, void *ws, const int32_t *src_idx, hipStream_t s) {
-    if (n <= 0 || count <= 0)
-        return hipSuccess;
-    if (count > GEMM_MAX_MATS || k % 256 || (Btype != LFAMD_TYPE_F32 && Btype != LFAMD_TYPE_Q8_K))
-        return hipErrorInvalidValue;
+// The staged activation image the body reads (what prep_i8_kernel writes, and what the fused producers of norm_quant.hip write
+// directly — lfamd_rms_norm_quantize / lfamd_swiglu_quantize with LFAMD_TYPE_STAGED_Q8K): Xq [nb][n_pad][256], d8T [nb][n_pad] f32,
+// Xs [nb][n_pad][16] f16, n_pad = n rounded up to 128, lfamd_gemm_i8_workspace(k, n) bytes in all.
+static hipError_t gemm_i8_go(int count, const void *const *A, const long *m, long k, const void *image, long n, float *const *C, const long *ldc,
+                             hipStream_t s) {
     const int nb = (int)(k / 256);
     const long n_pad = (n + 127) / 128 * 128;
-    int8_t *Xq = (int8_t *)ws;
-    float *d8T = (float *)((uint8_t *)ws + (size_t)n_pad * nb * 256);
-    _Float16 *Xs = (_Float16 *)((uint8_t *)d8T + (size_t)n_pad * nb * 4);
-    const dim3 pg((unsigned)n_pad, (unsigned)((nb + 15) / 16));
-    if (Btype == LFAMD_TYPE_F32)
-        prep_i8_kernel<true><<<pg, 512, 0, s>>>((const uint8_t *)B, b_row_bytes, n, n_pad, nb, Xq, d8T, Xs, src_idx);
-    else
-        prep_i8_kernel<false><<<pg, 512, 0, s>>>((const uint8_t *)B, b_row_bytes, n, n_pad, nb, Xq, d8T, Xs, src_idx);
+    const int8_t *Xq = (const int8_t *)image;
+    const float *d8T = (const float *)((const uint8_t *)image + (size_t)n_pad * nb * 256);
+    const _Float16 *Xs = (const _Float16 *)((const uint8_t *)d8T + (size_t)n_pad * nb * 4);
     gemm_mats mats;
     int n_rb = 0;
     mats.count = 0;
@@ -514,4 +507,34 @@ extern "C" hipError_t lfamd_launch_gemm_i8(int count, const void *const *A, cons
     const int n_ct = (int)((n + I8_COLS - 1) / I8_COLS);
     gemm_i8_kernel<<<(unsigned)(n_rb * n_ct), 512, 0, s>>>(mats, nb, Xq, d8T, Xs, n, n_pad, n_rb, n_ct);
     return hipGetLastError();
+}
+
+// B: f32 rows or Q8_K blocks; ws: lfamd_gemm_i8_workspace(k, n) bytes.
+extern "C" hipError_t lfamd_launch_gemm_i8(int count, const void *const *A, const long *m, long k, int Btype, const void *B, size_t b_row_bytes,
+                                           long n, float *const *C, const long *ldc, void *ws, const int32_t *src_idx, hipStream_t s) {
+    if (n <= 0 || count <= 0)
+        return hipSuccess;
+    if (count > GEMM_MAX_MATS || k % 256 || (Btype != LFAMD_TYPE_F32 && Btype != LFAMD_TYPE_Q8_K))
+        return hipErrorInvalidValue;
+    const int nb = (int)(k / 256);
+    const long n_pad = (n + 127) / 128 * 128;
+    int8_t *Xq = (int8_t *)ws;
+    float *d8T = (float *)((uint8_t *)ws + (size_t)n_pad * nb * 256);
+    _Float16 *Xs = (_Float16 *)((uint8_t *)d8T + (size_t)n_pad * nb * 4);
+    const dim3 pg((unsigned)n_pad, (unsigned)((nb + 15) / 16));
+    if (Btype == LFAMD_TYPE_F32)
+        prep_i8_kernel<true><<<pg, 512, 0, s>>>((const uint8_t *)B, b_row_bytes, n, n_pad, nb, Xq, d8T, Xs, src_idx);
+    else
+        prep_i8_kernel<false><<<pg, 512, 0, s>>>((const uint8_t *)B, b_row_bytes, n, n_pad, nb, Xq, d8T, Xs, src_idx);
+    return gemm_i8_go(count, A, m, k, ws, n, C, ldc, s);
+}
+
+// The activations arrive as the staged image already (a fused producer wrote it): the GEMM alone, no staging launch.
+extern "C" hipError_t lfamd_launch_gemm_i8_staged(int count, const void *const *A, const long *m, long k, const void *image, long n,
+                                                  float *const *C, const long *ldc, hipStream_t s) {
+    if (n <= 0 || count <= 0)
+        return hipSuccess;
+    if (count > GEMM_MAX_MATS || k % 256 || !image || ((uintptr_t)image & 15))
+        return hipErrorInvalidValue;
+    return gemm_i8_go(count, A, m, k, image, n, C, ldc, s);
 }

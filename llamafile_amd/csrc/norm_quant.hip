@@ -54,13 +54,71 @@ __device__ static inline void put_q8k_block(uint8_t *blk, const float (&y)[4], i
         *(float *)blk = nz ? 1.0f / iscale : 0.0f;
 }
 
+// The same block written straight into the staged image of the int8 batch body (csrc/gemm_i8.hip: Xq [nb][n_pad][256] int8 in the
+// byte order of its unpacked nibbles, d8T [nb][n_pad] f32, Xs [nb][n_pad][16] f16 bsums): the codes, scale and sums are those of
+// put_q8k_block bit for bit — only where they go differs, so the mat-mul behind gives the bits it gives on the f32 row.
+// Lane l holds codes 4 l .. 4 l + 3; group g = l >> 1 of eight codes c0..c7 is stored as (c0,c4,c1,c5 | c2,c6,c3,c7) at
+// (g >> 2) * 32 + (g & 1) * 16 + ((g >> 1) & 1) * 8 of the token's 256 bytes (prep_i8_kernel).
+struct staged_image {
+    int8_t *Xq;
+    float *d8T;
+    _Float16 *Xs;
+    long n_pad;
+};
+__device__ static inline void put_staged_block(const staged_image &im, int b, long tok, const float (&y)[4], int lane) {
+    const float a0 = fabsf(y[0]), a1 = fabsf(y[1]), a2 = fabsf(y[2]), a3 = fabsf(y[3]);
+    const float amax = wave_max_f32(fmaxf(fmaxf(a0, a1), fmaxf(a2, a3)));
+    const bool m0 = a0 == amax, m1 = a1 == amax, m2 = a2 == amax, m3 = a3 == amax;
+    const unsigned long long ball = __builtin_amdgcn_ballot_w64(m0 || m1 || m2 || m3);
+    const float cand = m0 ? y[0] : (m1 ? y[1] : (m2 ? y[2] : y[3]));
+    const bool nz = amax != 0.0f;
+    const float val = nz ? readlane_f32(cand, ball ? __builtin_ctzll(ball) : 0) : 1.0f;
+    const float iscale = -128.0f / val;
+    int q[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const int c = (int)rintf(iscale * y[e]);
+        q[e] = nz ? (c > 127 ? 127 : c) : 0;
+    }
+    const uint32_t mine = (uint32_t)(q[0] & 0xff) | ((uint32_t)(q[1] & 0xff) << 8) | ((uint32_t)(q[2] & 0xff) << 16) | ((uint32_t)(q[3] & 0xff) << 24);
+    const uint32_t other = dpp_u32<DPP_XOR1>(mine);
+    const size_t o = (size_t)b * im.n_pad + tok;
+    if ((lane & 1) == 0) { // mine = c0..c3, other = c4..c7
+        const int g = lane >> 1;
+        const uint32_t w0 = __builtin_amdgcn_perm(other, mine, 0x05010400u); // (c0, c4, c1, c5)
+        const uint32_t w1 = __builtin_amdgcn_perm(other, mine, 0x07030602u); // (c2, c6, c3, c7)
+        *(uint2 *)(im.Xq + o * 256 + (g >> 2) * 32 + (g & 1) * 16 + ((g >> 1) & 1) * 8) = make_uint2(w0, w1);
+    }
+    int bs = q[0] + q[1] + q[2] + q[3];
+    bs += (int)dpp_u32<DPP_XOR1>((uint32_t)bs);
+    bs += (int)dpp_u32<DPP_XOR2>((uint32_t)bs);
+    if ((lane & 3) == 0)
+        im.Xs[o * 16 + (lane >> 2)] = (_Float16)(float)bs;
+    if (lane == 0)
+        im.d8T[o] = nz ? 1.0f / iscale : 0.0f;
+}
+__device__ static inline void put_staged_zero(const staged_image &im, int b, long tok, int lane) { // a padding token of the image
+    const size_t o = (size_t)b * im.n_pad + tok;
+    *(uint32_t *)(im.Xq + o * 256 + 4 * lane) = 0u;
+    if (lane < 8)
+        *(uint32_t *)(im.Xs + o * 16 + 2 * lane) = 0u;
+    if (lane == 0)
+        im.d8T[o] = 0.0f;
+}
+
 // one work-group (4 waves) per row; wave w owns the 256-blocks w, w + 4, ...
+template <bool STAGED>
 __global__ __launch_bounds__(256) void rms_norm_q8k_kernel(const float *__restrict__ x, size_t x_row_bytes, const float *__restrict__ w,
                                                            float eps, long k, uint8_t *__restrict__ yq, size_t yq_row_bytes,
-                                                           float *__restrict__ yf, size_t yf_row_bytes) {
+                                                           float *__restrict__ yf, size_t yf_row_bytes, long nrows, staged_image im) {
     __shared__ double part[4];
     const long row = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (STAGED && row >= nrows) { // (uniform) the image's padding tokens
+        for (int b = wave; b < (int)(k / 256); b += 4)
+            put_staged_zero(im, b, row, lane);
+        return;
+    }
     const float *xr = (const float *)((const uint8_t *)x + row * x_row_bytes);
     const int nb = (int)(k / 256);
     double s = 0.0;
@@ -85,22 +143,31 @@ __global__ __launch_bounds__(256) void rms_norm_q8k_kernel(const float *__restri
             y[0] *= g.x, y[1] *= g.y, y[2] *= g.z, y[3] *= g.w;
         if (frow)
             *(float4 *)(frow + (size_t)b * 256 + 4 * lane) = make_float4(y[0], y[1], y[2], y[3]);
-        if (!qrow)
-            continue;
-        put_q8k_block(qrow + (size_t)b * 292, y, lane);
+        if constexpr (STAGED) {
+            put_staged_block(im, b, row, y, lane);
+        } else {
+            if (!qrow)
+                continue;
+            put_q8k_block(qrow + (size_t)b * 292, y, lane);
+        }
     }
 }
 
 // SwiGLU in front of ffn_down: y = silu(gate) * up with silu(x) = x / (1 + expf(-x)) (silu_f32, ggml-cuda.cu.patch:16172-16179;
 // ggml_silu_f32, ggml-vector.inc:1662-1664) and the MUL node, then Q8_K.  One wave per 256-block.
+template <bool STAGED>
 __global__ __launch_bounds__(256) void swiglu_q8k_kernel(const float *__restrict__ gate, size_t gate_row_bytes, const float *__restrict__ up,
                                                          size_t up_row_bytes, long k, uint8_t *__restrict__ yq, size_t yq_row_bytes,
-                                                         float *__restrict__ yf, size_t yf_row_bytes) {
+                                                         float *__restrict__ yf, size_t yf_row_bytes, long nrows, staged_image im) {
     const long row = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.x * 4 + wave;
     if (b >= (int)(k / 256))
         return;
+    if (STAGED && row >= nrows) { // (uniform) the image's padding tokens
+        put_staged_zero(im, b, row, lane);
+        return;
+    }
     const float4 g = *(const float4 *)((const float *)((const uint8_t *)gate + row * gate_row_bytes) + (size_t)b * 256 + 4 * lane);
     const float4 u = *(const float4 *)((const float *)((const uint8_t *)up + row * up_row_bytes) + (size_t)b * 256 + 4 * lane);
     const float gv[4] = {g.x, g.y, g.z, g.w}, uv[4] = {u.x, u.y, u.z, u.w};
@@ -110,25 +177,52 @@ __global__ __launch_bounds__(256) void swiglu_q8k_kernel(const float *__restrict
         y[e] = (gv[e] / (1.0f + expf(-gv[e]))) * uv[e];
     if (yf)
         *(float4 *)((float *)((uint8_t *)yf + row * yf_row_bytes) + (size_t)b * 256 + 4 * lane) = make_float4(y[0], y[1], y[2], y[3]);
-    if (yq)
+    if constexpr (STAGED)
+        put_staged_block(im, b, row, y, lane);
+    else if (yq)
         put_q8k_block(yq + row * yq_row_bytes + (size_t)b * 292, y, lane);
 }
 
 } // namespace
 
+static staged_image staged_of(void *image, long k, long nrows) {
+    const long nb = k / 256, n_pad = (nrows + 127) / 128 * 128;
+    staged_image im;
+    im.Xq = (int8_t *)image;
+    im.d8T = (float *)((uint8_t *)image + (size_t)n_pad * nb * 256);
+    im.Xs = (_Float16 *)((uint8_t *)im.d8T + (size_t)n_pad * nb * 4);
+    im.n_pad = n_pad;
+    return im;
+}
+
+extern "C" size_t lfamd_staged_q8k_size(long k, long nrows) {
+    if (k <= 0 || k % 256 || nrows < 0)
+        return 0;
+    const size_t n_pad = ((size_t)nrows + 127) / 128 * 128, nb = (size_t)(k / 256);
+    return n_pad * nb * 256 + n_pad * nb * 4 + n_pad * nb * 32; // = lfamd_gemm_i8_workspace(k, nrows)
+}
+
 extern "C" int lfamd_rms_norm_quantize(const float *d_x, size_t x_row_bytes, const float *d_weight, float eps, long nrows, long k,
                                        int vec_dot_type, void *d_yq, size_t yq_row_bytes, float *d_yf, size_t yf_row_bytes,
                                        void *stream) {
-    if (nrows < 0 || k <= 0 || k % 256 || (d_yq && vec_dot_type != LFAMD_TYPE_Q8_K) || (!d_yq && !d_yf) ||
+    const bool staged = d_yq && vec_dot_type == LFAMD_TYPE_STAGED_Q8K; // d_yq = an image of lfamd_staged_q8k_size(k, nrows) bytes
+    if (nrows < 0 || k <= 0 || k % 256 || (d_yq && vec_dot_type != LFAMD_TYPE_Q8_K && !staged) || (!d_yq && !d_yf) ||
         ((uintptr_t)d_x & 15) || (x_row_bytes & 15) || ((uintptr_t)d_weight & 15) || ((uintptr_t)d_yf & 15) || (yf_row_bytes & 15) ||
-        ((uintptr_t)d_yq & 3) || (yq_row_bytes & 3)) {
-        lfamd_set_error("lfamd_rms_norm_quantize: k must be a multiple of 256, output format Q8_K, 16-byte aligned f32 rows");
+        ((uintptr_t)d_yq & (staged ? 15 : 3)) || (!staged && (yq_row_bytes & 3))) {
+        lfamd_set_error("lfamd_rms_norm_quantize: k must be a multiple of 256, output format Q8_K (or the staged image, 16-byte aligned), "
+                        "16-byte aligned f32 rows");
         return LFAMD_ERR_INVALID;
     }
     if (nrows == 0)
         return LFAMD_OK;
-    rms_norm_q8k_kernel<<<(unsigned)nrows, 256, 0, (hipStream_t)stream>>>(d_x, x_row_bytes, d_weight, eps, k, (uint8_t *)d_yq, yq_row_bytes,
-                                                                            d_yf, yf_row_bytes);
+    if (staged) {
+        const staged_image im = staged_of(d_yq, k, nrows);
+        rms_norm_q8k_kernel<true><<<(unsigned)im.n_pad, 256, 0, (hipStream_t)stream>>>(d_x, x_row_bytes, d_weight, eps, k, nullptr, 0, d_yf,
+                                                                                       yf_row_bytes, nrows, im);
+    } else {
+        rms_norm_q8k_kernel<false><<<(unsigned)nrows, 256, 0, (hipStream_t)stream>>>(d_x, x_row_bytes, d_weight, eps, k, (uint8_t *)d_yq,
+                                                                                     yq_row_bytes, d_yf, yf_row_bytes, nrows, staged_image{});
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         lfamd_set_error(hipGetErrorString(e));
@@ -140,17 +234,26 @@ extern "C" int lfamd_rms_norm_quantize(const float *d_x, size_t x_row_bytes, con
 extern "C" int lfamd_swiglu_quantize(const float *d_gate, size_t gate_row_bytes, const float *d_up, size_t up_row_bytes, long nrows,
                                      long k, int vec_dot_type, void *d_yq, size_t yq_row_bytes, float *d_yf, size_t yf_row_bytes,
                                      void *stream) {
-    if (nrows < 0 || k <= 0 || k % 256 || (d_yq && vec_dot_type != LFAMD_TYPE_Q8_K) || (!d_yq && !d_yf) || !d_gate || !d_up ||
+    const bool staged = d_yq && vec_dot_type == LFAMD_TYPE_STAGED_Q8K; // d_yq = an image of lfamd_staged_q8k_size(k, nrows) bytes
+    if (nrows < 0 || k <= 0 || k % 256 || (d_yq && vec_dot_type != LFAMD_TYPE_Q8_K && !staged) || (!d_yq && !d_yf) || !d_gate || !d_up ||
         ((uintptr_t)d_gate & 15) || (gate_row_bytes & 15) || ((uintptr_t)d_up & 15) || (up_row_bytes & 15) || ((uintptr_t)d_yf & 15) ||
-        (yf_row_bytes & 15) || ((uintptr_t)d_yq & 3) || (yq_row_bytes & 3) || nrows > 65535) {
-        lfamd_set_error("lfamd_swiglu_quantize: k must be a multiple of 256, output format Q8_K, 16-byte aligned f32 rows, <= 65535 rows");
+        (yf_row_bytes & 15) || ((uintptr_t)d_yq & (staged ? 15 : 3)) || (!staged && (yq_row_bytes & 3)) || nrows > 65535 - 127) {
+        lfamd_set_error("lfamd_swiglu_quantize: k must be a multiple of 256, output format Q8_K (or the staged image, 16-byte aligned), "
+                        "16-byte aligned f32 rows, <= 65408 rows");
         return LFAMD_ERR_INVALID;
     }
     if (nrows == 0)
         return LFAMD_OK;
-    const dim3 grid((unsigned)((k / 256 + 3) / 4), (unsigned)nrows);
-    swiglu_q8k_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(d_gate, gate_row_bytes, d_up, up_row_bytes, k, (uint8_t *)d_yq, yq_row_bytes,
-                                                            d_yf, yf_row_bytes);
+    if (staged) {
+        const staged_image im = staged_of(d_yq, k, nrows);
+        const dim3 grid((unsigned)((k / 256 + 3) / 4), (unsigned)im.n_pad);
+        swiglu_q8k_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(d_gate, gate_row_bytes, d_up, up_row_bytes, k, nullptr, 0, d_yf,
+                                                                      yf_row_bytes, nrows, im);
+    } else {
+        const dim3 grid((unsigned)((k / 256 + 3) / 4), (unsigned)nrows);
+        swiglu_q8k_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(d_gate, gate_row_bytes, d_up, up_row_bytes, k, (uint8_t *)d_yq,
+                                                                       yq_row_bytes, d_yf, yf_row_bytes, nrows, staged_image{});
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         lfamd_set_error(hipGetErrorString(e));

@@ -88,3 +88,68 @@ def test_swiglu_quantize_feeds_ffn_down(gpu, oracle, n, k):
     z = C.c_void_p(0)
     assert L.lfamd_swiglu_quantize(C.c_void_p(gd.data_ptr()), k * 4, C.c_void_p(ud.data_ptr()), k * 4, n, k - 16, T.Q8_K,
                                    C.c_void_p(yq.data_ptr()), qrow, z, 0, None) == -2
+
+
+def _staged_mul_mat(L, W, image, m, k, n, flags, multi=None):
+    """lfamd_mul_mat (or lfamd_mul_mat_multi over `multi` = a list of PackedWeights) on a staged image; returns the outputs."""
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    if multi is None:
+        out = torch.empty((n, m), dtype=torch.float32, device="cuda")
+        rc = L.lfamd_mul_mat(T.Q4_K, C.c_void_p(W.data.data_ptr()), m, k, _hip.TYPE_STAGED_Q8K, C.c_void_p(image.data_ptr()), 0, n,
+                             C.c_void_p(out.data_ptr()), m, C.c_void_p(0), 0, flags, st)
+        return rc, out
+    cnt = len(multi)
+    outs = [torch.empty((n, w.rows), dtype=torch.float32, device="cuda") for w in multi]
+    A = (C.c_void_p * cnt)(*[w.data.data_ptr() for w in multi])
+    Cs = (C.c_void_p * cnt)(*[o.data_ptr() for o in outs])
+    ms = (C.c_long * cnt)(*[w.rows for w in multi])
+    rc = L.lfamd_mul_mat_multi(T.Q4_K, cnt, A, ms, k, _hip.TYPE_STAGED_Q8K, C.c_void_p(image.data_ptr()), 0, n, Cs, ms, C.c_void_p(0), 0, flags, st)
+    return rc, outs
+
+
+@pytest.mark.parametrize("m,k,n", [(2048, 512, 512), (4096, 256, 300), (4096, 1024, 257)])
+@pytest.mark.parametrize("producer", ["swiglu", "rms_norm"])
+def test_producers_write_the_staged_image_of_the_int8_body(gpu, producer, m, k, n):
+    """lfamd_swiglu_quantize / lfamd_rms_norm_quantize with LFAMD_TYPE_STAGED_Q8K: the Q4_K batch body on the int8 matrix cores
+    reads what the producer wrote — no staging launch in front of the mat-mul — and gives the BITS of the same mat-mul on the
+    producer's f32 output (which quantises and stages in its own launch); ragged token counts (the image's padding tokens are
+    zero), sibling matrices on one image, and LFAMD_ERR_UNSUPPORTED where a call does not run that body."""
+    L = _hip.lib()
+    flags = gpu.host_variant_flags()
+    assert L.lfamd_mul_mat_takes_staged(T.Q4_K, m, k, n, flags) == 1
+    rng = np.random.default_rng(m + k + n)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    size = L.lfamd_staged_q8k_size(k, n)
+    assert size == ((n + 127) // 128 * 128) * (k // 256) * (256 + 4 + 32)
+    image = torch.full((size,), 0x5A, dtype=torch.uint8, device="cuda")
+    yf = torch.zeros((n, k), dtype=torch.float32, device="cuda")
+    if producer == "swiglu":
+        g = torch.from_numpy((rng.standard_normal((n, k)) * 3.0).astype(np.float32)).cuda()
+        u = torch.from_numpy(rng.standard_normal((n, k)).astype(np.float32)).cuda()
+        _hip.check(L.lfamd_swiglu_quantize(C.c_void_p(g.data_ptr()), k * 4, C.c_void_p(u.data_ptr()), k * 4, n, k, _hip.TYPE_STAGED_Q8K,
+                                           C.c_void_p(image.data_ptr()), 0, C.c_void_p(yf.data_ptr()), k * 4, st), "swiglu_quantize (staged)")
+    else:
+        x = torch.from_numpy((rng.standard_normal((n, k)) * rng.uniform(0.1, 30.0, (n, 1))).astype(np.float32)).cuda()
+        w = torch.from_numpy(rng.uniform(0.5, 1.5, k).astype(np.float32)).cuda()
+        _hip.check(L.lfamd_rms_norm_quantize(C.c_void_p(x.data_ptr()), k * 4, C.c_void_p(w.data_ptr()), 1e-5, n, k, _hip.TYPE_STAGED_Q8K,
+                                             C.c_void_p(image.data_ptr()), 0, C.c_void_p(yf.data_ptr()), k * 4, st), "rms_norm_quantize (staged)")
+    W = gpu.upload_weights(T.Q4_K, synth.random_weights_torch(T.Q4_K, m, k, 7).cpu().numpy(), m, k)
+    rc, got = _staged_mul_mat(L, W, image, m, k, n, flags)
+    assert rc == 0, L.lfamd_last_error()
+    want = gpu.mul_mat(W, yf.view(torch.uint8).view(n, k * 4), T.F32, n=n)
+    torch.cuda.synchronize()
+    assert torch.equal(got.view(torch.int32), want.view(torch.int32))
+    # two sibling matrices on the one image
+    W2 = gpu.upload_weights(T.Q4_K, synth.random_weights_torch(T.Q4_K, m, k, 8).cpu().numpy(), m, k)
+    rc, outs = _staged_mul_mat(L, None, image, m, k, n, flags, multi=[W, W2])
+    assert rc == 0, L.lfamd_last_error()
+    assert torch.equal(outs[0].view(torch.int32), want.view(torch.int32))
+    assert torch.equal(outs[1].view(torch.int32), gpu.mul_mat(W2, yf.view(torch.uint8).view(n, k * 4), T.F32, n=n).view(torch.int32))
+    # calls that do not run the int8 body decline the image: a handful of rows, the exact-code flag, another type
+    assert L.lfamd_mul_mat_takes_staged(T.Q4_K, 64, k, n, flags) == 0
+    Ws = gpu.upload_weights(T.Q4_K, synth.random_weights(T.Q4_K, 64, k, 9), 64, k)
+    rc, _ = _staged_mul_mat(L, Ws, image, 64, k, n, flags)
+    assert rc == -1
+    rc, _ = _staged_mul_mat(L, W, image, m, k, n, flags | _hip.FLAG_PRECISE)
+    assert rc == -1
+    assert L.lfamd_mul_mat_takes_staged(T.Q6_K, m, k, n, flags) == 0
