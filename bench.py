@@ -779,6 +779,15 @@ def run():
             roofline_gemm["large_shape"] = {"shape": [q.m, q.k, a.prefill], "avg_launch_us": round(gus, 2),
                                             "achieved": round(tf, 1), "frac": round(tf / MFMA_F16_PEAK_TFLOPS, 4),
                                             "kernel": "prep_scaled_kernel + gemm_kr_kernel<Q4_K> (256x128 tile, row-split waves, scaled operands)"}
+            if L_.lfamd_mul_mat_takes_staged_scaled(q.W.type, q.m, q.k, a.prefill, runner.flags):  # (the same, behind a fused producer)
+                image = torch.empty(L_.lfamd_staged_scaled_size(q.k, a.prefill), dtype=torch.uint8, device=dev)
+                _hip.check(L_.lfamd_rms_norm_quantize(C.c_void_p(xin.data_ptr()), xin.stride(0) * 4, C.c_void_p(0), C.c_float(1e-5), a.prefill, q.k,
+                                                      _hip.TYPE_STAGED_SCALED, C.c_void_p(image.data_ptr()), 0, C.c_void_p(0), 0,
+                                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)), "rms_norm_quantize (scaled image)")
+                sus = sgemm.time_mul_mat(q.W, image, _hip.TYPE_STAGED_SCALED, a.prefill, warmup=3, iters=20)
+                stf = 2.0 * q.m * q.k * a.prefill / (sus * 1e-6) / 1e12
+                roofline_gemm["large_shape"]["from_producer_staged_image"] = {"avg_launch_us": round(sus, 2), "achieved": round(stf, 1),
+                                                                              "frac": round(stf / MFMA_F16_PEAK_TFLOPS, 4)}
 
     # ---- small batches (a few sequences decoding together): one call of 8 tokens on the three decode shapes of a layer
     small_batch = None

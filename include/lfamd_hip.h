@@ -203,6 +203,14 @@ int lfamd_mul_mat_id_multi(int type, int count, const void *const *d_W_packed, l
 #define LFAMD_TYPE_STAGED_Q8K 0x1000
 size_t lfamd_staged_q8k_size(long k, long nrows);
 int lfamd_mul_mat_takes_staged(int Atype, long m, long k, long n, unsigned flags);
+/* The same for the scaled-operand f16 batch bodies (Q4_K / Q5_K / Q6_K batches that do not run the int8 body: attn_q/k/v and
+ * ffn_gate/up behind a norm, Q6_K ffn_down behind the SwiGLU): LFAMD_TYPE_STAGED_SCALED, a buffer of lfamd_staged_scaled_size(k,
+ * nrows) bytes — f16(q8 * d8 * 2^-e(token)) operands with a per-token power-of-two normalisation, the mins operand, 2^e per token;
+ * one image serves sibling matrices of different K-quant types (lfamd_mul_mat_multi / _multi_types).  The bits of the same call on
+ * the producer's f32 output.  lfamd_mul_mat_takes_staged_scaled() says whether a call accepts it. */
+#define LFAMD_TYPE_STAGED_SCALED 0x1001
+size_t lfamd_staged_scaled_size(long k, long nrows);
+int lfamd_mul_mat_takes_staged_scaled(int Atype, long m, long k, long n, unsigned flags);
 
 /* ---- the step in front of the path, fused: RMS-norm x weight -> Q8_K -----------------------------
  * y[i] = (x[i] * 1/sqrtf(mean(x^2) + eps)) * weight[i] per row (ggml_compute_forward_rms_norm_f32 + the MUL node; GPU

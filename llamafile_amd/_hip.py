@@ -21,6 +21,7 @@ FLAG_GEMM_WIDE = 16
 FLAG_GEMM_PLAIN = 32
 FLAG_Q80_EXACT = 64
 TYPE_STAGED_Q8K = 0x1000  # the int8 batch body's staged activation image (lfamd_hip.h)
+TYPE_STAGED_SCALED = 0x1001  # the scaled-operand f16 batch bodies' staged activation image
 
 
 class LfamdError(RuntimeError):
@@ -49,6 +50,8 @@ _SIGS = {
     "lfamd_mul_mat_is_exact": (_i, [_i, _l, _l, _l, _u]),
     "lfamd_mul_mat_takes_staged": (_i, [_i, _l, _l, _l, _u]),
     "lfamd_staged_q8k_size": (_sz, [_l, _l]),
+    "lfamd_mul_mat_takes_staged_scaled": (_i, [_i, _l, _l, _l, _u]),
+    "lfamd_staged_scaled_size": (_sz, [_l, _l]),
     "lfamd_quantize_rows": (_i, [_i, _vp, _l, _l, _sz, _vp, _sz, _vp]),
     "lfamd_mul_mat_workspace": (_sz, [_i, _l, _l, _l]),
     "lfamd_mul_mat": (_i, [_i, _vp, _l, _l, _i, _vp, _sz, _l, _vp, _l, _vp, _sz, _u, _vp]),

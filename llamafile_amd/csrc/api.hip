@@ -468,6 +468,49 @@ int lfamd_mul_mat_is_exact(int Atype, long m, long k, long n, unsigned flags) {
     return use_gemm_i8(Atype, n, flags, k, (m + 127) / 128) ? 1 : (lfamd_gemm_wide_scaled_ok(Atype, 0) ? 0 : 1);
 }
 
+// Which body a K-quant batch runs when it is not the int8 one.  Two families: 128 x 128 / 256 x 128 tiles with K streamed once
+// (gemm_wide.hip and its loader-wave / K-split-wave / row-split descendants) when that grid fills the 256 CUs; the 128 x 64 split-K body
+// (gemm_mfma.hip, exact codes) for smaller grids; LFAMD_GEMM_BODY=narrow|wide forces one.  The wide family runs scaled operands (one
+// f16 rounding each, ~1e-4 relative) unless the caller wants the exact integer-code arithmetic (LFAMD_FLAG_PRECISE); it has a 128 x 64
+// tile for the grids the 128 x 128 tile cannot fill, so it also replaces the split-K body down to LW_MIN_TILES.  Returns `scaled`.
+static bool gemm_body_choice(int Atype, long m, long n, unsigned flags, bool &narrow) {
+    static const char *body = getenv("LFAMD_GEMM_BODY");
+    const int plain = (flags & LFAMD_FLAG_GEMM_PLAIN) ? 1 : 0;
+    const long tiles128 = ((m + 127) / 128) * (long)(align_up((size_t)n, 128) / 128);
+    const int can_scale = !(flags & LFAMD_FLAG_PRECISE) && lfamd_gemm_wide_scaled_ok(Atype, plain);
+    narrow = (flags & LFAMD_FLAG_GEMM_NARROW) ? true
+             : (flags & LFAMD_FLAG_GEMM_WIDE) ? false
+             : body                           ? body[0] == 'n'
+                                              : (tiles128 < 192 && !(can_scale && tiles128 >= LW_MIN_TILES));
+    return !narrow && can_scale;
+}
+
+// Does a call accept the scaled-operand staged image a fused producer wrote (LFAMD_TYPE_STAGED_SCALED)?  The K-quant batches whose
+// body reads it: what lfamd_mul_mat would stage with prep_scaled_kernel itself.
+int lfamd_mul_mat_takes_staged_scaled(int Atype, long m, long k, long n, unsigned flags) {
+    if (!type_known(Atype) || m <= 0 || k <= 0 || n <= 0 || Atype == LFAMD_TYPE_Q4_0)
+        return 0;
+    bool narrow;
+    return !(flags & LFAMD_FLAG_FORCE_GENERIC) && !use_gemm_sb(Atype, n, flags, k, m) && use_gemm(Atype, n, flags, k) &&
+                   !use_gemm_i8(Atype, n, flags, k, (m + 127) / 128) && gemm_body_choice(Atype, m, n, flags, narrow)
+               ? 1
+               : 0;
+}
+
+struct scaled_image_ptrs {
+    const void *Xh, *d8T, *Xm;
+    size_t n_pad;
+};
+static scaled_image_ptrs scaled_image_of(const void *image, long k, long n) {
+    scaled_image_ptrs p;
+    p.n_pad = align_up((size_t)n, 128);
+    const size_t nb = (size_t)(k / 256);
+    p.Xh = image;
+    p.d8T = (const uint8_t *)image + align_up(p.n_pad * (size_t)k * 2, 256);
+    p.Xm = (const uint8_t *)p.d8T + align_up(nb * p.n_pad * 4, 256);
+    return p;
+}
+
 // Does a call accept the staged image a fused producer wrote (LFAMD_TYPE_STAGED_Q8K)?  Exactly the calls that run the int8 body.
 int lfamd_mul_mat_takes_staged(int Atype, long m, long k, long n, unsigned flags) {
     if (!type_known(Atype) || m <= 0 || k <= 0 || n <= 0)
@@ -547,6 +590,19 @@ int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const v
         HIPCHK(lfamd_launch_gemm_i8_staged(1, &A1, &m, k, d_B, n, &d_C, &ldc, (hipStream_t)stream), "gemm_i8 (staged input)");
         return LFAMD_OK;
     }
+    if (Btype == LFAMD_TYPE_STAGED_SCALED) { // a fused producer wrote the scaled-operand bodies' staged image
+        if (m == 0 || n == 0)
+            return LFAMD_OK;
+        if (!lfamd_mul_mat_takes_staged_scaled(Atype, m, k, n, flags) || !d_B || ((uintptr_t)d_B & 15))
+            return fail(LFAMD_ERR_UNSUPPORTED, "mul_mat: this call does not run a scaled-operand batch body (lfamd_mul_mat_takes_staged_scaled)%s", "");
+        const size_t part = lfamd_gemm_lw_ksplit_bytes(m, n); // partial tiles of a K-split launch: the only workspace left
+        if (part && (ws_bytes < part || !d_ws))
+            return fail(LFAMD_ERR_WORKSPACE, "mul_mat: workspace too small%s", "");
+        const scaled_image_ptrs im = scaled_image_of(d_B, k, n);
+        HIPCHK(lfamd_launch_gemm_wide(Atype, d_A, m, k, im.Xh, im.d8T, im.Xm, n, (long)im.n_pad, d_C, ldc, plain | 2, d_ws, ws_bytes, (hipStream_t)stream),
+               "gemm_wide (staged input)");
+        return LFAMD_OK;
+    }
     const int vdt = lfamd_vec_dot_type(Atype);
     const bool float_a = Atype == LFAMD_TYPE_F32 || Atype == LFAMD_TYPE_F16 || Atype == LFAMD_TYPE_BF16;
     if (float_a) {
@@ -590,17 +646,8 @@ int lfamd_mul_mat(int Atype, const void *d_A, long m, long k, int Btype, const v
         }
         // two bodies: 128 x 128 tiles, K streamed once (gemm_wide.hip) when that grid fills the 256 CUs; the
         // 128 x 64 split-K body (gemm_mfma.hip) for smaller grids.  LFAMD_GEMM_BODY=narrow|wide forces one.
-        static const char *body = getenv("LFAMD_GEMM_BODY");
-        const long tiles128 = ((m + 127) / 128) * (long)(n_pad / 128);
-        // Q4_K / Q5_K on the loader-wave body: scaled operands (one f16 rounding each, ~1e-4 relative) unless the
-        // caller wants the exact integer-code arithmetic (LFAMD_FLAG_PRECISE).  That body has a 128 x 64 tile for
-        // the grids the 128 x 128 tile cannot fill, so it also replaces the split-K body down to LW_MIN_TILES.
-        const int can_scale = !precise && lfamd_gemm_wide_scaled_ok(Atype, plain);
-        const bool narrow = (flags & LFAMD_FLAG_GEMM_NARROW) ? true
-                            : (flags & LFAMD_FLAG_GEMM_WIDE) ? false
-                            : body                           ? body[0] == 'n'
-                                                             : (tiles128 < 192 && !(can_scale && tiles128 >= LW_MIN_TILES));
-        const int scaled = !narrow && can_scale;
+        bool narrow;
+        const int scaled = gemm_body_choice(Atype, m, n, flags, narrow) ? 1 : 0;
         if (Btype == LFAMD_TYPE_F32)
             HIPCHK(lfamd_launch_prep_f32(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, scaled ? 2 : 0, nullptr, s), "prep_f32");
         else
@@ -797,9 +844,11 @@ int lfamd_mul_mat_multi_types(int count, const int *Atype, const void *const *d_
     // scaled-operand GEMM of every type reads the SAME staged activations, so they are prepared once; then one launch of
     // the loader-wave body per run of equal types.
     {
+        const bool staged_in = Btype == LFAMD_TYPE_STAGED_SCALED; // (a fused producer wrote the scaled image: d_B, 16-byte aligned)
         bool share = n > 8 && count > 1 && k > 0 && k % 256 == 0 && !(flags & (LFAMD_FLAG_PRECISE | LFAMD_FLAG_FORCE_GENERIC |
                                                                                 LFAMD_FLAG_GEMM_NARROW)) &&
-                     (Btype == LFAMD_TYPE_F32 || Btype == LFAMD_TYPE_Q8_K) && b_row_bytes >= lfamd_row_size(Btype, k);
+                     (staged_in ? d_B && ((uintptr_t)d_B & 15) == 0
+                                : (Btype == LFAMD_TYPE_F32 || Btype == LFAMD_TYPE_Q8_K) && b_row_bytes >= lfamd_row_size(Btype, k));
         const int plain = (flags & LFAMD_FLAG_GEMM_PLAIN) ? 1 : 0;
         bool mixed = false;
         for (int j = 0; j < count && share; j++) {
@@ -810,13 +859,15 @@ int lfamd_mul_mat_multi_types(int count, const int *Atype, const void *const *d_
         }
         const size_t n_pad = align_up((size_t)n, 128), nbk = (size_t)(k / 256);
         const size_t need = align_up(n_pad * (size_t)k * 2, 256) + align_up(nbk * n_pad * 4, 256) + align_up(n_pad * nbk * 32, 256);
-        if (share && mixed && d_ws && ws_bytes >= need) {
+        if (share && mixed && (staged_in || (d_ws && ws_bytes >= need))) {
             hipStream_t s = (hipStream_t)stream;
-            uint8_t *ws = (uint8_t *)d_ws;
+            uint8_t *ws = staged_in ? (uint8_t *)const_cast<void *>(d_B) : (uint8_t *)d_ws; // (the image has the workspace's layout)
             void *Xh = ws;
             void *d8T = ws + align_up(n_pad * (size_t)k * 2, 256);
             void *Xm = (uint8_t *)d8T + align_up(nbk * n_pad * 4, 256);
-            if (Btype == LFAMD_TYPE_F32)
+            if (staged_in)
+                ; // nothing to stage
+            else if (Btype == LFAMD_TYPE_F32)
                 HIPCHK(lfamd_launch_prep_f32(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, 2, nullptr, s), "prep_f32");
             else
                 HIPCHK(lfamd_launch_prep_q8k(d_B, b_row_bytes, n, (long)n_pad, k, Xh, d8T, Xm, 2, nullptr, s), "prep_q8k");
@@ -889,6 +940,32 @@ int lfamd_mul_mat_multi(int Atype, int count, const void *const *d_A, const long
         for (int j0 = 0; j0 < count; j0 += 4) {
             const int c = count - j0 < 4 ? count - j0 : 4;
             HIPCHK(lfamd_launch_gemm_i8_staged(c, d_A + j0, m + j0, k, d_B, n, d_C + j0, ldc + j0, (hipStream_t)stream), "gemm_i8 (staged input, multi)");
+        }
+        return LFAMD_OK;
+    }
+    if (Btype == LFAMD_TYPE_STAGED_SCALED) { // sibling matrices on one scaled image: the route the same call takes on f32 rows
+        if (n == 0)
+            return LFAMD_OK;
+        if (!d_B || ((uintptr_t)d_B & 15))
+            return fail(LFAMD_ERR_INVALID, "mul_mat_multi: the staged image must be 16-byte aligned%s", "");
+        bool fuse = count > 1 && count <= 4 && use_gemm(Atype, n, flags, k) && Atype != LFAMD_TYPE_Q4_0 && k > 0 && k % 256 == 0 &&
+                    !(flags & (LFAMD_FLAG_GEMM_NARROW | LFAMD_FLAG_PRECISE | LFAMD_FLAG_FORCE_GENERIC)) && lfamd_gemm_wide_scaled_ok(Atype, plain);
+        long rbs = 0;
+        for (int j = 0; j < count && fuse; j++) {
+            fuse = m[j] >= 0 && ldc[j] >= m[j];
+            rbs += (m[j] + 127) / 128;
+        }
+        const scaled_image_ptrs im = scaled_image_of(d_B, k, n);
+        if (fuse && (rbs * (long)(im.n_pad / 128) >= 192 || (flags & LFAMD_FLAG_GEMM_WIDE))) { // (one launch over the concatenated row blocks)
+            HIPCHK(lfamd_launch_gemm_wide_multi(Atype, count, d_A, m, k, im.Xh, im.d8T, im.Xm, n, (long)im.n_pad, d_C, ldc, plain | 2, nullptr, 0,
+                                                (hipStream_t)stream),
+                   "gemm_wide_multi (staged input)");
+            return LFAMD_OK;
+        }
+        for (int j = 0; j < count; j++) { // one call per matrix: each must take the image itself
+            const int r = lfamd_mul_mat(Atype, d_A[j], m[j], k, Btype, d_B, 0, n, d_C[j], ldc[j], d_ws, ws_bytes, flags, stream);
+            if (r != LFAMD_OK)
+                return r;
         }
         return LFAMD_OK;
     }

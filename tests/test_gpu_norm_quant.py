@@ -153,3 +153,86 @@ def test_producers_write_the_staged_image_of_the_int8_body(gpu, producer, m, k, 
     rc, _ = _staged_mul_mat(L, W, image, m, k, n, flags | _hip.FLAG_PRECISE)
     assert rc == -1
     assert L.lfamd_mul_mat_takes_staged(T.Q6_K, m, k, n, flags) == 0
+
+
+def _call_multi(L, types, Ws, k, Btype, B, brb, n, flags, ws):
+    cnt = len(Ws)
+    outs = [torch.empty((n, w.rows), dtype=torch.float32, device="cuda") for w in Ws]
+    A = (C.c_void_p * cnt)(*[w.data.data_ptr() for w in Ws])
+    Cs = (C.c_void_p * cnt)(*[o.data_ptr() for o in outs])
+    ms = (C.c_long * cnt)(*[w.rows for w in Ws])
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    if len(set(types)) == 1:
+        rc = L.lfamd_mul_mat_multi(types[0], cnt, A, ms, k, Btype, C.c_void_p(B.data_ptr()), brb, n, Cs, ms, C.c_void_p(ws.data_ptr()), ws.numel(), flags, st)
+    else:
+        ts = (C.c_int * cnt)(*types)
+        rc = L.lfamd_mul_mat_multi_types(cnt, ts, A, ms, k, Btype, C.c_void_p(B.data_ptr()), brb, n, Cs, ms, C.c_void_p(ws.data_ptr()), ws.numel(), flags, st)
+    return rc, outs
+
+
+@pytest.mark.parametrize("k,n", [(512, 512), (1024, 300)])
+@pytest.mark.parametrize("producer", ["rms_norm", "swiglu"])
+def test_producers_write_the_scaled_image_of_the_f16_bodies(gpu, producer, k, n):
+    """LFAMD_TYPE_STAGED_SCALED: the image prep_scaled_kernel would write (f16 operands with a per-token power-of-two normalisation,
+    mins operand, 2^e per token) comes straight from the fused producer; single matrices (Q4_K on a large grid, Q6_K), sibling
+    matrices in one launch (ffn_gate + ffn_up) and siblings of two types (attn_q/k Q4_K + attn_v Q6_K) read it and give the BITS of
+    the same calls on the producer's f32 output."""
+    L = _hip.lib()
+    flags = gpu.host_variant_flags()
+    rng = np.random.default_rng(k * 7 + n)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    size = L.lfamd_staged_scaled_size(k, n)
+    image = torch.full((size,), 0x5A, dtype=torch.uint8, device="cuda")
+    yf = torch.zeros((n, k), dtype=torch.float32, device="cuda")
+    if producer == "swiglu":
+        g = torch.from_numpy((rng.standard_normal((n, k)) * 3.0).astype(np.float32)).cuda()
+        u = torch.from_numpy((rng.standard_normal((n, k)) * rng.uniform(1e-3, 50.0, (n, 1))).astype(np.float32)).cuda()
+        g[1, :] = 0.0  # an all-zero row: no normalisation
+        _hip.check(L.lfamd_swiglu_quantize(C.c_void_p(g.data_ptr()), k * 4, C.c_void_p(u.data_ptr()), k * 4, n, k, _hip.TYPE_STAGED_SCALED,
+                                           C.c_void_p(image.data_ptr()), 0, C.c_void_p(yf.data_ptr()), k * 4, st), "swiglu_quantize (scaled image)")
+    else:
+        x = torch.from_numpy((rng.standard_normal((n, k)) * rng.uniform(1e-3, 50.0, (n, 1))).astype(np.float32)).cuda()
+        w = torch.from_numpy(rng.uniform(0.5, 1.5, k).astype(np.float32)).cuda()
+        _hip.check(L.lfamd_rms_norm_quantize(C.c_void_p(x.data_ptr()), k * 4, C.c_void_p(w.data_ptr()), 1e-5, n, k, _hip.TYPE_STAGED_SCALED,
+                                             C.c_void_p(image.data_ptr()), 0, C.c_void_p(yf.data_ptr()), k * 4, st), "rms_norm_quantize (scaled image)")
+    yb = yf.view(torch.uint8).view(n, k * 4)
+
+    def W(t, m, seed):
+        return gpu.upload_weights(t, synth.random_weights_torch(t, m, k, seed).cpu().numpy(), m, k)
+
+    # single matrices: a Q4_K grid that fills the chip (row-split body), a Q6_K matrix (loader-wave body)
+    for t, m in ((T.Q4_K, 14336), (T.Q6_K, 4096), (T.Q5_K, 1000)):
+        assert L.lfamd_mul_mat_takes_staged_scaled(t, m, k, n, flags) == 1, (T.NAMES[t], m)
+        Wt = W(t, m, 11)
+        ws = torch.empty(max(16, L.lfamd_mul_mat_workspace(t, m, k, n)), dtype=torch.uint8, device="cuda")
+        out = torch.empty((n, m), dtype=torch.float32, device="cuda")
+        rc = L.lfamd_mul_mat(t, C.c_void_p(Wt.data.data_ptr()), m, k, _hip.TYPE_STAGED_SCALED, C.c_void_p(image.data_ptr()), 0, n,
+                             C.c_void_p(out.data_ptr()), m, C.c_void_p(ws.data_ptr()), ws.numel(), flags, st)
+        assert rc == 0, L.lfamd_last_error()
+        want = gpu.mul_mat(Wt, yb, T.F32, n=n)
+        torch.cuda.synchronize()
+        assert torch.equal(out.view(torch.int32), want.view(torch.int32)), (T.NAMES[t], m)
+    # ffn_gate + ffn_up: one launch over both
+    Ws = [W(T.Q4_K, 14336, 21), W(T.Q4_K, 14336, 22)]
+    ws = torch.empty(max(L.lfamd_mul_mat_workspace(T.Q4_K, 14336, k, n), 16), dtype=torch.uint8, device="cuda")
+    rc, got = _call_multi(L, [T.Q4_K, T.Q4_K], Ws, k, _hip.TYPE_STAGED_SCALED, image, 0, n, flags, ws)
+    assert rc == 0, L.lfamd_last_error()
+    rc, want = _call_multi(L, [T.Q4_K, T.Q4_K], Ws, k, T.F32, yb, k * 4, n, flags, ws)
+    assert rc == 0
+    torch.cuda.synchronize()
+    for a, b in zip(got, want):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    # attn_q / attn_k (Q4_K) + attn_v (Q6_K): one staging for both types
+    types = [T.Q4_K, T.Q4_K, T.Q6_K]
+    Ws = [W(T.Q4_K, 4096, 31), W(T.Q4_K, 1024, 32), W(T.Q6_K, 1024, 33)]
+    ws = torch.empty(max(L.lfamd_mul_mat_workspace(T.Q4_K, 4096, k, n), L.lfamd_mul_mat_workspace(T.Q6_K, 1024, k, n), 16), dtype=torch.uint8, device="cuda")
+    rc, got = _call_multi(L, types, Ws, k, _hip.TYPE_STAGED_SCALED, image, 0, n, flags, ws)
+    assert rc == 0, L.lfamd_last_error()
+    rc, want = _call_multi(L, types, Ws, k, T.F32, yb, k * 4, n, flags, ws)
+    assert rc == 0
+    torch.cuda.synchronize()
+    for a, b in zip(got, want):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    # a call that runs another body declines the image
+    assert L.lfamd_mul_mat_takes_staged_scaled(T.Q4_K, 4096, k, n, flags | _hip.FLAG_PRECISE) == 0
+    assert L.lfamd_mul_mat_takes_staged_scaled(T.Q8_0, 4096, k, n, flags) == 0
