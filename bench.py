@@ -201,6 +201,52 @@ class Runner:
         return launches, nops
 
 
+def staged_prefill(runner, n):
+    """The prefill pass when the ops in front of the mat-muls are this module's fused producers (lfamd_rms_norm_quantize /
+    lfamd_swiglu_quantize writing the batch bodies' staged images): every call group that accepts an image gets one (the producers
+    themselves are not part of the pass: they stand where the graph's norm / SwiGLU nodes stand anyway).  Returns a closure that
+    launches the pass and the number of groups per input format."""
+    L, b = runner.L, runner.buf[n]
+    if "calls" not in b:
+        runner.prepare(n)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ws, wsn = C.c_void_p(b["ws"].data_ptr()), b["ws"].numel()
+    images, plan, counts = {}, [], {"scaled": 0, "int8": 0, "f32": 0}
+
+    def image_for(x, k, kind):
+        key = (x.data_ptr(), kind)
+        if key not in images:
+            size = L.lfamd_staged_scaled_size(k, n) if kind == "scaled" else L.lfamd_staged_q8k_size(k, n)
+            img = torch.empty(size, dtype=torch.uint8, device=x.device)
+            _hip.check(L.lfamd_rms_norm_quantize(C.c_void_p(x.data_ptr()), x.stride(0) * 4, C.c_void_p(0), C.c_float(1e-5), n, k,
+                                                 _hip.TYPE_STAGED_SCALED if kind == "scaled" else _hip.TYPE_STAGED_Q8K,
+                                                 C.c_void_p(img.data_ptr()), 0, C.c_void_p(0), 0, stream), "rms_norm_quantize (staged)")
+            images[key] = img
+        return images[key]
+
+    for kind_, g, x, outs, A_arr, C_arr, m_arr, t_arr in b["calls"]:
+        o0 = g[0]
+        choice = ("f32", T.F32, x, x.stride(0) * 4)
+        for kind, bt in (("scaled", _hip.TYPE_STAGED_SCALED), ("int8", _hip.TYPE_STAGED_Q8K)):
+            img = image_for(x, o0.k, kind)
+            rc = L.lfamd_mul_mat_multi_types(len(g), t_arr, A_arr, m_arr, o0.k, bt, C.c_void_p(img.data_ptr()), 0, n, C_arr, m_arr, ws, wsn,
+                                             runner.flags, stream)
+            if rc == 0:
+                choice = (kind, bt, img, 0)
+                break
+        counts[choice[0]] += 1
+        plan.append((len(g), t_arr, A_arr, m_arr, o0.k, choice[1], choice[2], choice[3], C_arr))
+    torch.cuda.synchronize()
+
+    def run():
+        for cnt, t_arr, A_arr, m_arr, k, bt, src, brb, C_arr in plan:
+            rc = L.lfamd_mul_mat_multi_types(cnt, t_arr, A_arr, m_arr, k, bt, C.c_void_p(src.data_ptr()), brb, n, C_arr, m_arr, ws, wsn,
+                                             runner.flags, stream)
+            if rc:
+                _hip.check(rc, "mul_mat_multi_types (staged pass)")
+    return run, counts
+
+
 def cpu_share():
     """Host threads this process may really use: the affinity mask capped by the cgroup CPU quota (the GPU box gives a
     1-GPU job 16 of its 256 hardware threads; 128 OpenMP threads under that quota were throttled at random, which is
@@ -677,6 +723,22 @@ def run():
     finally:
         runner.flags = saved_flags
 
+    # the same prefill pass behind fused producers (eager launches like the leg above; the f32 pass timed the same way beside it)
+    staged_leg = None
+    if world == 1 and not a.gguf:
+        try:
+            run_staged, counts = staged_prefill(runner, a.prefill)
+            run_staged()
+            st_us, _ = time_region(run_staged, 3)
+            runner.run_pass(a.prefill)
+            ef_us, _ = time_region(lambda: runner.run_pass(a.prefill), 3)
+            staged_leg = {"pass_ms": round(st_us / 3e3, 3), "f32_rows_pass_ms_same_timing": round(ef_us / 3e3, 3), "call_groups": counts,
+                          "what": "every call group whose body reads a staged image takes it from lfamd_rms_norm_quantize / "
+                                  "lfamd_swiglu_quantize (LFAMD_TYPE_STAGED_SCALED / _Q8K) instead of staging f32 rows itself; the "
+                                  "producers stand where the graph's norm / SwiGLU nodes stand and are not timed; same bits"}
+        except Exception as e:  # noqa: BLE001
+            print(f"bench.py: staged prefill leg skipped ({type(e).__name__}: {str(e)[:200]})", file=sys.stderr)
+
     # ---- roofline of the dominant kernel: the decode GEMV of the dominant weight type, all its
     # launches of one decode pass, back to back on the stream, timed with HIP events
     dom_type = T.Q8_0 if a.model == "llama3-8b-q8_0" else T.Q4_K
@@ -845,6 +907,7 @@ def run():
             "prefill_pass_ms": round(pf_us / 1e3, 3), "decode_pass_ms": round(dc_us / 1e3, 4),
             "prefill_exact": {"flags": "LFAMD_FLAG_PRECISE", "pass_ms": round(pfx_us / 1e3, 3),
                               "tokens_per_s": round(a.prefill / (pfx_us * 1e-6), 1), "numerics": "2e-6 of the oracle"},
+            **({"prefill_behind_fused_producers": staged_leg} if staged_leg else {}),
             "decode_launches_per_pass": sum(1 for _ in runner.buf[1]["calls"]),
             "decode_GBps_whole_pass": round(runner.weight_bytes() / (dc_us * 1e-6) / 1e9, 1),
         },
