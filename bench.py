@@ -227,7 +227,8 @@ def staged_prefill(runner, n):
     for kind_, g, x, outs, A_arr, C_arr, m_arr, t_arr in b["calls"]:
         o0 = g[0]
         choice = ("f32", T.F32, x, x.stride(0) * 4)
-        for kind, bt in (("scaled", _hip.TYPE_STAGED_SCALED), ("int8", _hip.TYPE_STAGED_Q8K)):
+        # (attn_output's rows come from the attention, which is not one of this module's producers: f32 rows, staged by the call)
+        for kind, bt in (() if o0.spec.input == "attn_out_in" else (("scaled", _hip.TYPE_STAGED_SCALED), ("int8", _hip.TYPE_STAGED_Q8K))):
             img = image_for(x, o0.k, kind)
             rc = L.lfamd_mul_mat_multi_types(len(g), t_arr, A_arr, m_arr, o0.k, bt, C.c_void_p(img.data_ptr()), 0, n, C_arr, m_arr, ws, wsn,
                                              runner.flags, stream)
@@ -239,9 +240,10 @@ def staged_prefill(runner, n):
     torch.cuda.synchronize()
 
     def run():
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         for cnt, t_arr, A_arr, m_arr, k, bt, src, brb, C_arr in plan:
             rc = L.lfamd_mul_mat_multi_types(cnt, t_arr, A_arr, m_arr, k, bt, C.c_void_p(src.data_ptr()), brb, n, C_arr, m_arr, ws, wsn,
-                                             runner.flags, stream)
+                                             runner.flags, st)
             if rc:
                 _hip.check(rc, "mul_mat_multi_types (staged pass)")
     return run, counts
