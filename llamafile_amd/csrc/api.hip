@@ -511,6 +511,17 @@ static scaled_image_ptrs scaled_image_of(const void *image, long k, long n) {
     return p;
 }
 
+// sibling matrices of one type on one launch of the int8 body: their row blocks together must make a grid it takes
+static bool multi_i8_ok(int Atype, int count, const long *m, const long *ldc, long k, long n, unsigned flags) {
+    long rbs = 0;
+    for (int j = 0; j < count; j++) {
+        if (m[j] < 0 || ldc[j] < m[j])
+            return false;
+        rbs += (m[j] + 127) / 128;
+    }
+    return rbs > 0 && use_gemm(Atype, n, flags, k) && use_gemm_i8(Atype, n, flags, k, rbs);
+}
+
 // Does a call accept the staged image a fused producer wrote (LFAMD_TYPE_STAGED_Q8K)?  Exactly the calls that run the int8 body.
 int lfamd_mul_mat_takes_staged(int Atype, long m, long k, long n, unsigned flags) {
     if (!type_known(Atype) || m <= 0 || k <= 0 || n <= 0)
@@ -934,9 +945,10 @@ int lfamd_mul_mat_multi(int Atype, int count, const void *const *d_A, const long
     if (Btype == LFAMD_TYPE_STAGED_Q8K) { // sibling matrices on one staged image: every one of them must take it
         if (n == 0)
             return LFAMD_OK;
-        for (int j = 0; j < count; j++)
-            if (m[j] > 0 && (ldc[j] < m[j] || !lfamd_mul_mat_takes_staged(Atype, m[j], k, n, flags)))
-                return fail(LFAMD_ERR_UNSUPPORTED, "mul_mat_multi: a matrix of this call does not run the int8 batch body%s", "");
+        if (!(count > 1 && count <= 4 && multi_i8_ok(Atype, count, m, ldc, k, n, flags))) // (else: each matrix by itself)
+            for (int j = 0; j < count; j++)
+                if (m[j] > 0 && (ldc[j] < m[j] || !lfamd_mul_mat_takes_staged(Atype, m[j], k, n, flags)))
+                    return fail(LFAMD_ERR_UNSUPPORTED, "mul_mat_multi: a matrix of this call does not run the int8 batch body%s", "");
         for (int j0 = 0; j0 < count; j0 += 4) {
             const int c = count - j0 < 4 ? count - j0 : 4;
             HIPCHK(lfamd_launch_gemm_i8_staged(c, d_A + j0, m + j0, k, d_B, n, d_C + j0, ldc + j0, (hipStream_t)stream), "gemm_i8 (staged input, multi)");
@@ -948,6 +960,8 @@ int lfamd_mul_mat_multi(int Atype, int count, const void *const *d_A, const long
             return LFAMD_OK;
         if (!d_B || ((uintptr_t)d_B & 15))
             return fail(LFAMD_ERR_INVALID, "mul_mat_multi: the staged image must be 16-byte aligned%s", "");
+        if (count > 1 && count <= 4 && multi_i8_ok(Atype, count, m, ldc, k, n, flags))
+            return fail(LFAMD_ERR_UNSUPPORTED, "mul_mat_multi: these matrices run the int8 batch body together (LFAMD_TYPE_STAGED_Q8K)%s", "");
         bool fuse = count > 1 && count <= 4 && use_gemm(Atype, n, flags, k) && Atype != LFAMD_TYPE_Q4_0 && k > 0 && k % 256 == 0 &&
                     !(flags & (LFAMD_FLAG_GEMM_NARROW | LFAMD_FLAG_PRECISE | LFAMD_FLAG_FORCE_GENERIC)) && lfamd_gemm_wide_scaled_ok(Atype, plain);
         long rbs = 0;
@@ -1002,6 +1016,15 @@ int lfamd_mul_mat_multi(int Atype, int count, const void *const *d_A, const long
                                        (flags & LFAMD_FLAG_Q0_VREGS32) ? 1 : 0, (flags & LFAMD_FLAG_PRECISE) ? 1 : 0,
                                        (hipStream_t)stream),
                "gemv_multi");
+        return LFAMD_OK;
+    }
+    // Q4_K siblings whose tiles TOGETHER make a grid the int8 body takes (attn_q/k/v of an all-Q4_K layer: 48 row blocks at 512
+    // tokens): one staging, one launch over the concatenated row blocks, exact integer dots (6144 x 4096 x 512: 47.5 us against 56.8)
+    if (count > 1 && count <= 4 && (Btype == LFAMD_TYPE_F32 || Btype == LFAMD_TYPE_Q8_K) && k > 0 && b_row_bytes >= lfamd_row_size(Btype, k) &&
+        multi_i8_ok(Atype, count, m, ldc, k, n, flags)) {
+        if (ws_bytes < lfamd_gemm_i8_workspace(k, n) || !d_ws)
+            return fail(LFAMD_ERR_WORKSPACE, "mul_mat_multi: workspace too small%s", "");
+        HIPCHK(lfamd_launch_gemm_i8(count, d_A, m, k, Btype, d_B, b_row_bytes, n, d_C, ldc, d_ws, nullptr, (hipStream_t)stream), "gemm_i8 (multi)");
         return LFAMD_OK;
     }
     // K-quant batches: ONE activation prep for all the matrices, and one launch of the 128 x 128 body over their

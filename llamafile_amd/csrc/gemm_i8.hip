@@ -461,16 +461,18 @@ __global__ __launch_bounds__(512) void prep_i8_kernel(const uint8_t *__restrict_
     }
 }
 
-// Which launches take the int8 body (LFAMD_GEMM_NO_I8: the f16 bodies instead — A/B runs).  Q4_K, and a grid the 128 x 128 tile
-// cannot fill (at most 128 of them — where the f16 path runs its own 128 x 64 tile, gemm_ks.hip) but whose 128 x 64 tiles fill at
-// least half the CUs (smaller grids keep the K-split launches of gemm_lw.hip).  Measured, prep + GEMM per call at 512 tokens:
-// 4096 x 4096 32.5 us (f16 scaled operands: 32.9), 4096 x 14336 89.6 (88.3): the same time for exact integer dots; on grids that
-// fill the chip with 256 x 128 tiles the f16 body is faster (14336 x 4096: 75 us against 99) and stays.
+// Which launches take the int8 body (LFAMD_GEMM_NO_I8: the f16 bodies instead — A/B runs).  Q4_K, at most TWO rounds of its 128 x 64
+// tiles (<= 256 tiles of 128 x 128) and at least half a round (smaller grids keep the K-split launches of gemm_lw.hip).  Measured,
+// prep + GEMM per call at 512 tokens against the scaled-operand f16 bodies (profiles/r04_i8_grid_limit.txt): 4096 x 4096 30.5 us
+// (32.9), 4096 x 14336 83 (88), 6144 x 4096 47.5 (56.8), 8192 x 4096 56.6 (61.9), 8192 x 8192 92.8 (106.2), 4096 x 4096 x 1024 51.3
+// (60.4), 6144 x 4096 x 300 29.0 (54.9) — faster AND exact; beyond two rounds the 256 x 128 f16 tile wins (9216 x 4096: 70.9 against
+// 65.0, 14336 x 4096: 97 against 75-80) and stays.  row_blocks128: of all the matrices of the launch together.
 extern "C" int lfamd_gemm_i8_ok(int Atype, long row_blocks128, long n) {
     static const bool off = getenv("LFAMD_GEMM_NO_I8") != nullptr;
     if (off || Atype != LFAMD_TYPE_Q4_K || n < 1)
         return 0;
-    return row_blocks128 * ((n + I8_COLS - 1) / I8_COLS) >= 128 && row_blocks128 * ((n + 127) / 128) <= 128;
+    static const long max128 = getenv("LFAMD_I8_MAX_TILES128") ? atol(getenv("LFAMD_I8_MAX_TILES128")) : 256; // A/B runs
+    return row_blocks128 * ((n + I8_COLS - 1) / I8_COLS) >= 128 && row_blocks128 * ((n + 127) / 128) <= max128;
 }
 
 extern "C" size_t lfamd_gemm_i8_workspace(long k, long n) { // Xq, d8T, Xs

@@ -12,8 +12,9 @@ from helpers import elem_err, rel_err
 
 pytestmark = pytest.mark.gpu
 
-# (m, n, k): at least 128 tiles of 128 x 64 and at most 128 of 128 x 128, so the default route is the int8 body
-SHAPES = [(2048, 512, 512), (4096, 256, 256), (1000, 1100, 768), (16384 - 32 + 5, 70, 256), (4096 + 5, 257, 1024)]
+# (m, n, k): at least 128 tiles of 128 x 64 and at most 256 of 128 x 128 (two rounds of its tiles), so the default route is the int8 body
+SHAPES = [(2048, 512, 512), (4096, 256, 256), (1000, 1100, 768), (16384 - 32 + 5, 70, 256), (4096 + 5, 257, 1024), (6144 + 9, 512, 512),
+          (8192, 500, 256)]
 
 
 def _oracle_rows(oracle, A, B, m, n, k, rows, cols):
@@ -69,3 +70,27 @@ def test_int8_body_respects_ldc_and_leaves_the_rest_alone(gpu):
     assert rc == 0, L.lfamd_last_error()
     torch.cuda.synchronize()
     assert torch.equal(out[:, :m], ref) and bool((out[:, m:] == 7.0).all())
+
+
+def test_int8_body_serves_sibling_matrices_in_one_launch(gpu, oracle):
+    """lfamd_mul_mat_multi on Q4_K siblings whose row blocks TOGETHER make a grid the int8 body takes (attn_q/k/v of an all-Q4_K
+    layer): one staging, one launch, exact integer dots — every matrix 2e-6 of the oracle on a sample, although the small ones alone
+    would run a scaled-operand body."""
+    k, n = 512, 512
+    ms = [4096, 1024, 1024]
+    L = _hip.lib()
+    assert L.lfamd_mul_mat_is_exact(T.Q4_K, 1024, k, n, gpu.host_variant_flags()) == 0  # (alone: the loader-wave body)
+    As = [synth.random_weights(T.Q4_K, m, k, 61 + i) for i, m in enumerate(ms)]
+    Ws = [gpu.upload_weights(T.Q4_K, A, m, k) for A, m in zip(As, ms)]
+    x = synth.random_activations(n, k, 62)
+    B = synth.quantize_activations(T.Q8_K, x)
+    fused = gpu.mul_mat_multi(Ws, torch.from_numpy(x).cuda().view(torch.uint8).view(n, k * 4), T.F32, n=n)
+    rng = np.random.default_rng(6)
+    for A, m, f in zip(As, ms, fused):
+        rows = np.unique(np.concatenate([np.arange(0, 24), np.arange(m - 24, m), rng.integers(0, m, 32)]))
+        cols = np.unique(np.concatenate([np.arange(0, 8), np.arange(n - 8, n), rng.integers(0, n, 16)]))
+        G = _oracle_rows(oracle, A, B, m, n, k, rows, cols)
+        Cs = f.cpu().numpy()[np.ix_(cols, rows)]
+        assert rel_err(Cs, G) <= 2e-6, (m, rel_err(Cs, G))
+        frac, worst = elem_err(Cs, G, rtol=1e-5)
+        assert frac == 0.0, (m, frac, worst)
