@@ -197,9 +197,10 @@ int lfamd_mul_mat_id_multi(int type, int count, const void *const *d_W_packed, l
  * the Q8_K codes, scales and block sums of quantize_row_q8_K, laid out the way the Q4_K batch body on the int8 matrix cores reads
  * them — a graph that owns the producer runs NO staging launch in front of the mat-mul (reference: quantize_q8_1 fused in front
  * of MMQ, ggml-cuda.cu.patch:15259-15292, 17896).  The result has the bits of the same call on the producer's f32 output.
- * lfamd_mul_mat_takes_staged() says whether a call accepts the image (Q4_K batches that run the int8 body: every matrix of at most
- * 128 tiles of 128 x 128 whose 128 x 64 tiles fill half the chip — attn_output / ffn_down of the Llama shapes at 512 tokens);
- * other calls answer LFAMD_ERR_UNSUPPORTED for it and want Q8_K blocks or f32 rows. */
+ * lfamd_mul_mat_takes_staged() says whether a call accepts the image (Q4_K batches that run the int8 body: grids of at most 256
+ * tiles of 128 x 128 whose 128 x 64 tiles fill half the chip — attn_q / attn_output / ffn_down of the Llama shapes at 512 tokens;
+ * sibling matrices of one lfamd_mul_mat_multi call count together); other calls answer LFAMD_ERR_UNSUPPORTED for it and want Q8_K
+ * blocks or f32 rows. */
 #define LFAMD_TYPE_STAGED_Q8K 0x1000
 size_t lfamd_staged_q8k_size(long k, long nrows);
 int lfamd_mul_mat_takes_staged(int Atype, long m, long k, long n, unsigned flags);
