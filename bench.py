@@ -898,7 +898,7 @@ def run():
             "workload": f"{a.model} mat-muls ({sum(len(l) for l in layers)} GGML_OP_MUL_MAT per pass, f32 activations in, quantisation fused, sibling ops fused at decode" + "), "
                         f"{a.prefill}-token prefill + {a.decode} decode, matmul-only",
             "numerics": "decode: exact int8 x int4/int6 block dot products with f32 scales (v_dot4_i32_i8); prefill: Q4_K on grids of up "
-                        "to 128 tiles of 128x128 (attn_q, attn_output, ffn_down) on the int8 matrix cores, exact integer sub-block dots "
+                        "to 256 tiles of 128x128 (attn_q and its Q4_K siblings, attn_output, ffn_down) on the int8 matrix cores, exact integer sub-block dots "
                         "(2e-6 of the oracle); larger Q4_K grids and Q6_K on f16 MFMA with scaled operands f16(d*sc*q) x f16(d8*code) "
                         "(<= 1e-3 relative, measured ~3e-4; exact integer codes with LFAMD_FLAG_PRECISE)",
             "model": a.model, "prefill_tokens": a.prefill, "decode_tokens": a.decode,

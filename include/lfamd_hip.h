@@ -113,7 +113,7 @@ int lfamd_scaled_gemm_ok(int type, long rows, long cols, const void *d_packed, v
 /* Which arithmetic a lfamd_mul_mat call with these arguments runs: 1 = exact integer block dot products with f32 scales (the
  * reference's CPU arithmetic, iqk_mul_mat.inc:601-643; within 2e-6 of it: only the order of the f32 sums differs) — every call
  * of up to 32 columns, LFAMD_FLAG_PRECISE, and since round 4 the Q4_K batches that run on the int8 matrix cores
- * (llamafile_amd/csrc/gemm_i8.hip: grids of at most 128 tiles of 128 x 128 that still fill half the chip — attn_q, attn_output,
+ * (llamafile_amd/csrc/gemm_i8.hip: grids of at most 256 tiles of 128 x 128 that still fill half the chip — attn_q, attn_output,
  * ffn_down of an 8B model at 512 tokens); 0 = scaled operands on the f16 matrix cores (one f16 rounding per operand, <= 1e-3,
  * measured ~3e-4; Q6_K's exact body also rounds sc * (q - 32) above 2048).  No device call is made. */
 int lfamd_mul_mat_is_exact(int Atype, long m, long k, long n, unsigned flags);
