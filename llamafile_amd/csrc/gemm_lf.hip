@@ -508,12 +508,14 @@ extern "C" hipError_t lfamd_launch_gemm_lf_float(int Atype, const void *A, size_
     return hipGetLastError();
 }
 
-// Which launches take this body: Q8_0, rows of whole quads.  NT = 4 (128 x 128 tiles) where those fill the chip, else 128 x 64.
+// Which launches take this body: Q8_0, rows of whole quads.  Tile width: see lf_nt.
 static int lf_nt(long row_blocks128, long n) {
     static const int force = getenv("LFAMD_LF_NT") ? atoi(getenv("LFAMD_LF_NT")) : 0; // A/B runs
     if (force == 2 || force == 4)
         return force;
-    return row_blocks128 * ((n + 127) / 128) >= 160 ? 4 : 2; // (6144 x 4096 x 512: 192 tiles of 128 x 128 44 us, 384 of 128 x 64 54)
+    // 128 x 64 tiles while they fit ONE round of the 256 CUs, else 128 x 128 (4096 x 4096 x 512: 37.2 against 43.3 us; 4608 x 4096: 55.3
+    // against 44.8; 6144 x 4096: 53.7 against 44.1; 14336 x 4096: 116 against 97) — the two give the same bits
+    return row_blocks128 * ((n + 63) / 64) <= 256 ? 2 : 4;
 }
 
 extern "C" size_t lfamd_gemm_lf_workspace(long k, long n) { // Xh
