@@ -15,7 +15,13 @@
 //                 position r * 8 + (j ^ (4 (T & 1) + (r >> 1))) of tile T (chosen on the SOURCE address): every 16-lane group
 //                 of a ds_read_b128 then covers all 64 banks.
 //   dequantise  : q ^ 0x80 = q + 128 as a byte; v_perm builds the f16 pair 1024 + u, a packed add of -1152 gives q exactly, a
-//                 packed multiply d * q rounded once: 14 VALU per K-step and wave, feeding NT MFMAs.
+//                 packed multiply d * q rounded once: 14 VALU per K-step and wave, feeding NT MFMAs — issued BETWEEN the MFMAs of
+//                 the K-step before (a wave issues in order: NT MFMAs back to back hold its instruction stream for 32 (NT - 1)
+//                 cycles, and what followed them started only then).
+//   what bounds : LDS bandwidth.  Per K-step a computing wave reads NT code fragments + half a weight chunk (1 KiB each) for NT
+//                 MFMAs and the four waves read the same code fragments: 147 KB of reads + 49 KB of DMA writes per stage at
+//                 128 x 128 = 1530 cycles at 128 B per clock (stamps: 1530-1580 per stage for 1024 of MFMA; 128 x 64: 113 KB = 885,
+//                 stamps 1060); the large grids are then paced by the loaders (L2 -> LDS, ~10 TB/s over the chip).
 //   activations : f16(d8 * q8) (quantize_row_q8_0 arithmetic, or the caller's Q8_0 blocks), [quad][token][256 B] in the K order
 //                 above, 16-byte chunks XOR-swizzled by token on the source address.
 #include "gemm_wide_impl.h"
@@ -44,6 +50,52 @@ __device__ static inline void lf_dsr8(uint2 &dst, uint32_t addr) {
     asm volatile("ds_read_b64 %0, %1" : "=v"(dst) : "v"(addr));
 }
 
+// The dequantisation of one fragment quarter as asm blocks that sit between two MFMAs (K-step pipeline of gemm_lf_q80_kernel):
+//   u = w ^ 0x80808080 (q + 128 as bytes); t = perm -> the f16 pair (1024 + u); t += -1152 (q exactly); f = t * (d, d) (ONE rounding).
+// The multiply of quarter j - 1 leads the block of quarter j: a packed multiply right behind the packed add it reads needs a wait
+// state.  `after` is the accumulator of the MFMA in front of the block: not read, it only orders the block behind that MFMA.
+__device__ static inline void lf_q_first(uint32_t &u, half2_t &t, uint32_t w, uint32_t k64, uint32_t sel, uint32_t m1152, const float16_t_ &after) {
+    asm volatile("v_xor_b32 %0, 0x80808080, %2\n\tv_perm_b32 %1, %3, %0, %4\n\tv_pk_add_f16 %1, %5, %1"
+                 : "=&v"(u), "=&v"(t)
+                 : "v"(w), "s"(k64), "v"(sel), "v"(m1152), "v"(after));
+}
+__device__ static inline void lf_q_mul_second(half2_t &f, half2_t &t, half2_t tp, half2_t d, uint32_t u, uint32_t k64, uint32_t sel, uint32_t m1152,
+                                              const float16_t_ &after) {
+    asm volatile("v_pk_mul_f16 %0, %2, %3\n\tv_perm_b32 %1, %5, %4, %6\n\tv_pk_add_f16 %1, %7, %1"
+                 : "=&v"(f), "=&v"(t)
+                 : "v"(tp), "v"(d), "v"(u), "s"(k64), "v"(sel), "v"(m1152), "v"(after));
+}
+__device__ static inline void lf_q_mul_first(half2_t &f, uint32_t &u, half2_t &t, half2_t tp, half2_t d, uint32_t w, uint32_t k64, uint32_t sel,
+                                             uint32_t m1152, const float16_t_ &after) {
+    asm volatile("v_pk_mul_f16 %0, %3, %4\n\tv_xor_b32 %1, 0x80808080, %5\n\tv_perm_b32 %2, %6, %1, %7\n\tv_pk_add_f16 %2, %8, %2"
+                 : "=&v"(f), "=&v"(u), "=&v"(t)
+                 : "v"(tp), "v"(d), "v"(w), "s"(k64), "v"(sel), "v"(m1152), "v"(after));
+}
+// 64-token tile: two quarters per block
+__device__ static inline void lf_h_first(half2_t &t0, half2_t &t1, uint32_t w, uint32_t k64, uint32_t sel0, uint32_t sel1, uint32_t m1152,
+                                         const float16_t_ &after) {
+    uint32_t u;
+    asm volatile("v_xor_b32 %0, 0x80808080, %3\n\tv_perm_b32 %1, %4, %0, %5\n\tv_perm_b32 %2, %4, %0, %6\n\tv_pk_add_f16 %1, %7, %1\n\tv_pk_add_f16 %2, %7, %2"
+                 : "=&v"(u), "=&v"(t0), "=&v"(t1)
+                 : "v"(w), "s"(k64), "v"(sel0), "v"(sel1), "v"(m1152), "v"(after));
+}
+__device__ static inline void lf_h_mul_second(half2_t &f0, half2_t &f1, half2_t &t2, half2_t &t3, half2_t tp0, half2_t tp1, half2_t d, uint32_t w,
+                                              uint32_t k64, uint32_t sel0, uint32_t sel1, uint32_t m1152, const float16_t_ &after) {
+    uint32_t u;
+    asm volatile("v_pk_mul_f16 %0, %5, %7\n\tv_xor_b32 %4, 0x80808080, %8\n\tv_pk_mul_f16 %1, %6, %7\n\tv_perm_b32 %2, %9, %4, %10\n\t"
+                 "v_perm_b32 %3, %9, %4, %11\n\tv_pk_add_f16 %2, %12, %2\n\tv_pk_add_f16 %3, %12, %3"
+                 : "=&v"(f0), "=&v"(f1), "=&v"(t2), "=&v"(t3), "=&v"(u)
+                 : "v"(tp0), "v"(tp1), "v"(d), "v"(w), "s"(k64), "v"(sel0), "v"(sel1), "v"(m1152), "v"(after));
+}
+
+#ifdef LF_STAMPS // development (tools/lf_stamps.py): s_memtime sums of one work-group's compute wave 0 and loader wave 4
+__device__ unsigned long long g_lf_stamps[16];
+extern "C" int lfamd_debug_lf_stamps(unsigned long long *dst) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_lf_stamps), sizeof(g_lf_stamps));
+}
+#define LF_T() __builtin_amdgcn_s_memtime()
+#endif
+
 template <int NT>
 __global__ __launch_bounds__(512) void gemm_lf_q80_kernel(const gemm_mats mats, int nq, const _Float16 *__restrict__ Xh, long n, long n_pad,
                                                            int n_rb, int n_ct) {
@@ -57,6 +109,11 @@ __global__ __launch_bounds__(512) void gemm_lf_q80_kernel(const gemm_mats mats, 
     __shared__ __attribute__((aligned(16))) uint8_t lds[RING * SLOT];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 31, h = lane >> 5;
+#ifdef LF_STAMPS
+    const unsigned long long st_start = LF_T();
+    const bool st_on = blockIdx.x == 40;
+    unsigned long long st_a = 0, st_b = 0, st_c = 0;
+#endif
 
     // ---- tile of this work-group (the order of gemm_ks: XCD-aware super-tiles)
     int rb, ct;
@@ -145,15 +202,31 @@ __global__ __launch_bounds__(512) void gemm_lf_q80_kernel(const gemm_mats mats, 
             // landed and everybody is done with stage b - 1, whose slot takes stage b + RING - 1
             int behind = nq - 2 - b; // stages issued behind stage b + 1
             behind = behind < 0 ? 0 : behind > RING - 3 ? RING - 3 : behind;
+#ifdef LF_STAMPS
+            const unsigned long long t0 = LF_T();
+#endif
             if (RING == 4 && behind >= 1)
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
             else
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef LF_STAMPS
+            const unsigned long long t1 = LF_T();
+#endif
             asm volatile("s_barrier" ::: "memory");
+#ifdef LF_STAMPS
+            const unsigned long long t2 = LF_T();
+#endif
             if (b + RING - 1 < nq)
                 dma_stage(lds0 + (uint32_t)(slot_i * SLOT));
             slot_i = slot_i + 1 == RING ? 0 : slot_i + 1;
+#ifdef LF_STAMPS
+            st_a += t1 - t0, st_b += t2 - t1, st_c += LF_T() - t2;
+#endif
         }
+#ifdef LF_STAMPS
+        if (st_on && wave == 4 && lane == 0)
+            g_lf_stamps[8] = st_a, g_lf_stamps[9] = st_b, g_lf_stamps[10] = st_c, g_lf_stamps[11] = LF_T() - st_start;
+#endif
         return;
     }
 
@@ -182,10 +255,11 @@ __global__ __launch_bounds__(512) void gemm_lf_q80_kernel(const gemm_mats mats, 
     asm volatile("s_barrier" ::: "memory"); // stage 0 has landed for everybody
 
     // Registers of the LDS pipeline (all reads are asm, every wait is counted: LDS reads of a wave return in issue order): XF[2][NT]
-    // the code fragments ONE K-step ahead (two ahead measured the same), WQ[2] the weight chunks (one serves two K-steps) one pair
-    // ahead, SC the stage's scales.  In K-step s the wave issues X(s + 1) [NT reads], at odd s the weight chunk of pair (s + 1) / 2,
-    // at s = 7 the next stage's scales — from the NEXT slot once s + 1 = 8: that stage has landed, the barrier at the top of this one
-    // said so — then waits for what step s needs: younger than it are exactly this step's own reads.
+    // the code fragments ONE K-step ahead (two ahead measured the same), WQ[2] the weight chunks (one serves two K-steps) a pair
+    // ahead of their dequantisation, SC the stage's scales.  In K-step s the wave issues X(s + 1) [NT reads], at even s the weight
+    // chunk of K-steps s + 2, s + 3, at s = 6 the next stage's scales — from the NEXT slot once past this stage's end: that stage has
+    // landed, the barrier at the top of this one said so — then waits for what the PREVIOUS step issued: younger are exactly this
+    // step's own reads.
     u32x4 XF[2][NT], WQ[2];
     uint2 SC;
 #define LF_WAIT(N) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N))
@@ -204,43 +278,92 @@ __global__ __launch_bounds__(512) void gemm_lf_q80_kernel(const gemm_mats mats, 
         if (NT == 4)                                                                                                          \
             asm volatile("" : "+v"(XF[(S)&1][NT - 2]), "+v"(XF[(S)&1][NT - 1]));                                                \
     } while (0)
+    // The K-steps are a software pipeline: the fragment of K-step s + 1 is dequantised BETWEEN the MFMAs of K-step s (stamps of the
+    // form that dequantised and multiplied in the same step: 1311 / 1986 cycles per stage at NT = 2 / 4 for 512 / 1024 of MFMA and no
+    // barrier wait at all; now 1060 / 1530-1580, tools/lf_stamps.py).
+    frag_u FW[2];  // K-step s multiplies FW[s & 1]
+    half2_t Dk[4]; // per block of the quad: (d, d)
+    uint32_t m1152u; // (-1152, -1152) in a VGPR: as an SGPR operand of the packed add, hipcc pads a wait state in front of the multiply
+    asm volatile("v_mov_b32 %0, 0xe480e480" : "=v"(m1152u));
+    const half2_t m1152 = as_half2(m1152u);
+#define LF_DK()                                                                                                               \
+    do {                                                                                                                      \
+        asm volatile("" : "+v"(SC));                                                                                          \
+        Dk[0] = as_half2(__builtin_amdgcn_perm(SC.x, SC.x, 0x01000100u)), Dk[1] = as_half2(__builtin_amdgcn_perm(SC.x, SC.x, 0x03020302u)); \
+        Dk[2] = as_half2(__builtin_amdgcn_perm(SC.y, SC.y, 0x01000100u)), Dk[3] = as_half2(__builtin_amdgcn_perm(SC.y, SC.y, 0x03020302u)); \
+    } while (0)
+    // fragment quarter J of K-step S1: dword J >> 1 of the step's chunk half, byte pair J & 1; scale of block 2 (S1 & 1) + (J >> 1)
+#define LF_QW(S1, J) (((S1)&1) ? ((J) < 2 ? WQ[((S1) >> 1) & 1].z : WQ[((S1) >> 1) & 1].w) : ((J) < 2 ? WQ[((S1) >> 1) & 1].x : WQ[((S1) >> 1) & 1].y))
+#define LF_QD(S1, J) Dk[2 * ((S1)&1) + ((J) >> 1)]
+    half2_t TQ[4]; // q as f16 pairs, one slot ahead of their multiply
+    uint32_t UQ;   // a dword's q + 128 bytes between its two quarters
+    uint32_t sel_lo, sel_hi, k64;
+    asm volatile("v_mov_b32 %0, 0x04010400\n\tv_mov_b32 %1, 0x04030402\n\ts_mov_b32 %2, 0x64646464" : "=v"(sel_lo), "=v"(sel_hi), "=s"(k64));
     LF_XREAD(0, 0u);
     lf_dsr16<0>(WQ[0], adW[0]);
     lf_dsr8(SC, adD);
+    LF_WAIT(0);
+    asm volatile("" : "+v"(WQ[0]));
+    LF_DK();
+#pragma unroll
+    for (int J = 0; J < 4; J++) { // the whole fragment of K-step 0 but its last multiplies (they open K-step 0)
+        const uint32_t w = J < 2 ? WQ[0].x : WQ[0].y;
+        TQ[J] = as_half2(__builtin_amdgcn_perm(0x64646464u, w ^ 0x80808080u, (J & 1) ? 0x04030402u : 0x04010400u)) + m1152;
+    }
+    FW[0].p[0] = TQ[0] * Dk[0], FW[0].p[1] = TQ[1] * Dk[0];
+    if (NT == 4)
+        FW[0].p[2] = TQ[2] * Dk[1];
 
-    half2_t Dk[4]; // per block of the quad: (d, d)
     int slot_c = 0;
     for (int b = 0; b < nq; b++) {
         const uint32_t so = (uint32_t)(slot_c * SLOT);
         slot_c = slot_c + 1 == RING ? 0 : slot_c + 1;
         const uint32_t so_n = (uint32_t)(slot_c * SLOT);
+#ifdef LF_STAMPS
+        const unsigned long long t0 = LF_T();
+#endif
         asm volatile("s_barrier" ::: "memory"); // stage b + 1 has landed for everybody (the loaders waited for their pieces)
+#ifdef LF_STAMPS
+        const unsigned long long t1 = LF_T();
+#endif
+// K-step S: issue X(S + 1), at even S the weight chunk of K-steps S + 2, S + 3, at S = 6 the next stage's scales (from the NEXT slot
+// once past this stage's end: it has landed, the barrier above said so); the last multiplies of THIS step's fragment; wait for
+// everything the previous step issued; then the MFMAs of S, each followed by an asm block with a part of fragment S + 1 (the blocks
+// are volatile and read the accumulator of the MFMA in front of them, so the order MFMA - block - MFMA holds; sched_barrier per step)
 #define LF_STEP(S)                                                                                                            \
     do {                                                                                                                      \
         LF_XREAD((S) + 1, (S) == 7 ? so_n : so);                                                                              \
-        if ((S)&1)                                                                                                            \
-            lf_dsr16<0>(WQ[(((S) + 1) >> 1) & 1], adW[(((S) + 1) >> 1) & 3] + ((S) == 7 ? so_n : so));                           \
-        if ((S) == 7)                                                                                                         \
+        if (((S)&1) == 0)                                                                                                     \
+            lf_dsr16<0>(WQ[(((S) + 2) >> 1) & 1], adW[(((S) + 2) >> 1) & 3] + ((S) == 6 ? so_n : so));                           \
+        if ((S) == 6)                                                                                                         \
             lf_dsr8(SC, adD + so_n);                                                                                          \
-        LF_WAIT(NT + ((S)&1) + ((S) == 7));                                                                                   \
+        if (NT == 2)                                                                                                          \
+            FW[(S)&1].p[2] = TQ[2] * LF_QD(S, 2);                                                                               \
+        FW[(S)&1].p[3] = TQ[3] * LF_QD(S, 3);                                                                                   \
+        LF_WAIT(NT + (((S)&1) == 0) + ((S) == 6));                                                                            \
         LF_XTIE(S);                                                                                                           \
-        asm volatile("" : "+v"(WQ[((S) >> 1) & 1]));                                                                           \
-        if ((S) == 0) { /* (d, d) of the quad's four blocks */                                                                \
-            asm volatile("" : "+v"(SC));                                                                                      \
-            Dk[0] = as_half2(__builtin_amdgcn_perm(SC.x, SC.x, 0x01000100u)), Dk[1] = as_half2(__builtin_amdgcn_perm(SC.x, SC.x, 0x03020302u)); \
-            Dk[2] = as_half2(__builtin_amdgcn_perm(SC.y, SC.y, 0x01000100u)), Dk[3] = as_half2(__builtin_amdgcn_perm(SC.y, SC.y, 0x03020302u)); \
+        asm volatile("" : "+v"(WQ[(((S) + 1) >> 1) & 1]));                                                                     \
+        if ((S) == 7)                                                                                                         \
+            LF_DK();                                                                                                          \
+        _Pragma("unroll") for (int t = 0; t < NT; t++) {                                                                       \
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, XF[(S)&1][t]), FW[(S)&1].v, acc[t], 0, 0, 0); \
+            if (NT == 4) {                                                                                                    \
+                if (t == 0)                                                                                                   \
+                    lf_q_first(UQ, TQ[0], LF_QW((S) + 1, 0), k64, sel_lo, m1152u, acc[t]);                                       \
+                else if (t == 1)                                                                                              \
+                    lf_q_mul_second(FW[((S) + 1) & 1].p[0], TQ[1], TQ[0], LF_QD((S) + 1, 0), UQ, k64, sel_hi, m1152u, acc[t]);      \
+                else if (t == 2)                                                                                              \
+                    lf_q_mul_first(FW[((S) + 1) & 1].p[1], UQ, TQ[2], TQ[1], LF_QD((S) + 1, 1), LF_QW((S) + 1, 2), k64, sel_lo, m1152u, acc[t]); \
+                else                                                                                                          \
+                    lf_q_mul_second(FW[((S) + 1) & 1].p[2], TQ[3], TQ[2], LF_QD((S) + 1, 2), UQ, k64, sel_hi, m1152u, acc[t]);      \
+            } else if (t == 0) {                                                                                              \
+                lf_h_first(TQ[0], TQ[1], LF_QW((S) + 1, 0), k64, sel_lo, sel_hi, m1152u, acc[t]);                                \
+            } else {                                                                                                          \
+                lf_h_mul_second(FW[((S) + 1) & 1].p[0], FW[((S) + 1) & 1].p[1], TQ[2], TQ[3], TQ[0], TQ[1], LF_QD((S) + 1, 0),       \
+                                LF_QW((S) + 1, 2), k64, sel_lo, sel_hi, m1152u, acc[t]);                                         \
+            }                                                                                                                 \
         }                                                                                                                     \
-        const u32x4 &wq_ = WQ[((S) >> 1) & 1];                                                                                 \
-        const uint32_t u0_ = (((S)&1) ? wq_.z : wq_.x) ^ 0x80808080u, u1_ = (((S)&1) ? wq_.w : wq_.y) ^ 0x80808080u;            \
-        const half2_t m1152_ = {(_Float16)-1152.0f, (_Float16)-1152.0f};                                                      \
-        frag_u f_; /* (1024 + u) - 1152 = q exactly, then ONE rounding in d * q (a fused -1152 d would be a rounded constant) */ \
-        f_.p[0] = (as_half2(__builtin_amdgcn_perm(0x64646464u, u0_, 0x04010400u)) + m1152_) * Dk[2 * ((S)&1)];                  \
-        f_.p[1] = (as_half2(__builtin_amdgcn_perm(0x64646464u, u0_, 0x04030402u)) + m1152_) * Dk[2 * ((S)&1)];                  \
-        f_.p[2] = (as_half2(__builtin_amdgcn_perm(0x64646464u, u1_, 0x04010400u)) + m1152_) * Dk[2 * ((S)&1) + 1];              \
-        f_.p[3] = (as_half2(__builtin_amdgcn_perm(0x64646464u, u1_, 0x04030402u)) + m1152_) * Dk[2 * ((S)&1) + 1];              \
-        _Pragma("unroll") for (int t = 0; t < NT; t++)                                                                         \
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, XF[(S)&1][t]), f_.v, acc[t], 0, 0, 0);  \
-        __builtin_amdgcn_sched_barrier(0); /* (left alone hipcc gathers the reads of all eight steps at the top of the stage) */ \
+        __builtin_amdgcn_sched_barrier(0);                                                                                    \
     } while (0)
         LF_STEP(0);
         LF_STEP(1);
@@ -251,13 +374,23 @@ __global__ __launch_bounds__(512) void gemm_lf_q80_kernel(const gemm_mats mats, 
         LF_STEP(6);
         LF_STEP(7);
 #undef LF_STEP
+#ifdef LF_STAMPS
+        st_a += t1 - t0, st_b += LF_T() - t1;
+#endif
     }
+#ifdef LF_STAMPS
+    if (st_on && wave == 0 && lane == 0)
+        g_lf_stamps[0] = st_a, g_lf_stamps[1] = st_b, g_lf_stamps[2] = (unsigned long long)nq, g_lf_stamps[3] = LF_T() - st_start;
+#endif
     LF_WAIT(0); // (the reads of a stage that does not exist: slot contents never used)
     LF_XTIE(0);
     asm volatile("" : "+v"(WQ[0]), "+v"(SC));
 #undef LF_WAIT
 #undef LF_XREAD
 #undef LF_XTIE
+#undef LF_DK
+#undef LF_QW
+#undef LF_QD
 
     // ---- store: lane (i, h) holds weight row 32 rt + i, register e = token n0 + 32 t + 8 (e >> 2) + 4 h + (e & 3)
     if ((long)rt * 32 + i < m) {
@@ -271,6 +404,10 @@ __global__ __launch_bounds__(512) void gemm_lf_q80_kernel(const gemm_mats mats, 
                     C[tk * ldc + row] = acc[t][e];
             }
     }
+#ifdef LF_STAMPS
+    if (st_on && wave == 0 && lane == 0)
+        g_lf_stamps[4] = LF_T() - st_start;
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
