@@ -300,19 +300,19 @@ def cpu_baseline(layers, prefill, decode):
         by_name = {s.name.split(".")[-1]: s for s in layer}
         rate = {}  # weight type -> FLOP/s at n = prefill
         pf_ops = [by_name["attn_output"], by_name["ffn_gate"], by_name["ffn_down"]]
-        fl = {T.Q4_K: 0.0, T.Q6_K: 0.0}
-        tm = {T.Q4_K: 0.0, T.Q6_K: 0.0}
+        fl, tm = {}, {}
         for spec in pf_ops:
             ts = timed(spec, prefill, 3)
             spreads.append(max(ts) / min(ts))
             med_min.append(statistics.median(ts) / min(ts))
-            fl[spec.type] += 2.0 * spec.m * spec.k * prefill
-            tm[spec.type] += statistics.median(ts)
+            fl[spec.type] = fl.get(spec.type, 0.0) + 2.0 * spec.m * spec.k * prefill
+            tm[spec.type] = tm.get(spec.type, 0.0) + statistics.median(ts)
         for t in fl:
             if tm[t] > 0:
                 rate[t] = fl[t] / tm[t]
-        for t in (T.Q4_K, T.Q6_K):  # (a model whose layer 0 lacks one of the types: price it like the other)
-            rate.setdefault(t, next(iter(rate.values())))
+        for ops in layers:  # (a type layer 0 does not hold, e.g. output.weight's: priced like the first one measured)
+            for s in ops:
+                rate.setdefault(s.type, next(iter(rate.values())))
         t_prefill = sum(2.0 * s.m * s.k * prefill / rate[s.type] for ops in layers for s in ops)
         t_dec_layer = 0.0
         for spec in layer:
@@ -339,8 +339,9 @@ def cpu_baseline(layers, prefill, decode):
     return {
         "value": round((prefill + decode) / total, 3), "unit": "tokens/s", "cores": nth, "kind": "port",
         "median_over_fastest_repeat": round(mm, 3), "max_over_min_repeat": round(spread, 3), "unstable": unstable,
-        "sample": f"n={prefill} timed directly on attn_output 4096x4096, ffn_gate 14336x4096 (Q4_K) and ffn_down 4096x14336 "
-                  f"(layer 0's type), median of 3; n=1 on layer 0's 7 mat-muls, median of 5; {nth} pinned threads "
+        "sample": f"n={prefill} timed directly on layer 0's attn_output, ffn_gate and ffn_down ("
+                  + ", ".join(f"{by.m}x{by.k} {T.NAMES[by.type]}" for by in (next(s for s in layer if s.name.endswith(nm)) for nm in ("attn_output", "ffn_gate", "ffn_down")))
+                  + f"), median of 3; n=1 on layer 0's {len(layer)} mat-muls, median of 5; {nth} pinned threads "
                   f"(OMP_PROC_BIND=close, the cgroup's CPU share); other ops priced at their type's measured rate "
                   f"({', '.join(f'{T.NAMES[t]} {r / 1e9:.1f} GFLOP/s' for t, r in rate.items())}); "
                   f"decode {1.0 / t_decode_token:.2f} tok/s, prefill {prefill / t_prefill:.2f} tok/s",
