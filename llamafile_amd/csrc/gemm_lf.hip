@@ -197,6 +197,38 @@ __global__ __launch_bounds__(512) void gemm_lf_q80_kernel(const gemm_mats mats, 
         }
         asm volatile("s_barrier" ::: "memory"); // stage 0 has landed for everybody
         int slot_i = RING - 1; // slot of stage b + RING - 1
+        if constexpr (RING == 3) {
+            // A ring of three leaves the loader no slack under ONE barrier per stage: it would issue stage b + 1 and wait for it at
+            // once (stamps: 805 cycles of wait + 1079 of issue per stage against 1530 of K-steps).  Two barriers per stage instead:
+            // B1 — everybody is done with stage b - 1, its slot takes stage b + 2; B2 — in front of the computing waves' first read
+            // of stage b + 1 (K-step 6) — stage b + 1, issued a whole stage ago, has landed.
+            for (int b = 0; b < nq; b++) {
+#ifdef LF_STAMPS
+                const unsigned long long t0 = LF_T();
+#endif
+                asm volatile("s_barrier" ::: "memory"); // B1
+#ifdef LF_STAMPS
+                const unsigned long long t1 = LF_T();
+#endif
+                if (b + 2 < nq) {
+                    dma_stage(lds0 + (uint32_t)(slot_i * SLOT));
+#ifdef LF_STAMPS
+                    st_c += LF_T() - t1;
+#endif
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                slot_i = slot_i + 1 == RING ? 0 : slot_i + 1;
+#ifdef LF_STAMPS
+                const unsigned long long t2 = LF_T();
+#endif
+                asm volatile("s_barrier" ::: "memory"); // B2
+#ifdef LF_STAMPS
+                st_a += t2 - t1, st_b += (t1 - t0) + (LF_T() - t2); // (st_a: issue + vmcnt wait; st_c: the issue alone)
+#endif
+            }
+        } else {
         for (int b = 0; b < nq; b++) {
             // this wave's pieces of stage b + 1 (all but those of the stages issued behind it); past the barrier everybody's have
             // landed and everybody is done with stage b - 1, whose slot takes stage b + RING - 1
@@ -205,7 +237,7 @@ __global__ __launch_bounds__(512) void gemm_lf_q80_kernel(const gemm_mats mats, 
 #ifdef LF_STAMPS
             const unsigned long long t0 = LF_T();
 #endif
-            if (RING == 4 && behind >= 1)
+            if (behind >= 1)
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
             else
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -222,6 +254,7 @@ __global__ __launch_bounds__(512) void gemm_lf_q80_kernel(const gemm_mats mats, 
 #ifdef LF_STAMPS
             st_a += t1 - t0, st_b += t2 - t1, st_c += LF_T() - t2;
 #endif
+        }
         }
 #ifdef LF_STAMPS
         if (st_on && wave == 4 && lane == 0)
@@ -322,7 +355,7 @@ __global__ __launch_bounds__(512) void gemm_lf_q80_kernel(const gemm_mats mats, 
 #ifdef LF_STAMPS
         const unsigned long long t0 = LF_T();
 #endif
-        asm volatile("s_barrier" ::: "memory"); // stage b + 1 has landed for everybody (the loaders waited for their pieces)
+        asm volatile("s_barrier" ::: "memory"); // ring of 4: stage b + 1 has landed for everybody; ring of 3: B1, everybody is done with stage b - 1
 #ifdef LF_STAMPS
         const unsigned long long t1 = LF_T();
 #endif
@@ -332,6 +365,8 @@ __global__ __launch_bounds__(512) void gemm_lf_q80_kernel(const gemm_mats mats, 
 // are volatile and read the accumulator of the MFMA in front of them, so the order MFMA - block - MFMA holds; sched_barrier per step)
 #define LF_STEP(S)                                                                                                            \
     do {                                                                                                                      \
+        if (RING == 3 && (S) == 6)                                                                                            \
+            asm volatile("s_barrier" ::: "memory"); /* B2: stage b + 1 has landed for everybody */                            \
         LF_XREAD((S) + 1, (S) == 7 ? so_n : so);                                                                              \
         if (((S)&1) == 0)                                                                                                     \
             lf_dsr16<0>(WQ[(((S) + 2) >> 1) & 1], adW[(((S) + 2) >> 1) & 3] + ((S) == 6 ? so_n : so));                           \
@@ -545,12 +580,17 @@ __global__ __launch_bounds__(512) void gemm_lf_float_kernel(const gemm_mats mats
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_barrier" ::: "memory"); // stage 0 has landed for everybody
         int slot_i = RING - 1;
+        static_assert(RING == 3, "two barriers per stage (cf. gemm_lf_q80_kernel's ring of three)");
         for (int b = 0; b < nq; b++) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // stage b + 1
-            asm volatile("s_barrier" ::: "memory");
-            if (b + RING - 1 < nq)
+            asm volatile("s_barrier" ::: "memory"); // B1: everybody is done with stage b - 1, its slot takes stage b + 2
+            if (b + 2 < nq) {
                 dma_stage(lds0 + (uint32_t)(slot_i * LFF_SLOT));
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory"); // stage b + 1, issued a whole stage ago
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             slot_i = slot_i + 1 == RING ? 0 : slot_i + 1;
+            asm volatile("s_barrier" ::: "memory"); // B2: stage b + 1 has landed for everybody
         }
         return;
     }
@@ -582,9 +622,11 @@ __global__ __launch_bounds__(512) void gemm_lf_float_kernel(const gemm_mats mats
         const uint32_t so = (uint32_t)(slot_c * LFF_SLOT);
         slot_c = slot_c + 1 == RING ? 0 : slot_c + 1;
         const uint32_t so_n = (uint32_t)(slot_c * LFF_SLOT);
-        asm volatile("s_barrier" ::: "memory"); // stage b + 1 has landed for everybody
+        asm volatile("s_barrier" ::: "memory"); // B1: everybody is done with stage b - 1
 #define LFF_STEP(S)                                                                                                           \
     do {                                                                                                                      \
+        if ((S) == 7)                                                                                                         \
+            asm volatile("s_barrier" ::: "memory"); /* B2: stage b + 1 has landed for everybody */                            \
         lf_dsr16<0>(WF[((S) + 1) & 1], adW[((S) + 1) & 7] + ((S) == 7 ? so_n : so));                                            \
         lf_dsr16<0>(XF[((S) + 1) & 1][0], adX[((S) + 1) & 7] + ((S) == 7 ? so_n : so));                                         \
         lf_dsr16<8192>(XF[((S) + 1) & 1][1], adX[((S) + 1) & 7] + ((S) == 7 ? so_n : so));                                      \
