@@ -20,8 +20,10 @@ from helpers import elem_err, rel_err
 pytestmark = pytest.mark.gpu
 
 # (m, n, k): one quad, three quads, many; fewer rows than a P80 tile, rows that are no multiple of 8 / 32 / 128; tokens around the
-# 64- and 128-token tile edges; (1100, 700, 512) does not fit one round of 128 x 64 tiles and takes the wide tile by default
-SHAPES = [(5, 9, 128), (64, 20, 128), (40, 33, 384), (129, 65, 256), (300, 128, 1024), (1000, 129, 640), (1100, 700, 512), (2048, 64, 4096)]
+# 64- and 128-token tile edges; (1100, 700, 512) does not fit one round of 128 x 64 tiles and takes the wide tile by default, and so
+# do (4224, 520, 128) and (4300, 513, 256): its ring of three stages with one and two stages to go round (two barriers per stage)
+SHAPES = [(5, 9, 128), (64, 20, 128), (40, 33, 384), (129, 65, 256), (300, 128, 1024), (1000, 129, 640), (1100, 700, 512), (2048, 64, 4096),
+          (4224, 520, 128), (4300, 513, 256)]
 
 
 @pytest.mark.parametrize("shape", SHAPES, ids=str)
