@@ -18,10 +18,11 @@
 //                 packed multiply d * q rounded once: 14 VALU per K-step and wave, feeding NT MFMAs — issued BETWEEN the MFMAs of
 //                 the K-step before (a wave issues in order: NT MFMAs back to back hold its instruction stream for 32 (NT - 1)
 //                 cycles, and what followed them started only then).
-//   what bounds : LDS bandwidth.  Per K-step a computing wave reads NT code fragments + half a weight chunk (1 KiB each) for NT
-//                 MFMAs and the four waves read the same code fragments: 147 KB of reads + 49 KB of DMA writes per stage at
-//                 128 x 128 = 1530 cycles at 128 B per clock (stamps: 1530-1580 per stage for 1024 of MFMA; 128 x 64: 113 KB = 885,
-//                 stamps 1060); the large grids are then paced by the loaders (L2 -> LDS, ~10 TB/s over the chip).
+//   what bounds : the computing wave's own instruction stream (ablations on a stamped build, profiles/r04_lf_stamps.txt): with the
+//                 MFMAs taken OUT a stage still takes 884 / 1255 cycles at 128 x 64 / 128 x 128 (512 / 1024 are the MFMAs'), without
+//                 the dequantisation 676 / 1284, without the code-fragment reads 939 / 1350, without any DMA in the steady state
+//                 the same as with it; LDS bandwidth is not it (147 KB of reads per 128 x 128 stage = 574 cycles at 256 B per clock).
+//                 The large grids are paced by the loaders (L2 -> LDS, ~10 TB/s over the chip).
 //   activations : f16(d8 * q8) (quantize_row_q8_0 arithmetic, or the caller's Q8_0 blocks), [quad][token][256 B] in the K order
 //                 above, 16-byte chunks XOR-swizzled by token on the source address.
 #include "gemm_wide_impl.h"
