@@ -130,6 +130,10 @@ def check_valu_hazards(text):
       VALU writes an SGPR -> v_readlane / v_writelane lane select: 4;  -> VALU reading it as a constant: 2;  -> VMEM address: 5
       VALU writes VCC     -> v_div_fmas: 4                            VALU writes EXEC  -> DPP: 5
       SALU writes M0      -> LDS-DMA load (`*_load_lds_*` / `lds` modifier): 1
+      packed 16-bit VALU result (`v_pk_*_f16 / _i16 / _u16`, or a result written to a register half: `dst_sel:` / op_sel's destination bit)
+                          -> any VALU or MFMA reading that VGPR: 1 (LLVM's dst_sel forwarding hazard; hipcc pads it — and assumes
+                          it of every asm statement's outputs — but not BETWEEN two instructions of one asm statement: gemm_lf.hip's
+                          dequantisation blocks keep a multiply one block behind the add it reads)
     The walk is linear (these windows are at most five instructions long).  -> {kernel: [message + instruction]}"""
     res = {}
     for name, body in re.findall(r"^(_Z\w+):[^\n]*\n(.*?)\.Lfunc_end", text, re.S | re.M):
@@ -173,6 +177,8 @@ def check_valu_hazards(text):
                 need(lambda k, vg, sg, fl: k == "valu" and sg & src_s, 2, "VALU-written SGPR -> VALU constant")
             if is_valu and not op.startswith(_TRANS):
                 need(lambda k, vg, sg, fl: k == "trans" and vg & src_v, 1, "transcendental result -> VALU")
+            if op.startswith("v_"):  # (MFMAs included)
+                need(lambda k, vg, sg, fl: k == "valu" and "half" in fl and vg & src_v, 1, "packed / half-register result -> VALU")
             if op.startswith("v_div_fmas"):
                 need(lambda k, vg, sg, fl: k == "valu" and "vcc" in fl, 4, "VALU-written VCC -> v_div_fmas")
             if is_vmem:
@@ -189,6 +195,9 @@ def check_valu_hazards(text):
                     fl.add("vcc")
                 if op.startswith("v_cmpx") or dst.startswith("exec"):
                     fl.add("exec")
+                m_sel = re.search(r"op_sel:\[([01,]+)\]", l)
+                if (op.startswith("v_pk_") and re.search(r"_(f16|bf16|i16|u16)(_e64)?$", op)) or ("dst_sel:" in l and "dst_sel:DWORD" not in l) or (m_sel and not op.startswith("v_pk_") and m_sel.group(1).endswith("1") and m_sel.group(1).count(",") >= 2):
+                    fl.add("half")
                 recent.append(("trans" if op.startswith(_TRANS) else "valu", _regs(dst), _sregs(dst) | _sregs(dst2), fl, 0))
                 if op.startswith(_TRANS):  # (a transcendental is a VALU producer for the other rules as well)
                     recent.append(("valu", _regs(dst), set(), set(), 0))
