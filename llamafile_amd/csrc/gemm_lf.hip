@@ -508,7 +508,7 @@ __global__ __launch_bounds__(256) void prep_lf_kernel(const uint8_t *__restrict_
 // pieces each measured 3-9 % slower), four computing waves, fragments one K-step ahead.  f32 accumulate on the matrix cores like the reference's fmaf chains.
 #define LFF_X 32768
 #define LFF_SLOT (32768 + 16384)
-template <bool BF>
+template <bool BF, bool M16>
 __global__ __launch_bounds__(512) void gemm_lf_float_kernel(const gemm_mats mats, int nq, size_t a_row_bytes, const uint16_t *__restrict__ Xh,
                                                                       long n, long n_pad, int n_rb, int n_ct) {
 #ifdef LF_CHECK_NQ
@@ -598,6 +598,85 @@ __global__ __launch_bounds__(512) void gemm_lf_float_kernel(const gemm_mats mats
 
     const int rw = wave;
     const int rt = rb * 4 + rw;
+    if constexpr (M16) {
+        // The same tile on v_mfma_f32_16x16x32: a K-step is 32 weights, the wave's 32 rows x 64 tokens are 2 x 4 tiles of 16 x 16 —
+        // the same operand bytes, accumulators and MFMA cycles as the 32 x 32 x 16 form; what differs is the clock the chip holds
+        // under it (MI355X_MICROARCH.md, DVFS give-back item 7).  Lane (r16, kq): 16-byte chunk 4 s + kq of row / token r16.
+        const int r16 = lane & 15, kq = lane >> 4;
+        uint32_t aW[4], aX[4]; // K-step s: row tile 0 / token tile 0 (the others: + 4096 per tile of 16)
+#pragma unroll
+        for (int sx = 0; sx < 4; sx++) {
+            aW[sx] = lds0 + (uint32_t)((rw * 32 + r16) * 256 + (((4 * sx + kq) ^ r16) << 4));
+            aX[sx] = lds0 + (uint32_t)(LFF_X + r16 * 256 + (((4 * sx + kq) ^ r16) << 4));
+        }
+        float4_t_ ac[4][2];
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+                ac[t][u] = float4_t_{0.0f, 0.0f, 0.0f, 0.0f};
+        asm volatile("s_barrier" ::: "memory"); // stage 0 has landed for everybody
+        u32x4 W2[2][2], X2[2][4];
+#define LFF_READ(BUF, SX, BASE)                                                                                               \
+    do {                                                                                                                      \
+        lf_dsr16<0>(W2[BUF][0], aW[SX] + (BASE));                                                                              \
+        lf_dsr16<4096>(W2[BUF][1], aW[SX] + (BASE));                                                                           \
+        lf_dsr16<0>(X2[BUF][0], aX[SX] + (BASE));                                                                              \
+        lf_dsr16<4096>(X2[BUF][1], aX[SX] + (BASE));                                                                           \
+        lf_dsr16<8192>(X2[BUF][2], aX[SX] + (BASE));                                                                           \
+        lf_dsr16<12288>(X2[BUF][3], aX[SX] + (BASE));                                                                          \
+    } while (0)
+        LFF_READ(0, 0, 0u);
+        typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+        int slot_c = 0;
+        for (int b = 0; b < nq; b++) {
+            const uint32_t so = (uint32_t)(slot_c * LFF_SLOT);
+            slot_c = slot_c + 1 == RING ? 0 : slot_c + 1;
+            const uint32_t so_n = (uint32_t)(slot_c * LFF_SLOT);
+            asm volatile("s_barrier" ::: "memory"); // B1: everybody is done with stage b - 1
+#define LFF_STEP16(S)                                                                                                         \
+    do {                                                                                                                      \
+        if ((S) == 3)                                                                                                         \
+            asm volatile("s_barrier" ::: "memory"); /* B2: stage b + 1 has landed for everybody */                            \
+        LFF_READ(((S) + 1) & 1, ((S) + 1) & 3, (S) == 3 ? so_n : so);                                                          \
+        asm volatile("s_waitcnt lgkmcnt(6)"                                                                                   \
+                     : "+v"(W2[(S)&1][0]), "+v"(W2[(S)&1][1]), "+v"(X2[(S)&1][0]), "+v"(X2[(S)&1][1]), "+v"(X2[(S)&1][2]),      \
+                       "+v"(X2[(S)&1][3]));                                                                                    \
+        _Pragma("unroll") for (int t = 0; t < 4; t++) _Pragma("unroll") for (int u = 0; u < 2; u++) {                            \
+            if constexpr (BF)                                                                                                 \
+                ac[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, X2[(S)&1][t]),                  \
+                                                                   __builtin_bit_cast(bf16x8_t, W2[(S)&1][u]), ac[t][u], 0, 0, 0); \
+            else                                                                                                              \
+                ac[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, X2[(S)&1][t]),                    \
+                                                                  __builtin_bit_cast(half8_t, W2[(S)&1][u]), ac[t][u], 0, 0, 0);  \
+        }                                                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                                    \
+    } while (0)
+            LFF_STEP16(0);
+            LFF_STEP16(1);
+            LFF_STEP16(2);
+            LFF_STEP16(3);
+#undef LFF_STEP16
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(W2[0][0]), "+v"(W2[0][1]), "+v"(X2[0][0]), "+v"(X2[0][1]), "+v"(X2[0][2]), "+v"(X2[0][3])); // (a stage that does not exist)
+#undef LFF_READ
+        // lane (r16, kq) holds weight row 32 rt + 16 u + r16, register j = token n0 + 16 t + 4 kq + j
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const long row = (long)rt * 32 + 16 * u + r16;
+            if (row < m)
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const long tk = n0 + 16 * t + 4 * kq + j;
+                        if (tk < n)
+                            C[tk * ldc + row] = ac[t][u][j];
+                    }
+        }
+        return;
+    }
     uint32_t adW[8], adX[8];
 #pragma unroll
     for (int s = 0; s < 8; s++) {
@@ -681,10 +760,18 @@ extern "C" hipError_t lfamd_launch_gemm_lf_float(int Atype, const void *A, size_
         mats.A[q] = (const uint8_t *)A, mats.C[q] = C, mats.m[q] = q ? 0 : m, mats.ldc[q] = q ? 0 : ldc, mats.rb_end[q] = n_rb;
     const int nq = (int)(k / 128);
     const unsigned grid = (unsigned)(n_rb * n_ct);
-    if (Atype == LFAMD_TYPE_BF16)
-        gemm_lf_float_kernel<true><<<grid, 512, 0, s>>>(mats, nq, a_row_bytes, (const uint16_t *)Xh, n, n_pad, n_rb, n_ct);
-    else
-        gemm_lf_float_kernel<false><<<grid, 512, 0, s>>>(mats, nq, a_row_bytes, (const uint16_t *)Xh, n, n_pad, n_rb, n_ct);
+    static const bool m16 = !(getenv("LFAMD_LFF_M16") && atoi(getenv("LFAMD_LFF_M16")) == 0); // (A/B runs: 0 = the 32 x 32 x 16 form)
+    if (Atype == LFAMD_TYPE_BF16) {
+        if (m16)
+            gemm_lf_float_kernel<true, true><<<grid, 512, 0, s>>>(mats, nq, a_row_bytes, (const uint16_t *)Xh, n, n_pad, n_rb, n_ct);
+        else
+            gemm_lf_float_kernel<true, false><<<grid, 512, 0, s>>>(mats, nq, a_row_bytes, (const uint16_t *)Xh, n, n_pad, n_rb, n_ct);
+    } else {
+        if (m16)
+            gemm_lf_float_kernel<false, true><<<grid, 512, 0, s>>>(mats, nq, a_row_bytes, (const uint16_t *)Xh, n, n_pad, n_rb, n_ct);
+        else
+            gemm_lf_float_kernel<false, false><<<grid, 512, 0, s>>>(mats, nq, a_row_bytes, (const uint16_t *)Xh, n, n_pad, n_rb, n_ct);
+    }
     return hipGetLastError();
 }
 
