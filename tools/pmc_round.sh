@@ -45,7 +45,7 @@ for k, d in agg.items():
     c = {n: sum(v) / len(v) for n, v in d.items()}
     c["launches_sampled"] = len(next(iter(d.values())))
     cyc = c.get("GRBM_GUI_ACTIVE", 0) / 8.0  # the counter sums the 8 XCDs (MI355X_MICROARCH.md, DVFS)
-    if cyc and "SQ_INSTS_MFMA" in c:
+    if cyc and "SQ_INSTS_MFMA" in c:  # (GRBM_GUI_ACTIVE reads high on dispatches shorter than ~0.3 ms: a LOWER bound of the utilisation)
         c["kernel_cycles"] = cyc
         c["mfma_pipe_utilisation"] = c["SQ_INSTS_MFMA"] * 32.0 / 1024.0 / cyc  # 32 cycles per 32x32x16 MFMA, 1024 SIMDs
     if "FETCH_SIZE" in c:
