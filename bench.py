@@ -19,6 +19,7 @@ live with HIP events; `cpu_baseline` is the CPU restatement (oracle, kind "port"
 from __future__ import annotations
 
 import argparse
+import datetime
 import ctypes as C
 import json
 import os
@@ -558,7 +559,9 @@ def run():
             # the max over the ranks' clocks on gloo; its own NCCL backend (created lazily, only if ever used) is the fallback
             # should the module's communicator fail its self-test on this node.
             same_device = backend != "nccl"
-            torch.distributed.init_process_group("gloo" if same_device else "cpu:gloo,cuda:nccl", rank=rank, world_size=world)
+            # (ten minutes, not the default thirty, before a collective a lost rank never joins gives up)
+            torch.distributed.init_process_group("gloo" if same_device else "cpu:gloo,cuda:nccl", rank=rank, world_size=world,
+                                                 timeout=datetime.timedelta(seconds=600))
             try:
                 comm = make_comm(rank, world, same_device=same_device)
             except Exception as e:  # noqa: BLE001
