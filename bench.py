@@ -379,7 +379,15 @@ def make_comm(rank, world, same_device=False):
     from llamafile_amd import tp
     oneshot = int(os.environ.get("LFAMD_ONESHOT_BYTES", str((32 << 20) if same_device else 65536)))
     use_rccl = not same_device and world > 1
-    comm = tp.Comm(rank, world, use_rccl=use_rccl, oneshot_bytes=oneshot)
+    try:
+        comm = tp.Comm(rank, world, use_rccl=use_rccl, oneshot_bytes=oneshot)
+    except RuntimeError as e:  # (raised on EVERY rank when the one-shot exchange failed on any: tp.Comm votes)
+        if "one-shot peer all-reduce unavailable" not in str(e) or not use_rccl:
+            raise
+        if rank == 0:
+            print(f"bench.py: {e}: RCCL for every size", file=sys.stderr)
+        oneshot = 0
+        comm = tp.Comm(rank, world, use_rccl=True, oneshot_bytes=0)
     comm.mode = ("RCCL" if use_rccl else "no RCCL") + (f" + one-shot peer kernel <= {oneshot} B" if oneshot and world > 1 else "")
     comm.selftest = "not run"
     if oneshot and world > 1:

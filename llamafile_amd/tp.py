@@ -81,20 +81,36 @@ class Comm:
             idbuf = C.create_string_buffer(bytes(idt.numpy().tobytes()), 128)
         _hip.check(self.L.lfamd_comm_init(C.byref(self.h), rank, world, idbuf), "lfamd_comm_init")
         self.block = None
+        self.oneshot_error = None
         if oneshot_bytes and world > 1:
             nbytes = int(self.L.lfamd_oneshot_bytes(oneshot_bytes))
-            # fine-grained (uncached) device memory from the module: peers must see these stores inside a running kernel
-            self.block = C.c_void_p()
-            _hip.check(self.L.lfamd_oneshot_alloc(C.byref(self.block), nbytes), "lfamd_oneshot_alloc")
+            # fine-grained (uncached) device memory from the module: peers must see these stores inside a running kernel.
+            # Every rank takes part in BOTH exchanges whatever happens to it locally (a rank that raised between them would leave
+            # the others waiting in a collective): a local failure is carried to the vote at the end instead.
+            err = None
             hb = (C.c_char * 64)()
-            _hip.check(self.L.lfamd_oneshot_export(self.block, hb), "lfamd_oneshot_export")
+            try:
+                self.block = C.c_void_p()
+                _hip.check(self.L.lfamd_oneshot_alloc(C.byref(self.block), nbytes), "lfamd_oneshot_alloc")
+                _hip.check(self.L.lfamd_oneshot_export(self.block, hb), "lfamd_oneshot_export")
+            except Exception as e:  # noqa: BLE001
+                err = e
             mine = torch.frombuffer(bytearray(bytes(hb)), dtype=torch.uint8).clone()
             handles = [torch.empty(64, dtype=torch.uint8) for _ in range(world)]
             dist.all_gather(handles, mine, group=group)
-            allh = C.create_string_buffer(b"".join(h.numpy().tobytes() for h in handles), 64 * world)
-            _hip.check(self.L.lfamd_oneshot_attach(self.h, self.block, nbytes, allh, oneshot_bytes), "lfamd_oneshot_attach")
-            dist.all_reduce(torch.zeros(1), group=group)  # (a barrier on the CPU side) every rank's flag block is zeroed and
-            # mapped before the first all-reduce
+            if err is None:
+                try:
+                    allh = C.create_string_buffer(b"".join(h.numpy().tobytes() for h in handles), 64 * world)
+                    _hip.check(self.L.lfamd_oneshot_attach(self.h, self.block, nbytes, allh, oneshot_bytes), "lfamd_oneshot_attach")
+                except Exception as e:  # noqa: BLE001
+                    err = e
+            # the vote doubles as the CPU-side barrier: every rank's flag block is zeroed and mapped before the first all-reduce
+            vote = torch.tensor([0.0 if err is None else 1.0])
+            dist.all_reduce(vote, group=group)
+            if float(vote.item()) != 0.0:
+                self.oneshot_error = err if err is not None else RuntimeError("the one-shot exchange failed on another rank")
+                self.close()  # (every rank raises here: the caller may build an RCCL-only communicator instead)
+                raise RuntimeError(f"one-shot peer all-reduce unavailable on this node ({self.oneshot_error})")
 
     def allreduce_add(self, partial, residual=None, out=None):
         """out = residual + sum over ranks of partial (f32, on the current stream)."""
