@@ -1,4 +1,4 @@
-"""development: s_memtime sums of the Q8_0 loader-wave batch body (an LF_STAMPS build of gemm_lf.hip through LFAMD_HIP_SO): compute
+"""development: s_memtime sums of the Q8_0 loader-wave batch body (tools/build_diag.sh gemm_lf -DLF_STAMPS=1, then LFAMD_HIP_SO): compute
 wave 0 and loader wave 4 of one work-group; where a stage's time goes (barrier wait / K-steps; vmcnt wait / barrier wait / issue)."""
 import ctypes as C, os, sys, numpy as np, torch
 sys.path.insert(0, ".")
